@@ -1,0 +1,178 @@
+"""
+ctypes binding of libibo_hip.so (include/ibo_abi.h).
+
+The library is the product's ONLY compute path: if it is missing this module
+raises at import, and every compute call raises IBOError(IBO_ERR_NO_DEVICE)
+when no MI355X is visible.  Nothing here falls back to NumPy.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("IBO_HIP_LIB", os.path.join(_HERE, "libibo_hip.so"))
+
+OK, ERR_ARG, ERR_HIP, ERR_NOT_PD, ERR_STATE, ERR_NO_DEVICE, ERR_COMM = range(7)
+K_SE_ARD, K_SE_ISO, K_MATERN3, K_MATERN5 = 0, 1, 2, 3
+ACQ_EI, ACQ_PI, ACQ_UCB, ACQ_NONE = 0, 1, 2, 3
+ERF_LIBM, ERF_NR = 0, 1
+DIAG_UNIT_PLUS_NOISE, DIAG_KERNEL_PLUS_NOISE = 0, 1
+CLAMP_NATIVE = 1e-8      # cpp/optimizeGP.cpp:150-153
+CLAMP_PY = 10e-8         # ego/gaussianprocess/__init__.py:224
+COMM_ID_BYTES = 128
+
+_DP = POINTER(c_double)
+OBJECTIVE = ctypes.CFUNCTYPE(c_double, c_int, _DP)
+
+
+class IBOError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libibo_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NotPositiveDefinite(IBOError, np.linalg.LinAlgError):
+    """raised where the reference's numpy.linalg.cholesky raises LinAlgError"""
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "ibo_amd: %s not found. Build it with `make -C ibo_amd/csrc` (or __graft_entry__.build()); "
+        "there is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_sig("ibo_abi_version", c_int)
+_sig("ibo_last_error", c_char_p)
+_sig("ibo_device_count", c_int, POINTER(c_int))
+_sig("ibo_device_name", c_int, c_int, c_char_p, c_size_t)
+_sig("ibo_selftest_mfma", c_int, c_int, _DP)
+_sig("ibo_set_option", c_int, c_char_p, c_int)
+_sig("ibo_dev_alloc", c_int, c_int, c_size_t, POINTER(c_void_p))
+_sig("ibo_dev_free", c_int, c_int, c_void_p)
+_sig("ibo_memcpy_h2d", c_int, c_int, c_void_p, c_void_p, c_size_t)
+_sig("ibo_memcpy_d2h", c_int, c_int, c_void_p, c_void_p, c_size_t)
+_sig("ibo_device_synchronize", c_int, c_int)
+_sig("ibo_gp_create", c_int, c_int, POINTER(c_void_p))
+_sig("ibo_gp_destroy", c_int, c_void_p)
+_sig("ibo_gp_fit", c_int, c_void_p, c_int, c_int, c_int, _DP, _DP, _DP, c_int, c_double, c_double, POINTER(c_int))
+_sig("ibo_gp_fit_with_matrix", c_int, c_void_p, c_int, c_int, c_int, _DP, _DP, _DP, c_int, c_double, c_double,
+     _DP, POINTER(c_int))
+_sig("ibo_gp_set_y", c_int, c_void_p, _DP)
+_sig("ibo_gp_set_kstar_sf2", c_int, c_void_p, c_double)
+_sig("ibo_gp_set_prior", c_int, c_void_p, c_int, _DP, _DP, c_double, _DP, _DP)
+_sig("ibo_gp_get_R", c_int, c_void_p, _DP)
+_sig("ibo_gp_get_L", c_int, c_void_p, _DP)
+_sig("ibo_gp_get_W", c_int, c_void_p, _DP)
+_sig("ibo_gp_info", c_int, c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), _DP)
+_sig("ibo_gp_last_fit_ms", c_int, c_void_p, POINTER(c_float))
+_sig("ibo_cov_matrix", c_int, c_int, c_int, c_int, _DP, c_int, c_double, c_int, _DP, c_int, _DP, c_int, c_double, _DP)
+_sig("ibo_posterior_batch", c_int, c_void_p, c_int64, _DP, c_double, _DP, _DP)
+_sig("ibo_acq_sweep", c_int, c_void_p, c_int64, c_void_p, c_int, c_double, c_int, c_double, c_double,
+     c_int, _DP, c_double, c_int64, c_void_p, c_void_p, c_void_p, _DP, POINTER(c_int64))
+_sig("ibo_last_sweep_kernel_ms", c_int, c_void_p, POINTER(c_float), POINTER(c_char_p))
+_sig("ibo_direct_max", c_int, c_void_p, c_int, _DP, _DP, c_int, c_double, c_int, c_double, c_int, c_int, c_int,
+     c_int, _DP, _DP, POINTER(c_int64))
+_sig("ibo_direct_host", c_int, OBJECTIVE, c_int, _DP, _DP, c_int, c_int, c_int, c_int, _DP, _DP, POINTER(c_int64))
+_sig("ibo_nlml_grid", c_int, c_int, c_int, c_int, c_int, _DP, _DP, c_int, _DP, c_int, _DP, c_double, _DP)
+_sig("ibo_comm_get_unique_id", c_int, c_char_p)
+_sig("ibo_comm_init", c_int, c_int, c_int, c_int, c_char_p, POINTER(c_void_p))
+_sig("ibo_comm_destroy", c_int, c_void_p)
+_sig("ibo_comm_argmax", c_int, c_void_p, c_double, c_int64, _DP, c_int, _DP, POINTER(c_int64), _DP, POINTER(c_int))
+_sig("ibo_comm_barrier", c_int, c_void_p)
+# legacy libego symbols (kept so the .so is a drop-in under the reference's own ctypes code)
+_sig("acqmaxGP", _DP, c_int, _DP, _DP, _DP, _DP, _DP, c_int, c_int, c_int, _DP, c_int, _DP, _DP, c_double, _DP, _DP,
+     c_double, c_double, c_int, c_int, c_int)
+_sig("direct", _DP, OBJECTIVE, c_int, _DP, _DP, c_int, c_int, c_int)
+
+EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device_name", "ibo_selftest_mfma",
+            "ibo_set_option", "ibo_dev_alloc", "ibo_dev_free", "ibo_memcpy_h2d", "ibo_memcpy_d2h",
+            "ibo_device_synchronize", "ibo_gp_create", "ibo_gp_destroy", "ibo_gp_fit", "ibo_gp_fit_with_matrix",
+            "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
+            "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_posterior_batch",
+            "ibo_acq_sweep", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_host", "ibo_nlml_grid",
+            "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_argmax", "ibo_comm_barrier",
+            "acqmaxGP", "direct"]
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = lib.ibo_last_error().decode("utf-8", "replace")
+    if rc == ERR_NOT_PD:
+        raise NotPositiveDefinite(rc, msg)
+    raise IBOError(rc, msg)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dp(a):
+    return a.ctypes.data_as(_DP)
+
+
+def device_count():
+    n = c_int(0)
+    check(lib.ibo_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def default_device():
+    return int(os.environ.get("IBO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+class DeviceArray(object):
+    """A (M, D) fp64 array resident in HBM (candidate sets, per-candidate outputs)."""
+
+    def __init__(self, shape, device=None):
+        self.device = default_device() if device is None else device
+        self.shape = tuple(int(s) for s in shape)
+        self.nbytes = int(np.prod(self.shape)) * 8
+        p = c_void_p()
+        check(lib.ibo_dev_alloc(self.device, self.nbytes, ctypes.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, a, device=None):
+        a = f64(a)
+        d = cls(a.shape, device)
+        check(lib.ibo_memcpy_h2d(d.device, d.ptr, a.ctypes.data_as(c_void_p), d.nbytes))
+        return d
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        check(lib.ibo_memcpy_d2h(self.device, out.ctypes.data_as(c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def view_rows(self, start, stop):
+        """non-owning view of rows [start, stop) (row-major)"""
+        v = object.__new__(DeviceArray)
+        row = int(np.prod(self.shape[1:])) * 8 if len(self.shape) > 1 else 8
+        v.device = self.device
+        v.shape = (stop - start,) + self.shape[1:]
+        v.nbytes = (stop - start) * row
+        v.ptr = c_void_p(self.ptr.value + start * row)
+        v._base = self
+        return v
+
+    def free(self):
+        if getattr(self, "ptr", None) is not None and not hasattr(self, "_base"):
+            try:
+                lib.ibo_dev_free(self.device, self.ptr)
+            except Exception:
+                pass
+        self.ptr = None
+
+    def __del__(self):
+        self.free()

@@ -1,0 +1,717 @@
+// abi.hip -- the C ABI of libibo_hip.so (include/ibo_abi.h): handle management,
+// fit orchestration, sweep / posterior entry points, DIRECT on the GPU
+// objective, the marginal-likelihood grid and the legacy libego symbols.
+// There is no CPU fallback anywhere in this file: without a gfx950 device every
+// compute entry point returns IBO_ERR_NO_DEVICE.
+#include "../../include/ibo_abi.h"
+#include "ibo_common.h"
+#include "direct_host.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(IBO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define KERNEL_TRY(expr)                                                                      \
+    do {                                                                                      \
+        int e_ = (expr);                                                                      \
+        if (e_ != 0)                                                                          \
+            return fail(IBO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); \
+    } while (0)
+#define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
+
+static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
+
+static int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(IBO_ERR_NO_DEVICE, "no HIP device visible (%s); libibo_hip has no CPU fallback",
+                    e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(IBO_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    static bool env_read = false;
+    if (!env_read) {
+        const char *s = getenv("IBO_SWEEP_IMPL");
+        if (s && !strcmp(s, "gemv")) g_force_path = 1;
+        if (s && !strcmp(s, "mfma")) g_force_path = 2;
+        env_read = true;
+    }
+    return IBO_OK;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return IBO_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess) return fail(IBO_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        cap = n;
+        return IBO_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ibo_gp {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, fit0 = nullptr, fit1 = nullptr;
+    bool fitted = false;
+    int N = 0, D = 0, Npad = 0, DP = 0;
+    bool reversed = false;          // legacy invR path stores the observations in reverse order
+    KParams kp;
+    double noise = 0.0, maxY = 0.0;
+    float fit_ms = 0.f, sweep_ms = 0.f;
+    const char *sweep_kernel = "";
+    std::vector<double> Yhost;
+    DevBuf<double> Xp, Y, R, A, L, W, T, Wp, diag64, alphaY, alpha1, tmp, cand, outs, excl, qpart, mupart, partv, res_v;
+    DevBuf<int64_t> parti, res_i;
+    DevBuf<int> info;
+    // prior
+    int nb = 0; double ptheta = 0.0;
+    DevBuf<double> pmeans, pbeta, plowerb, pwidth;
+};
+
+// ------------------------------------------------------------------------ library
+extern "C" int ibo_abi_version(void) { return IBO_ABI_VERSION; }
+extern "C" const char *ibo_last_error(void) { return g_err; }
+
+extern "C" int ibo_device_count(int *count)
+{
+    if (!count) return fail(IBO_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return IBO_OK;
+}
+
+extern "C" int ibo_device_name(int device, char *buf, size_t buflen)
+{
+    if (!buf || !buflen) return fail(IBO_ERR_ARG, "buf is NULL");
+    IBO_TRY(use_device(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s %s cu=%d clk=%dMHz", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+             prop.clockRate / 1000);
+    return IBO_OK;
+}
+
+extern "C" int ibo_set_option(const char *key, int value)
+{
+    if (key && !strcmp(key, "sweep_path")) { g_force_path = value; return IBO_OK; }
+    return fail(IBO_ERR_ARG, "unknown option");
+}
+
+extern "C" int ibo_selftest_mfma(int device, double *max_abs_err)
+{
+    IBO_TRY(use_device(device));
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(double)));
+    KERNEL_TRY(launch_mfma_selftest(d, nullptr));
+    double h = -1.0;
+    HIP_TRY(hipMemcpy(&h, d, sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    if (max_abs_err) *max_abs_err = h;
+    if (h != 0.0) return fail(IBO_ERR_HIP, "fp64 MFMA fragment layout self-test failed: max |err| = %g", h);
+    return IBO_OK;
+}
+
+// ------------------------------------------------------------------------ device memory
+extern "C" int ibo_dev_alloc(int device, size_t bytes, void **dev_ptr)
+{
+    if (!dev_ptr) return fail(IBO_ERR_ARG, "dev_ptr is NULL");
+    IBO_TRY(use_device(device));
+    HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 8));
+    return IBO_OK;
+}
+extern "C" int ibo_dev_free(int device, void *dev_ptr)
+{
+    IBO_TRY(use_device(device));
+    if (dev_ptr) HIP_TRY(hipFree(dev_ptr));
+    return IBO_OK;
+}
+extern "C" int ibo_memcpy_h2d(int device, void *dev_dst, const void *host_src, size_t bytes)
+{
+    IBO_TRY(use_device(device));
+    HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return IBO_OK;
+}
+extern "C" int ibo_memcpy_d2h(int device, void *host_dst, const void *dev_src, size_t bytes)
+{
+    IBO_TRY(use_device(device));
+    HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return IBO_OK;
+}
+extern "C" int ibo_device_synchronize(int device)
+{
+    IBO_TRY(use_device(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return IBO_OK;
+}
+
+// ------------------------------------------------------------------------ model
+extern "C" int ibo_gp_create(int device, ibo_gp_t **out)
+{
+    if (!out) return fail(IBO_ERR_ARG, "out is NULL");
+    IBO_TRY(use_device(device));
+    ibo_gp *g = new ibo_gp();
+    g->device = device;
+    HIP_TRY(hipStreamCreate(&g->stream));
+    HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1));
+    HIP_TRY(hipEventCreate(&g->fit0)); HIP_TRY(hipEventCreate(&g->fit1));
+    memset(&g->kp, 0, sizeof(g->kp));
+    *out = g;
+    return IBO_OK;
+}
+
+extern "C" int ibo_gp_destroy(ibo_gp_t *g)
+{
+    if (!g) return IBO_OK;
+    (void)hipSetDevice(g->device);
+    (void)hipStreamSynchronize(g->stream);
+    g->Xp.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
+    g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
+    g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
+    g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release();
+    g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
+    (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
+    (void)hipEventDestroy(g->fit0); (void)hipEventDestroy(g->fit1);
+    (void)hipStreamDestroy(g->stream);
+    delete g;
+    return IBO_OK;
+}
+
+static int make_kparams(int ktype, int D, const double *hyper, int nhyper, double sf2, KParams *kp)
+{
+    if (D < 1 || D > IBO_DMAX) return fail(IBO_ERR_ARG, "D=%d unsupported (1..%d)", D, IBO_DMAX);
+    if (!hyper) return fail(IBO_ERR_ARG, "hyper is NULL");
+    memset(kp, 0, sizeof(*kp));
+    kp->D = D; kp->sf2 = sf2;
+    switch (ktype) {
+    case IBO_K_SE_ARD:
+        if (nhyper < D) return fail(IBO_ERR_ARG, "SE-ARD needs %d length scales, got %d", D, nhyper);
+        kp->family = FAM_SE;
+        for (int d = 0; d < D; d++) kp->w[d] = 1.0 / (hyper[d] * hyper[d]);
+        break;
+    case IBO_K_SE_ISO:
+    case IBO_K_MATERN3:
+    case IBO_K_MATERN5:
+        if (nhyper < 1) return fail(IBO_ERR_ARG, "kernel needs a length scale");
+        kp->family = ktype == IBO_K_SE_ISO ? FAM_SE : (ktype == IBO_K_MATERN3 ? FAM_M3 : FAM_M5);
+        for (int d = 0; d < D; d++) kp->w[d] = 1.0 / (hyper[0] * hyper[0]);
+        break;
+    default:
+        return fail(IBO_ERR_ARG, "unknown kernel type %d", ktype);
+    }
+    return IBO_OK;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// stage observations (optionally in reverse order) and size every buffer
+static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y, bool reverse)
+{
+    if (N < 1) return fail(IBO_ERR_ARG, "N=%d", N);
+    if (!X || !Y) return fail(IBO_ERR_ARG, "X/Y is NULL");
+    g->N = N; g->D = D; g->Npad = round_up(N, 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
+    g->reversed = reverse;
+    const int Np = g->Npad, DP = g->DP;
+    size_t nn = (size_t)Np * Np;
+    IBO_TRY(g->Xp.ensure((size_t)Np * DP)); IBO_TRY(g->Y.ensure(Np));
+    IBO_TRY(g->R.ensure((size_t)N * N)); IBO_TRY(g->L.ensure(nn)); IBO_TRY(g->W.ensure(nn));
+    IBO_TRY(g->T.ensure(nn)); IBO_TRY(g->Wp.ensure(nn)); IBO_TRY(g->diag64.ensure((size_t)(Np / 64) * 4096));
+    IBO_TRY(g->alphaY.ensure(Np)); IBO_TRY(g->alpha1.ensure(Np));
+    IBO_TRY(g->tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));
+    IBO_TRY(g->info.ensure(1));
+    std::vector<double> xp((size_t)Np * DP, 0.0), yp(Np, 0.0);
+    g->Yhost.assign(N, 0.0);
+    double my = Y[0];
+    for (int i = 0; i < N; i++) {
+        int s = reverse ? N - 1 - i : i;
+        for (int d = 0; d < D; d++) xp[(size_t)i * DP + d] = X[(size_t)s * D + d];
+        yp[i] = Y[s];
+        g->Yhost[i] = Y[s];
+        if (Y[i] > my) my = Y[i];      // acqmaxGP's maxY scan, cpp/optimizeGP.cpp:316-321
+    }
+    g->maxY = my;
+    HIP_TRY(hipMemcpyAsync(g->Xp.p, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(g->Y.p, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));      // xp/yp go out of scope
+    return IBO_OK;
+}
+
+static int check_info(ibo_gp *g, int *info)
+{
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, g->info.p, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (info) *info = h;
+    if (h != 0) {
+        g->fitted = false;
+        return fail(IBO_ERR_NOT_PD, "matrix is not positive definite (pivot %d)", h);
+    }
+    return IBO_OK;
+}
+
+static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const double *Y,
+                    const double *hyper, int nhyper, double sf2, double noise, const double *A_host, int *info)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    IBO_TRY(use_device(g->device));
+    KParams kp;
+    IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
+    g->fitted = false;
+    IBO_TRY(stage_data(g, N, D, X, Y, false));
+    g->kp = kp; g->noise = noise;
+    const int Np = g->Npad;
+    hipStream_t s = g->stream;
+    if (A_host) {
+        IBO_TRY(g->A.ensure((size_t)N * N));
+        HIP_TRY(hipMemcpyAsync(g->A.p, A_host, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipEventRecord(g->fit0, s));
+    KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, N, s));
+    KERNEL_TRY(launch_pad_copy(A_host ? g->A.p : g->R.p, N, N, g->L.p, Np, 1.0, s));
+    KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s));
+    KERNEL_TRY(launch_zero_upper(g->L.p, Np, s));
+    KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s));
+    KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));
+    KERNEL_TRY(launch_alpha(g->W.p, N, Np, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, s));
+    HIP_TRY(hipEventRecord(g->fit1, s));
+    IBO_TRY(check_info(g, info));
+    HIP_TRY(hipEventElapsedTime(&g->fit_ms, g->fit0, g->fit1));
+    g->fitted = true;
+    return IBO_OK;
+}
+
+extern "C" int ibo_gp_fit(ibo_gp_t *g, int ktype, int N, int D, const double *X, const double *Y,
+                          const double *hyper, int nhyper, double sf2, double noise, int *info)
+{
+    return fit_impl(g, ktype, N, D, X, Y, hyper, nhyper, sf2, noise, nullptr, info);
+}
+
+extern "C" int ibo_gp_fit_with_matrix(ibo_gp_t *g, int ktype, int N, int D, const double *X, const double *Y,
+                                      const double *hyper, int nhyper, double sf2, double noise,
+                                      const double *A_host, int *info)
+{
+    if (!A_host) return fail(IBO_ERR_ARG, "A_host is NULL");
+    return fit_impl(g, ktype, N, D, X, Y, hyper, nhyper, sf2, noise, A_host, info);
+}
+
+// legacy entry: the caller hands over invR (ego/acquisition/__init__.py:385-388).
+// invR = G G^T; q = |G^T k*|^2; reversing the index order makes G^T lower
+// triangular so the same sweep kernel applies (see pack_w_kernel, mode 1).
+static int fit_from_inverse(ibo_gp *g, int ktype, int N, int D, const double *X, const double *Y,
+                            const double *hyper, int nhyper, double sf2, double noise, const double *invR)
+{
+    IBO_TRY(use_device(g->device));
+    KParams kp;
+    IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
+    g->fitted = false;
+    IBO_TRY(stage_data(g, N, D, X, Y, true));
+    g->kp = kp; g->noise = noise;
+    const int Np = g->Npad;
+    hipStream_t s = g->stream;
+    IBO_TRY(g->A.ensure((size_t)N * N));
+    HIP_TRY(hipMemcpyAsync(g->A.p, invR, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(g->fit0, s));
+    KERNEL_TRY(launch_pad_copy(g->A.p, N, N, g->L.p, Np, 1.0, s));
+    KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s));
+    KERNEL_TRY(launch_pack_w(g->L.p, N, Np, 1, g->W.p, g->Wp.p, s));
+    KERNEL_TRY(launch_alpha(g->W.p, N, Np, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, s));
+    HIP_TRY(hipEventRecord(g->fit1, s));
+    IBO_TRY(check_info(g, nullptr));
+    HIP_TRY(hipEventElapsedTime(&g->fit_ms, g->fit0, g->fit1));
+    g->fitted = true;
+    return IBO_OK;
+}
+
+extern "C" int ibo_gp_set_y(ibo_gp_t *g, const double *Y_host)
+{
+    if (!g || !Y_host) return fail(IBO_ERR_ARG, "NULL argument");
+    if (!g->fitted) return fail(IBO_ERR_STATE, "set_y before fit");
+    IBO_TRY(use_device(g->device));
+    std::vector<double> yp(g->Npad, 0.0);
+    double my = Y_host[0];
+    for (int i = 0; i < g->N; i++) {
+        yp[i] = Y_host[g->reversed ? g->N - 1 - i : i];
+        g->Yhost[i] = yp[i];
+        if (Y_host[i] > my) my = Y_host[i];
+    }
+    g->maxY = my;
+    HIP_TRY(hipMemcpyAsync(g->Y.p, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    KERNEL_TRY(launch_alpha(g->W.p, g->N, g->Npad, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return IBO_OK;
+}
+
+extern "C" int ibo_gp_set_kstar_sf2(ibo_gp_t *g, double sf2)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    g->kp.sf2 = sf2;
+    return IBO_OK;
+}
+
+extern "C" int ibo_gp_set_prior(ibo_gp_t *g, int nb, const double *means, const double *beta, double theta,
+                                const double *lowerb, const double *width)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    if (nb <= 0) { g->nb = 0; return IBO_OK; }
+    if (g->D <= 0) return fail(IBO_ERR_STATE, "set_prior before fit (dimension unknown)");
+    if (!means || !beta || !lowerb || !width) return fail(IBO_ERR_ARG, "NULL prior array");
+    IBO_TRY(use_device(g->device));
+    const int D = g->D;
+    IBO_TRY(g->pmeans.ensure((size_t)nb * D)); IBO_TRY(g->pbeta.ensure(nb));
+    IBO_TRY(g->plowerb.ensure(D)); IBO_TRY(g->pwidth.ensure(D));
+    HIP_TRY(hipMemcpy(g->pmeans.p, means, sizeof(double) * nb * D, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->pbeta.p, beta, sizeof(double) * nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->plowerb.p, lowerb, sizeof(double) * D, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->pwidth.p, width, sizeof(double) * D, hipMemcpyHostToDevice));
+    g->nb = nb; g->ptheta = theta;
+    return IBO_OK;
+}
+
+static int copy_square(ibo_gp *g, const double *src, int ld, double *dst_host)
+{
+    IBO_TRY(use_device(g->device));
+    HIP_TRY(hipMemcpy2D(dst_host, sizeof(double) * g->N, src, sizeof(double) * ld, sizeof(double) * g->N, g->N,
+                        hipMemcpyDeviceToHost));
+    return IBO_OK;
+}
+
+extern "C" int ibo_gp_get_R(ibo_gp_t *g, double *R_host)
+{
+    if (!g || !R_host) return fail(IBO_ERR_ARG, "NULL argument");
+    if (!g->fitted || g->reversed) return fail(IBO_ERR_STATE, "R not available");
+    return copy_square(g, g->R.p, g->N, R_host);
+}
+extern "C" int ibo_gp_get_L(ibo_gp_t *g, double *L_host)
+{
+    if (!g || !L_host) return fail(IBO_ERR_ARG, "NULL argument");
+    if (!g->fitted || g->reversed) return fail(IBO_ERR_STATE, "L not available");
+    return copy_square(g, g->L.p, g->Npad, L_host);
+}
+extern "C" int ibo_gp_get_W(ibo_gp_t *g, double *W_host)
+{
+    if (!g || !W_host) return fail(IBO_ERR_ARG, "NULL argument");
+    if (!g->fitted || g->reversed) return fail(IBO_ERR_STATE, "W not available");
+    return copy_square(g, g->W.p, g->Npad, W_host);
+}
+extern "C" int ibo_gp_info(ibo_gp_t *g, int *N, int *D, int *device, double *max_y)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    if (N) *N = g->N;
+    if (D) *D = g->D;
+    if (device) *device = g->device;
+    if (max_y) *max_y = g->maxY;
+    return IBO_OK;
+}
+extern "C" int ibo_gp_last_fit_ms(ibo_gp_t *g, float *ms)
+{
+    if (!g || !ms) return fail(IBO_ERR_ARG, "NULL argument");
+    *ms = g->fit_ms;
+    return IBO_OK;
+}
+
+extern "C" int ibo_cov_matrix(int device, int ktype, int D, const double *hyper, int nhyper, double sf2,
+                              int n1, const double *A1, int n2, const double *A2, int diag_rule, double noise,
+                              double *K_host)
+{
+    if (!A1 || !K_host || n1 < 1) return fail(IBO_ERR_ARG, "bad argument");
+    IBO_TRY(use_device(device));
+    KParams kp;
+    IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
+    int m2 = A2 ? n2 : n1;
+    DevBuf<double> a1, a2, k;
+    IBO_TRY(a1.ensure((size_t)n1 * D)); IBO_TRY(k.ensure((size_t)n1 * m2));
+    HIP_TRY(hipMemcpy(a1.p, A1, sizeof(double) * n1 * D, hipMemcpyHostToDevice));
+    if (A2) {
+        IBO_TRY(a2.ensure((size_t)n2 * D));
+        HIP_TRY(hipMemcpy(a2.p, A2, sizeof(double) * n2 * D, hipMemcpyHostToDevice));
+    }
+    KERNEL_TRY(launch_cov_matrix(kp, n1, a1.p, n2, A2 ? a2.p : nullptr, D, diag_rule, noise, k.p, m2, nullptr));
+    HIP_TRY(hipMemcpy(K_host, k.p, sizeof(double) * (size_t)n1 * m2, hipMemcpyDeviceToHost));
+    a1.release(); a2.release(); k.release();
+    return IBO_OK;
+}
+
+// ------------------------------------------------------------------------ sweep
+static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
+                     double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,
+                     int64_t index_base, double *mu_dev, double *s2_dev, double *acq_dev,
+                     double *best_val, int64_t *best_idx)
+{
+    if (!g->fitted) return fail(IBO_ERR_STATE, "sweep before a successful fit");
+    if (M < 1 || !cand_dev) return fail(IBO_ERR_ARG, "empty candidate set");
+    if (acq < 0 || acq > 3) return fail(IBO_ERR_ARG, "unknown acquisition %d", acq);
+    hipStream_t s = g->stream;
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.kp = g->kp; a.N = g->N; a.Npad = g->Npad; a.DP = g->DP; a.M = M;
+    a.Xp = g->Xp.p; a.W = g->W.p; a.Wp = g->Wp.p; a.alphaY = g->alphaY.p; a.alpha1 = g->alpha1.p;
+    a.cand = cand_dev;
+    a.prior.nb = g->nb; a.prior.theta = g->ptheta; a.prior.means = g->pmeans.p; a.prior.beta = g->pbeta.p;
+    a.prior.lowerb = g->plowerb.p; a.prior.width = g->pwidth.p;
+    a.noise = g->noise; a.clamp_lo = clamp_lo; a.ymax = (ymax == ymax) ? ymax : g->maxY; a.parm = parm;
+    a.acq = acq; a.erf_mode = erf_mode;
+    a.n_excl = 0; a.excl_radius = excl_radius;
+    if (n_excl > 0) {
+        if (!excl_host) return fail(IBO_ERR_ARG, "excl_host is NULL");
+        IBO_TRY(g->excl.ensure((size_t)n_excl * g->D));
+        HIP_TRY(hipMemcpyAsync(g->excl.p, excl_host, sizeof(double) * n_excl * g->D, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        a.n_excl = n_excl; a.excl = g->excl.p;
+    }
+    a.index_base = index_base;
+    a.out_mu = mu_dev; a.out_s2 = s2_dev; a.out_acq = acq_dev;
+    int64_t ntiles = (M + 63) / 64;
+    IBO_TRY(g->partv.ensure(ntiles)); IBO_TRY(g->parti.ensure(ntiles));
+    IBO_TRY(g->res_v.ensure(1)); IBO_TRY(g->res_i.ensure(1));
+    a.part_val = g->partv.p; a.part_idx = g->parti.p; a.result_val = g->res_v.p; a.result_idx = g->res_i.p;
+    bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16);
+    if (gemv) {
+        IBO_TRY(g->qpart.ensure((size_t)(g->Npad / 64) * M)); IBO_TRY(g->mupart.ensure(2 * (size_t)M));
+        a.qpart = g->qpart.p; a.mupart = g->mupart.p;
+        KERNEL_TRY(launch_sweep_gemv(a, s, g->ev0, g->ev1));
+        g->sweep_kernel = "sweep_gemv_kernel";
+    } else {
+        KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
+        g->sweep_kernel = "sweep_mfma_kernel";
+    }
+    double hv; int64_t hi;
+    HIP_TRY(hipMemcpyAsync(&hv, g->res_v.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&hi, g->res_i.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventElapsedTime(&g->sweep_ms, g->ev0, g->ev1));
+    if (best_val) *best_val = hv;
+    if (best_idx) *best_idx = hi;
+    return IBO_OK;
+}
+
+extern "C" int ibo_acq_sweep(ibo_gp_t *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
+                             double clamp_lo, double ymax, int n_excl, const double *excl_host,
+                             double excl_radius, int64_t index_base, double *mu_dev, double *s2_dev,
+                             double *acq_dev, double *best_val, int64_t *best_idx)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    IBO_TRY(use_device(g->device));
+    return run_sweep(g, M, cand_dev, acq, parm, erf_mode, clamp_lo, ymax, n_excl, excl_host, excl_radius,
+                     index_base, mu_dev, s2_dev, acq_dev, best_val, best_idx);
+}
+
+extern "C" int ibo_last_sweep_kernel_ms(ibo_gp_t *g, float *ms, const char **kernel_name)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    if (ms) *ms = g->sweep_ms;
+    if (kernel_name) *kernel_name = g->sweep_kernel;
+    return IBO_OK;
+}
+
+// host-in / host-out evaluation of M points: values of one acquisition (or the
+// posterior) -- used by posterior_batch and by DIRECT's batches
+static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq, double parm, int erf_mode,
+                            double clamp_lo, double *mu_host, double *s2_host, double *acq_host)
+{
+    IBO_TRY(g->cand.ensure((size_t)M * g->D));
+    IBO_TRY(g->outs.ensure(3 * (size_t)M));
+    hipStream_t s = g->stream;
+    HIP_TRY(hipMemcpyAsync(g->cand.p, Q_host, sizeof(double) * M * g->D, hipMemcpyHostToDevice, s));
+    double *dmu = g->outs.p, *ds2 = g->outs.p + M, *dacq = g->outs.p + 2 * M;
+    IBO_TRY(run_sweep(g, M, g->cand.p, acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0,
+                      mu_host ? dmu : nullptr, s2_host ? ds2 : nullptr, acq_host ? dacq : nullptr, nullptr, nullptr));
+    if (mu_host) HIP_TRY(hipMemcpyAsync(mu_host, dmu, sizeof(double) * M, hipMemcpyDeviceToHost, s));
+    if (s2_host) HIP_TRY(hipMemcpyAsync(s2_host, ds2, sizeof(double) * M, hipMemcpyDeviceToHost, s));
+    if (acq_host) HIP_TRY(hipMemcpyAsync(acq_host, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return IBO_OK;
+}
+
+extern "C" int ibo_posterior_batch(ibo_gp_t *g, int64_t M, const double *Q_host, double clamp_lo,
+                                   double *mu_host, double *s2_host)
+{
+    if (!g || !Q_host || !mu_host) return fail(IBO_ERR_ARG, "NULL argument");
+    if (M < 1) return fail(IBO_ERR_ARG, "M=%lld", (long long)M);
+    IBO_TRY(use_device(g->device));
+    if (!g->fitted) return fail(IBO_ERR_STATE, "posterior before a successful fit");
+    return eval_host_points(g, M, Q_host, IBO_ACQ_NONE, 0.0, IBO_ERF_LIBM, clamp_lo, mu_host, s2_host, nullptr);
+}
+
+// ------------------------------------------------------------------------ DIRECT on the GPU objective
+static int direct_on_gp(ibo_gp *g, int D, const double *lb, const double *ub, int acq, double parm, int erf_mode,
+                        double clamp_lo, int maxiter, int maxtime, int maxsample, int compat,
+                        double *opt, double *optx, int64_t *nsamples)
+{
+    if (D != g->D) return fail(IBO_ERR_ARG, "bounds have %d dimensions, model has %d", D, g->D);
+    std::vector<double> neg;
+    ibo::batch_eval_t ev = [&](const double *pts, int n, double *vals) -> int {
+        int rc = eval_host_points(g, n, pts, acq, parm, erf_mode, clamp_lo, nullptr, nullptr, vals);
+        if (rc) return rc;
+        for (int i = 0; i < n; i++) vals[i] = -vals[i];     // DIRECT minimises the negated acquisition
+        return 0;
+    };
+    ibo::DirectOptions o;
+    o.maxiter = maxiter; o.maxtime = maxtime; o.maxsample = maxsample; o.compat = compat != 0;
+    o.per_rectangle = false;
+    ibo::DirectResult r = ibo::direct_minimize(ev, D, lb, ub, o);
+    if (r.status) return r.status;
+    if (opt) *opt = -r.fmin;
+    if (optx) for (int i = 0; i < D; i++) optx[i] = r.xmin[i];
+    if (nsamples) *nsamples = r.nsamples;
+    return IBO_OK;
+}
+
+extern "C" int ibo_direct_max(ibo_gp_t *g, int D, const double *lb, const double *ub, int acq, double parm,
+                              int erf_mode, double clamp_lo, int maxiter, int maxtime, int maxsample,
+                              int compat, double *opt, double *optx, int64_t *nsamples)
+{
+    if (!g || !lb || !ub) return fail(IBO_ERR_ARG, "NULL argument");
+    if (acq < 0 || acq > 2) return fail(IBO_ERR_ARG, "unknown acquisition %d", acq);
+    IBO_TRY(use_device(g->device));
+    if (!g->fitted) return fail(IBO_ERR_STATE, "direct before a successful fit");
+    return direct_on_gp(g, D, lb, ub, acq, parm, erf_mode, clamp_lo, maxiter, maxtime, maxsample, compat,
+                        opt, optx, nsamples);
+}
+
+// ------------------------------------------------------------------------ marginal-likelihood grid
+extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *X, const double *Y,
+                             int n_theta, const double *thetas, int nhyper, const double *sf2s, double noise,
+                             double *nlml_host)
+{
+    if (!X || !Y || !thetas || !nlml_host || N < 1 || n_theta < 1) return fail(IBO_ERR_ARG, "bad argument");
+    IBO_TRY(use_device(device));
+    const int Np = round_up(N, 64);
+    DevBuf<double> dX, dY, dK, dL, d64, dz, dout;
+    DevBuf<int> dinfo;
+    IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N)); IBO_TRY(dK.ensure((size_t)N * N));
+    IBO_TRY(dL.ensure((size_t)Np * Np)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096)); IBO_TRY(dz.ensure(Np));
+    IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
+    for (int t = 0; t < n_theta; t++) {
+        KParams kp;
+        IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
+        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dK.p, N, s));
+        KERNEL_TRY(launch_pad_copy(dK.p, N, N, dL.p, Np, 1.0, s));
+        KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p + t, s));
+        KERNEL_TRY(launch_fwd_quad_logdet(dL.p, N, Np, d64.p, dY.p, dz.p, dout.p + 2 * t, s));
+    }
+    std::vector<double> out(2 * (size_t)n_theta);
+    std::vector<int> info(n_theta);
+    HIP_TRY(hipMemcpy(out.data(), dout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(info.data(), dinfo.p, sizeof(int) * n_theta, hipMemcpyDeviceToHost));
+    const double half_log_2pi_n = 0.5 * N * log(2.0 * M_PI);
+    for (int t = 0; t < n_theta; t++)
+        nlml_host[t] = info[t] ? NAN : 0.5 * out[2 * t] + out[2 * t + 1] + half_log_2pi_n;
+    dX.release(); dY.release(); dK.release(); dL.release(); d64.release(); dz.release(); dout.release(); dinfo.release();
+    return IBO_OK;
+}
+
+// ------------------------------------------------------------------------ legacy libego symbols
+extern "C" const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR, double *X, double *Y, int nx,
+                                  int acqfunc, int kerneltype, double *hyperparams, int npbases,
+                                  double *pbasismeans, double *pbasisbeta, double pbasistheta,
+                                  double *pbasislowerb, double *pbasiswidth, double parm, double noise,
+                                  int maxiter, int maxtime, int maxsample)
+{
+    if (acqfunc < 0 || acqfunc > 2) {
+        printf("[C++] unknown acquisition function\n");     // cpp/optimizeGP.cpp:342-345
+        return NULL;
+    }
+    ibo_gp *g = nullptr;
+    int dev = 0;
+    const char *e = getenv("IBO_DEVICE");
+    if (e) dev = atoi(e);
+    if (ibo_gp_create(dev, &g) != IBO_OK) { fprintf(stderr, "[libibo_hip] %s\n", g_err); return NULL; }
+    // sf2: 1 for kernel types 0-2; magnitude^2 for Matern-5/2.  The reference reads
+    // hyperparams[ndim] there (cpp/optimizeGP.cpp:313), which is the magnitude only for
+    // ndim == 1 and out of bounds otherwise; the magnitude lives at hyperparams[1].
+    double sf2 = 1.0;
+    int nh = (kerneltype == IBO_K_SE_ARD) ? ndim : 1;
+    if (kerneltype == IBO_K_MATERN5) sf2 = hyperparams[1] * hyperparams[1];
+    double *res = nullptr;
+    int rc = fit_from_inverse(g, kerneltype, nx, ndim, X, Y, hyperparams, nh, sf2, noise, invR);
+    if (rc == IBO_OK && npbases > 0)
+        rc = ibo_gp_set_prior(g, npbases, pbasismeans, pbasisbeta, pbasistheta, pbasislowerb, pbasiswidth);
+    if (rc == IBO_OK) {
+        std::vector<double> xo(ndim);
+        double opt = 0.0;
+        rc = direct_on_gp(g, ndim, lb, ub, acqfunc, parm, IBO_ERF_LIBM, 1e-8, maxiter, maxtime, maxsample, 1,
+                          &opt, xo.data(), nullptr);
+        if (rc == IBO_OK) {
+            res = (double *)malloc(sizeof(double) * (ndim + 1));
+            res[0] = -opt;
+            for (int i = 0; i < ndim; i++) res[i + 1] = xo[i];
+        }
+    }
+    if (rc != IBO_OK) fprintf(stderr, "[libibo_hip] acqmaxGP failed: %s\n", g_err);
+    ibo_gp_destroy(g);
+    return res;
+}
+
+extern "C" const double *direct(objective_t objective, int ndim, double *lb, double *ub, int maxiter,
+                                int maxtime, int maxsample)
+{
+    std::vector<double> x(ndim);
+    ibo::batch_eval_t ev = [&](const double *pts, int n, double *vals) -> int {
+        for (int p = 0; p < n; p++) {
+            for (int i = 0; i < ndim; i++) x[i] = pts[(size_t)p * ndim + i];
+            vals[p] = objective(ndim, x.data());
+        }
+        return 0;
+    };
+    ibo::DirectOptions o;
+    o.maxiter = maxiter; o.maxtime = maxtime; o.maxsample = maxsample; o.compat = true; o.per_rectangle = true;
+    ibo::DirectResult r = ibo::direct_minimize(ev, ndim, lb, ub, o);
+    double *res = (double *)malloc(sizeof(double) * (ndim + 1));
+    res[0] = r.fmin;
+    for (int i = 0; i < ndim; i++) res[i + 1] = r.xmin[i];
+    return res;
+}
+
+// host-callback DIRECT with the sample counter and the compat switch exposed
+extern "C" int ibo_direct_host(objective_t objective, int ndim, const double *lb, const double *ub, int maxiter,
+                               int maxtime, int maxsample, int compat, double *fmin, double *xmin, int64_t *nsamples)
+{
+    if (!objective || !lb || !ub) return fail(IBO_ERR_ARG, "NULL argument");
+    std::vector<double> x(ndim);
+    ibo::batch_eval_t ev = [&](const double *pts, int n, double *vals) -> int {
+        for (int p = 0; p < n; p++) {
+            for (int i = 0; i < ndim; i++) x[i] = pts[(size_t)p * ndim + i];
+            vals[p] = objective(ndim, x.data());
+        }
+        return 0;
+    };
+    ibo::DirectOptions o;
+    o.maxiter = maxiter; o.maxtime = maxtime; o.maxsample = maxsample; o.compat = compat != 0; o.per_rectangle = true;
+    ibo::DirectResult r = ibo::direct_minimize(ev, ndim, lb, ub, o);
+    if (fmin) *fmin = r.fmin;
+    if (xmin) for (int i = 0; i < ndim; i++) xmin[i] = r.xmin[i];
+    if (nsamples) *nsamples = r.nsamples;
+    return IBO_OK;
+}

@@ -1,0 +1,163 @@
+// comm.hip -- the one collective of the sharded candidate sweep: an arg-max
+// exchange over RCCL (xGMI).  RCCL has no MAXLOC, so every rank writes
+// (value, index, payload...) into its own slot of a world_size-slot buffer that
+// is zero elsewhere and a single ncclAllReduce(sum) gathers all slots; the final
+// (max value, lowest global index) reduction is then done identically on every
+// rank.  16..(2+D)*8 bytes per rank: latency-bound, one collective per sweep.
+//
+// librccl is loaded lazily (dlopen) so single-GPU users and CPU-side symbol
+// checks never pay for it.
+#include "../../include/ibo_abi.h"
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+// minimal RCCL surface (matches /opt/rocm/include/rccl/rccl.h)
+typedef struct { char internal[128]; } rccl_unique_id_t;
+typedef void *rccl_comm_t;
+typedef int (*fn_get_unique_id)(rccl_unique_id_t *);
+typedef int (*fn_comm_init_rank)(rccl_comm_t *, int, rccl_unique_id_t, int);
+typedef int (*fn_all_reduce)(const void *, void *, size_t, int /*dtype*/, int /*op*/, rccl_comm_t, hipStream_t);
+typedef int (*fn_comm_destroy)(rccl_comm_t);
+typedef const char *(*fn_get_error_string)(int);
+enum { RCCL_FLOAT64 = 8, RCCL_SUM = 0 };
+
+static struct {
+    void *h = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_all_reduce all_reduce = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_get_error_string err = nullptr;
+} R;
+
+static thread_local char c_err[256];
+extern "C" const char *ibo_last_error(void);
+static int cfail(int code, const char *msg, int rc = 0)
+{
+    snprintf(c_err, sizeof(c_err), "%s (%s)", msg, (R.err && rc) ? R.err(rc) : "-");
+    fprintf(stderr, "[libibo_hip] comm: %s\n", c_err);
+    return code;
+}
+
+static int load_rccl()
+{
+    if (R.h) return IBO_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (R.h) break; }
+    if (!R.h) return cfail(IBO_ERR_COMM, "cannot dlopen librccl.so");
+    R.get_unique_id = (fn_get_unique_id)dlsym(R.h, "ncclGetUniqueId");
+    R.comm_init_rank = (fn_comm_init_rank)dlsym(R.h, "ncclCommInitRank");
+    R.all_reduce = (fn_all_reduce)dlsym(R.h, "ncclAllReduce");
+    R.comm_destroy = (fn_comm_destroy)dlsym(R.h, "ncclCommDestroy");
+    R.err = (fn_get_error_string)dlsym(R.h, "ncclGetErrorString");
+    if (!R.get_unique_id || !R.comm_init_rank || !R.all_reduce || !R.comm_destroy)
+        return cfail(IBO_ERR_COMM, "librccl.so lacks an expected symbol");
+    return IBO_OK;
+}
+
+struct ibo_comm {
+    int device, world, rank;
+    rccl_comm_t comm;
+    hipStream_t stream;
+    double *dbuf;
+    size_t cap;     // doubles
+};
+
+extern "C" int ibo_comm_get_unique_id(unsigned char id[IBO_COMM_ID_BYTES])
+{
+    if (!id) return IBO_ERR_ARG;
+    int rc = load_rccl();
+    if (rc) return rc;
+    rccl_unique_id_t u;
+    int e = R.get_unique_id(&u);
+    if (e) return cfail(IBO_ERR_COMM, "ncclGetUniqueId failed", e);
+    memcpy(id, u.internal, IBO_COMM_ID_BYTES);
+    return IBO_OK;
+}
+
+extern "C" int ibo_comm_init(int device, int world_size, int rank, const unsigned char id[IBO_COMM_ID_BYTES],
+                             ibo_comm_t **out)
+{
+    if (!out || !id || world_size < 1 || rank < 0 || rank >= world_size) return IBO_ERR_ARG;
+    int rc = load_rccl();
+    if (rc) return rc;
+    if (hipSetDevice(device) != hipSuccess) return cfail(IBO_ERR_HIP, "hipSetDevice failed");
+    ibo_comm *c = new ibo_comm();
+    c->device = device; c->world = world_size; c->rank = rank; c->dbuf = nullptr; c->cap = 0;
+    rccl_unique_id_t u;
+    memcpy(u.internal, id, IBO_COMM_ID_BYTES);
+    int e = R.comm_init_rank(&c->comm, world_size, u, rank);
+    if (e) { delete c; return cfail(IBO_ERR_COMM, "ncclCommInitRank failed", e); }
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return cfail(IBO_ERR_HIP, "hipStreamCreate failed"); }
+    *out = c;
+    return IBO_OK;
+}
+
+extern "C" int ibo_comm_destroy(ibo_comm_t *c)
+{
+    if (!c) return IBO_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->dbuf) (void)hipFree(c->dbuf);
+    R.comm_destroy(c->comm);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return IBO_OK;
+}
+
+// the deterministic final reduction, shared with the host-side (gloo) tests
+// through ibo_amd/multigpu.py which restates it in three lines
+static void slot_argmax(const double *buf, int world, int slot, double *bv, int64_t *bi, int *br)
+{
+    double v = 0.0; int64_t i = -1; int r = -1;
+    for (int k = 0; k < world; k++) {
+        const double *s = buf + (size_t)k * slot;
+        if (s[2] == 0.0) continue;                     // rank had no admissible candidate
+        int64_t idx = (int64_t)s[1];
+        if (r < 0 || s[0] > v || (s[0] == v && idx < i)) { v = s[0]; i = idx; r = k; }
+    }
+    *bv = v; *bi = i; *br = r;
+}
+
+extern "C" int ibo_comm_argmax(ibo_comm_t *c, double val, int64_t idx, const double *payload, int npayload,
+                               double *best_val, int64_t *best_idx, double *best_payload, int *best_rank)
+{
+    if (!c || npayload < 0 || (npayload && !payload)) return IBO_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return cfail(IBO_ERR_HIP, "hipSetDevice failed");
+    const int slot = 3 + npayload;          // value, index (exact in fp64 below 2^53), valid flag, payload
+    const size_t n = (size_t)slot * c->world;
+    if (n > c->cap) {
+        if (c->dbuf) (void)hipFree(c->dbuf);
+        if (hipMalloc((void **)&c->dbuf, n * sizeof(double)) != hipSuccess) return cfail(IBO_ERR_HIP, "hipMalloc failed");
+        c->cap = n;
+    }
+    std::vector<double> h(n, 0.0);
+    double *mine = h.data() + (size_t)c->rank * slot;
+    bool valid = idx >= 0 && val == val;
+    mine[0] = valid ? val : 0.0; mine[1] = valid ? (double)idx : 0.0; mine[2] = valid ? 1.0 : 0.0;
+    for (int k = 0; k < npayload; k++) mine[3 + k] = valid ? payload[k] : 0.0;
+    if (hipMemcpyAsync(c->dbuf, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return cfail(IBO_ERR_HIP, "H2D failed");
+    int e = R.all_reduce(c->dbuf, c->dbuf, n, RCCL_FLOAT64, RCCL_SUM, c->comm, c->stream);
+    if (e) return cfail(IBO_ERR_COMM, "ncclAllReduce failed", e);
+    if (hipMemcpyAsync(h.data(), c->dbuf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        return cfail(IBO_ERR_HIP, "D2H failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return cfail(IBO_ERR_HIP, "stream sync failed");
+    double bv; int64_t bi; int br;
+    slot_argmax(h.data(), c->world, slot, &bv, &bi, &br);
+    if (best_val) *best_val = bv;
+    if (best_idx) *best_idx = bi;
+    if (best_rank) *best_rank = br;
+    if (best_payload && br >= 0)
+        for (int k = 0; k < npayload; k++) best_payload[k] = h[(size_t)br * slot + 3 + k];
+    return IBO_OK;
+}
+
+extern "C" int ibo_comm_barrier(ibo_comm_t *c)
+{
+    double v; int64_t i; int r;
+    return ibo_comm_argmax(c, 0.0, 0, nullptr, 0, &v, &i, nullptr, &r);
+}

@@ -1,0 +1,310 @@
+// direct_host.cpp -- DIRECT with batched objective evaluation.
+//
+// The search is the one the reference's native optimiser performs
+// (cpp/direct.cpp:329-581: driver and potentially-optimal test; :111-141 sample
+// mapping and incumbent; :146-235 division), restructured so that the objective
+// is called on arrays of points: per iteration all split-point probes of all
+// potentially-optimal rectangles form one batch and all child centres a second
+// one (GPU objective), or per rectangle (host callbacks, identical call order
+// to the reference).  The incumbent is then replayed in the reference's
+// sequential order, so (fmin, xmin, nsamples) are those of the sequential run.
+//
+// Quirks kept on purpose: probes at lb+len/3 and lb+2len/3 order
+// the dimensions, child centres are sampled separately; strict '<' incumbent;
+// reverse-order division; I1 slope seeded with DBL_MIN; epsilon = 1e-9;
+// with compat the longest-side search is seeded from dimension 0 without
+// looking at fixed[0], which stalls the search when dimension 0 is fixed.
+#include "direct_host.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+
+namespace ibo {
+namespace {
+
+struct Pool {                 // rectangles, structure-of-arrays, insertion order preserved
+    int D = 0;
+    std::vector<double> lb, ub, ctr;   // size() * D
+    std::vector<double> y, d;
+    size_t size() const { return y.size(); }
+    void push(const double *l, const double *u, const double *c, double yy, double dd)
+    {
+        lb.insert(lb.end(), l, l + D); ub.insert(ub.end(), u, u + D); ctr.insert(ctr.end(), c, c + D);
+        y.push_back(yy); d.push_back(dd);
+    }
+    void erase(size_t j)
+    {
+        lb.erase(lb.begin() + j * D, lb.begin() + (j + 1) * D);
+        ub.erase(ub.begin() + j * D, ub.begin() + (j + 1) * D);
+        ctr.erase(ctr.begin() + j * D, ctr.begin() + (j + 1) * D);
+        y.erase(y.begin() + j); d.erase(d.begin() + j);
+    }
+};
+
+struct Division {             // the two-phase division of one rectangle
+    size_t src;
+    std::vector<double> lb, ub, ctr;   // copy of the rectangle
+    double y;
+    std::vector<int> dims;             // divided dimensions (probe order, then sorted)
+    std::vector<double> probes;        // 2*dims x D unit-cube points
+    std::vector<double> probe_vals;
+    std::vector<double> kid_lb, kid_ub, kid_ctr, kid_d;   // 2*dims children
+    std::vector<double> kid_vals;
+    double mid_d;
+};
+
+struct Search {
+    int D;
+    std::vector<double> lo, hi;
+    std::vector<char> fixed;
+    double fmin = DBL_MAX;
+    std::vector<double> xmin;
+    int64_t nsamples = 0;
+    bool compat;
+    const batch_eval_t *eval;
+    std::vector<double> mapped;
+
+    // unit cube -> caller's box (cpp/direct.cpp:113-120)
+    int evaluate(const double *unit, int n, double *vals)
+    {
+        mapped.resize((size_t)n * D);
+        for (int p = 0; p < n; p++)
+            for (int i = 0; i < D; i++)
+                mapped[(size_t)p * D + i] = fixed[i] ? lo[i] : unit[(size_t)p * D + i] * (hi[i] - lo[i]) + lo[i];
+        return (*eval)(mapped.data(), n, vals);
+    }
+    // incumbent update in sequential order (cpp/direct.cpp:122-139)
+    void account(const double *unit, double v)
+    {
+        nsamples++;
+        if (v < fmin) {
+            fmin = v;
+            for (int i = 0; i < D; i++) xmin[i] = lo[i] + (hi[i] - lo[i]) * unit[i];
+        }
+    }
+
+    void plan_probes(Division &dv) const
+    {
+        const double *l = dv.lb.data(), *u = dv.ub.data();
+        double maxlen;
+        if (compat) {
+            maxlen = u[0] - l[0];
+            for (int i = 1; i < D; i++) if (!fixed[i] && u[i] - l[i] > maxlen) maxlen = u[i] - l[i];
+        } else {
+            maxlen = -1.0;
+            for (int i = 0; i < D; i++) if (!fixed[i] && u[i] - l[i] > maxlen) maxlen = u[i] - l[i];
+        }
+        dv.dims.clear(); dv.probes.clear();
+        for (int i = 0; i < D; i++) {
+            if (!fixed[i] && u[i] - l[i] == maxlen) {
+                dv.dims.push_back(i);
+                size_t o = dv.probes.size();
+                dv.probes.insert(dv.probes.end(), dv.ctr.begin(), dv.ctr.end());
+                dv.probes.insert(dv.probes.end(), dv.ctr.begin(), dv.ctr.end());
+                dv.probes[o + i] = l[i] + maxlen / 3.;
+                dv.probes[o + D + i] = l[i] + 2. * maxlen / 3.;
+            }
+        }
+        dv.probe_vals.assign(dv.dims.size() * 2, 0.0);
+    }
+
+    void plan_children(Division &dv) const
+    {
+        const size_t m = dv.dims.size();
+        std::vector<double> best(m);
+        for (size_t q = 0; q < m; q++) {
+            double f1 = dv.probe_vals[2 * q], f2 = dv.probe_vals[2 * q + 1];
+            best[q] = (f1 < f2) ? f1 : f2;
+        }
+        // ascending, stable (libstdc++ sorts <= 16 elements by insertion; cpp/direct.cpp:194)
+        std::vector<int> order(dv.dims);
+        for (size_t a = 1; a < m; a++) {
+            int da = order[a]; double va = best[a];
+            size_t b = a;
+            while (b > 0 && va < best[b - 1]) { order[b] = order[b - 1]; best[b] = best[b - 1]; b--; }
+            order[b] = da; best[b] = va;
+        }
+        std::vector<double> l(dv.lb), u(dv.ub), cl(D), cu(D), cc(D);
+        dv.kid_lb.clear(); dv.kid_ub.clear(); dv.kid_ctr.clear(); dv.kid_d.clear();
+        auto add_kid = [&](const std::vector<double> &kl, const std::vector<double> &ku) {
+            double dd = 0.0;
+            for (int i = 0; i < D; i++) {
+                cc[i] = kl[i] + (ku[i] - kl[i]) / 2.;
+                dd += (kl[i] - cc[i]) * (kl[i] - cc[i]);
+            }
+            dv.kid_lb.insert(dv.kid_lb.end(), kl.begin(), kl.end());
+            dv.kid_ub.insert(dv.kid_ub.end(), ku.begin(), ku.end());
+            dv.kid_ctr.insert(dv.kid_ctr.end(), cc.begin(), cc.end());
+            dv.kid_d.push_back(std::sqrt(dd));
+        };
+        for (size_t q = 0; q < m; q++) {
+            int dd = order[q];
+            double w = u[dd] - l[dd];
+            double s1 = l[dd] + w / 3.;
+            double s2 = l[dd] + 2. * w / 3.;
+            cl = l; cu = u; cu[dd] = s1;
+            add_kid(cl, cu);
+            cl = l; cu = u; cl[dd] = s2;
+            add_kid(cl, cu);
+            l[dd] = s1; u[dd] = s2;
+        }
+        double md = 0.0;
+        for (int i = 0; i < D; i++) md += (l[i] - dv.ctr[i]) * (l[i] - dv.ctr[i]);
+        dv.mid_d = std::sqrt(md);
+        dv.lb = l; dv.ub = u;           // the middle rectangle keeps centre and value
+        dv.kid_vals.assign(2 * m, 0.0);
+    }
+
+    // replay in reference order and materialise the new rectangles
+    void apply(const Division &dv, Pool &pool)
+    {
+        const size_t m = dv.dims.size();
+        for (size_t q = 0; q < 2 * m; q++) account(&dv.probes[q * D], dv.probe_vals[q]);
+        for (size_t q = 0; q < 2 * m; q++) account(&dv.kid_ctr[q * D], dv.kid_vals[q]);
+        for (size_t q = 0; q < 2 * m; q++)
+            pool.push(&dv.kid_lb[q * D], &dv.kid_ub[q * D], &dv.kid_ctr[q * D], dv.kid_vals[q], dv.kid_d[q]);
+        pool.push(dv.lb.data(), dv.ub.data(), dv.ctr.data(), dv.y, dv.mid_d);
+    }
+};
+
+Division make_division(const Pool &pool, size_t j)
+{
+    Division dv;
+    const int D = pool.D;
+    dv.src = j;
+    dv.lb.assign(pool.lb.begin() + j * D, pool.lb.begin() + (j + 1) * D);
+    dv.ub.assign(pool.ub.begin() + j * D, pool.ub.begin() + (j + 1) * D);
+    dv.ctr.assign(pool.ctr.begin() + j * D, pool.ctr.begin() + (j + 1) * D);
+    dv.y = pool.y[j];
+    dv.mid_d = pool.d[j];
+    return dv;
+}
+
+// potentially-optimal rectangles (cpp/direct.cpp:378-471)
+void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out)
+{
+    const double eps = 10e-10;
+    const size_t n = pool.size();
+    const double *Y = pool.y.data(), *Dd = pool.d.data();
+    out.clear();
+    for (size_t j = 0; j < n; j++) {
+        double maxI1 = DBL_MIN, minI2 = DBL_MAX;
+        const double yj = Y[j], dj = Dd[j];
+        bool reject = false;
+        for (size_t i = 0; i < n; i++) {
+            if (i == j) continue;
+            const double di = Dd[i];
+            if (di < dj) {
+                double v = (yj - Y[i]) / (dj - di);
+                if (v > maxI1) maxI1 = v;
+            } else if (di > dj) {
+                double v = (Y[i] - yj) / (di - dj);
+                if (v < minI2) {
+                    minI2 = v;
+                    if (minI2 <= 0.) { reject = true; break; }
+                }
+            } else if (yj > Y[i]) { reject = true; break; }
+            if (maxI1 != DBL_MIN && minI2 != DBL_MAX && minI2 < maxI1) { reject = true; break; }
+        }
+        if (reject) continue;
+        bool take;
+        if (minI2 == DBL_MAX) take = true;
+        else if (fmin == 0.0) take = (yj <= dj * minI2);
+        else take = (eps <= (fmin - yj) / std::fabs(fmin) + (dj / std::fabs(fmin)) * minI2);
+        if (take) out.push_back(j);
+    }
+}
+
+}  // namespace
+
+DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, const double *ub,
+                             const DirectOptions &opt)
+{
+    DirectResult res;
+    const time_t start = time(nullptr);
+    Search S;
+    S.D = D; S.compat = opt.compat; S.eval = &eval;
+    S.lo.assign(lb, lb + D); S.hi.assign(ub, ub + D);
+    S.fixed.resize(D); S.xmin.assign(D, 0.0);
+    for (int i = 0; i < D; i++) S.fixed[i] = (lb[i] == ub[i]);
+
+    Pool pool; pool.D = D;
+    {   // the unit cube, its centre, and its first division (cpp/direct.cpp:352-357)
+        Division dv;
+        dv.src = 0;
+        dv.lb.assign(D, 0.0); dv.ub.assign(D, 1.0); dv.ctr.resize(D);
+        double dd = 0.0;
+        for (int i = 0; i < D; i++) { dv.ctr[i] = 0.0 + (1.0 - 0.0) / 2.; dd += (0.0 - dv.ctr[i]) * (0.0 - dv.ctr[i]); }
+        double y0;
+        if ((res.status = S.evaluate(dv.ctr.data(), 1, &y0))) return res;
+        S.account(dv.ctr.data(), y0);
+        dv.y = y0; dv.mid_d = std::sqrt(dd);
+        S.plan_probes(dv);
+        if (!dv.dims.empty() && (res.status = S.evaluate(dv.probes.data(), (int)dv.dims.size() * 2, dv.probe_vals.data()))) return res;
+        S.plan_children(dv);
+        if (!dv.dims.empty() && (res.status = S.evaluate(dv.kid_ctr.data(), (int)dv.dims.size() * 2, dv.kid_vals.data()))) return res;
+        S.apply(dv, pool);
+    }
+
+    std::vector<size_t> pot;
+    std::vector<Division> divs;
+    std::vector<double> pts, vals;
+    bool done = false;
+    int iteration = 0;
+    while (iteration < opt.maxiter && !done) {
+        iteration++;
+        potentially_optimal(pool, S.fmin, pot);
+        if (pot.empty()) {
+            printf("[cdirect] could not divide any more\n");
+            break;
+        }
+        divs.clear();
+        for (size_t q = pot.size(); q-- > 0;) divs.push_back(make_division(pool, pot[q]));   // reverse order
+        if (opt.per_rectangle) {
+            for (Division &dv : divs) {
+                S.plan_probes(dv);
+                int np = (int)dv.dims.size() * 2;
+                if (np && (res.status = S.evaluate(dv.probes.data(), np, dv.probe_vals.data()))) return res;
+                S.plan_children(dv);
+                if (np && (res.status = S.evaluate(dv.kid_ctr.data(), np, dv.kid_vals.data()))) return res;
+                S.apply(dv, pool);
+                pool.erase(dv.src);
+                if (S.nsamples > (int64_t)(unsigned)opt.maxsample) { done = true; break; }
+                if (time(nullptr) - start > opt.maxtime) { done = true; break; }
+            }
+        } else {
+            for (int phase = 0; phase < 2; phase++) {
+                pts.clear();
+                for (Division &dv : divs) {
+                    if (phase == 0) { S.plan_probes(dv); pts.insert(pts.end(), dv.probes.begin(), dv.probes.end()); }
+                    else { S.plan_children(dv); pts.insert(pts.end(), dv.kid_ctr.begin(), dv.kid_ctr.end()); }
+                }
+                int np = (int)(pts.size() / D);
+                vals.assign(np, 0.0);
+                if (np && (res.status = S.evaluate(pts.data(), np, vals.data()))) return res;
+                size_t o = 0;
+                for (Division &dv : divs) {
+                    size_t c = dv.dims.size() * 2;
+                    std::vector<double> &dst = phase == 0 ? dv.probe_vals : dv.kid_vals;
+                    for (size_t q = 0; q < c; q++) dst[q] = vals[o + q];
+                    o += c;
+                }
+            }
+            for (Division &dv : divs) {
+                S.apply(dv, pool);
+                pool.erase(dv.src);
+                if (S.nsamples > (int64_t)(unsigned)opt.maxsample) { done = true; break; }
+                if (time(nullptr) - start > opt.maxtime) { done = true; break; }
+            }
+        }
+        if (time(nullptr) - start > opt.maxtime) break;
+        if (S.nsamples > (int64_t)(unsigned)opt.maxsample) break;
+    }
+    res.fmin = S.fmin; res.xmin = S.xmin; res.nsamples = S.nsamples; res.iterations = iteration;
+    return res;
+}
+
+}  // namespace ibo

@@ -1,0 +1,528 @@
+// linalg.hip -- fit-side kernels for gfx950: covariance assembly, blocked
+// Cholesky, explicit triangular inverse, MFMA-fragment packing, alpha vectors.
+//
+// Replaces (reference, /root/reference):
+//   GaussianProcess._computeCorrelations   ego/gaussianprocess/__init__.py:134-149
+//   Kernel.covMatrix                       ego/gaussianprocess/kernel.py:46-53
+//   linalg.cholesky(R)                     ego/gaussianprocess/__init__.py:299
+//   linalg.inv(R) per maximize* call       ego/acquisition/__init__.py:385-388
+//
+// Layout: every N x N matrix lives row-major with leading dimension Npad
+// (a multiple of 64) so that all tile kernels run without bounds checks; the
+// pad is the identity for matrices that get factored and zero for W.
+#include "ibo_common.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// ------------------------------------------------------------------------
+// covariance matrix  K[i][j] = k(A1_i, A2_j)
+// ------------------------------------------------------------------------
+__global__ void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
+                                  const double *__restrict__ A2, int ldp, int square, int diag_rule,
+                                  double noise, double *__restrict__ K, int ldk)
+{
+    int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    int i = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= n1 || j >= n2) return;
+    const double *a = A1 + (size_t)i * ldp;
+    const double *b = A2 + (size_t)j * ldp;
+    double z = 0.0;
+    for (int d = 0; d < kp.D; d++) {
+        double t = a[d] - b[d];
+        z += kp.w[d] * (t * t);
+    }
+    double v = cov_from_z_rt(kp.family, z, kp.sf2);
+    if (square && i == j) {
+        // diag_rule 0: the reference never calls the kernel on the diagonal and
+        // hard-wires 1+noise (ego/gaussianprocess/__init__.py:138)
+        v = (diag_rule == 0) ? (1.0 + noise) : (v + noise);
+    }
+    K[(size_t)i * ldk + j] = v;
+}
+
+int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
+                      int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s)
+{
+    int square = (A2 == nullptr);
+    if (square) { A2 = A1; n2 = n1; }
+    dim3 grid((n2 + 15) / 16, (n1 + 15) / 16);
+    hipLaunchKernelGGL(cov_matrix_kernel, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
+                       diag_rule, noise, K, ldk);
+    return (int)hipGetLastError();
+}
+
+__global__ void pad_copy_kernel(const double *__restrict__ src, int N, int lds, double *__restrict__ dst,
+                                int Npad, double pad_diag)
+{
+    int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    int i0 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= Npad || i0 >= Npad) return;
+    int i = i0;
+    double v;
+    if (i < N && j < N) v = src[(size_t)i * lds + j];
+    else v = (i == j) ? pad_diag : 0.0;
+    dst[(size_t)i * Npad + j] = v;
+}
+
+int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s)
+{
+    dim3 grid(Npad / 64, Npad / 4);
+    hipLaunchKernelGGL(pad_copy_kernel, grid, dim3(256), 0, s, src, N, lds, dst, Npad, pad_diag);
+    return (int)hipGetLastError();
+}
+
+__global__ void zero_upper_kernel(double *A, int Npad)
+{
+    int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j > i) A[(size_t)i * Npad + j] = 0.0;
+}
+
+int launch_zero_upper(double *A, int Npad, hipStream_t s)
+{
+    dim3 grid(Npad / 64, Npad / 4);
+    hipLaunchKernelGGL(zero_upper_kernel, grid, dim3(256), 0, s, A, Npad);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// 64x64 output tile GEMM on fp64 MFMA, 256 threads (2x2 waves, 32x32 each).
+//   acc += sum_{k in [kbeg,kend)} A[r][k] * (TRANSB ? B[c][k] : B[k][c])
+// kbeg/kend multiples of 16.  As: 64*17 doubles, Bs: max(64*17, 16*80) doubles.
+// ------------------------------------------------------------------------
+#define AS_LD 17
+#define BS_LD 80
+template <bool TRANSB>
+__device__ __forceinline__ void gemm_tile_64(const double *__restrict__ A, int lda,
+                                             const double *__restrict__ B, int ldb, int kbeg, int kend,
+                                             d4_t (&acc)[2][2], double *As, double *Bs)
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        {
+            int r = t >> 2, kq = (t & 3) * 4;
+            const double2 *p = (const double2 *)(A + (size_t)r * lda + k0 + kq);
+            double2 v0 = p[0], v1 = p[1];
+            double *q = As + r * AS_LD + kq;
+            q[0] = v0.x; q[1] = v0.y; q[2] = v1.x; q[3] = v1.y;
+        }
+        if (TRANSB) {
+            int c = t >> 2, kq = (t & 3) * 4;
+            const double2 *p = (const double2 *)(B + (size_t)c * ldb + k0 + kq);
+            double2 v0 = p[0], v1 = p[1];
+            double *q = Bs + c * AS_LD + kq;
+            q[0] = v0.x; q[1] = v0.y; q[2] = v1.x; q[3] = v1.y;
+        } else {
+            int k = t >> 4, cq = (t & 15) * 4;
+            const double2 *p = (const double2 *)(B + (size_t)(k0 + k) * ldb + cq);
+            double2 v0 = p[0], v1 = p[1];
+            double *q = Bs + k * BS_LD + cq;
+            q[0] = v0.x; q[1] = v0.y; q[2] = v1.x; q[3] = v1.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            double a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * AS_LD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                if (TRANSB) b[n] = Bs[(wc * 32 + n * 16 + (lane & 15)) * AS_LD + k4 * 4 + (lane >> 4)];
+                else b[n] = Bs[(k4 * 4 + (lane >> 4)) * BS_LD + wc * 32 + n * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[m][n] = mfma_f64(a[m], b[n], acc[m][n]);
+        }
+        __syncthreads();
+    }
+}
+
+// C[row][col] for accumulator element (m, n, r) of this lane
+#define TILE_ROW(m, r) (wr * 32 + (m) * 16 + (lane >> 4) + 4 * (r))
+#define TILE_COL(n) (wc * 32 + (n) * 16 + (lane & 15))
+#define TILE_IDS const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr = wv >> 1, wc = wv & 1
+
+// ------------------------------------------------------------------------
+// blocked right-looking Cholesky, NB = 64
+// ------------------------------------------------------------------------
+#define SD 65
+__global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, int Npad, int jb,
+                                                        double *__restrict__ diag64, int *info)
+{
+    __shared__ double S[64 * SD];
+    __shared__ double V[64 * SD];
+    const int t = threadIdx.x;
+    double *Lb = L + (size_t)jb * 64 * Npad + jb * 64;
+    for (int e = t; e < 4096; e += 256) {
+        int r = e >> 6, c = e & 63;
+        S[r * SD + c] = Lb[(size_t)r * Npad + c];
+    }
+    for (int j = 0; j < 64; j++) {
+        __syncthreads();
+        if (t == 0) {
+            double d = S[j * SD + j];
+            if (!(d > 0.0)) {            // also catches NaN
+                atomicCAS(info, 0, jb * 64 + j + 1);
+                d = 1.0;
+            }
+            S[j * SD + j] = sqrt(d);
+        }
+        __syncthreads();
+        double djj = S[j * SD + j];
+        if (t > j && t < 64) S[t * SD + j] /= djj;
+        __syncthreads();
+        int i = t & 63;
+        if (i > j) {
+            double lij = S[i * SD + j];
+            for (int k = j + 1 + (t >> 6); k <= i; k += 4) S[i * SD + k] -= lij * S[k * SD + j];
+        }
+    }
+    __syncthreads();
+    // inverse of the 64x64 lower-triangular block, one column per thread
+    if (t < 64) {
+        int c = t;
+        for (int i = 0; i < c; i++) V[i * SD + c] = 0.0;
+        for (int i = c; i < 64; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; k++) s -= S[i * SD + k] * V[k * SD + c];
+            V[i * SD + c] = s / S[i * SD + i];
+        }
+    }
+    __syncthreads();
+    double *Db = diag64 + (size_t)jb * 4096;
+    for (int e = t; e < 4096; e += 256) {
+        int r = e >> 6, c = e & 63;
+        Lb[(size_t)r * Npad + c] = (c <= r) ? S[r * SD + c] : 0.0;
+        Db[e] = V[r * SD + c];
+    }
+}
+
+// rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, int Npad, int jb,
+                                                        const double *__restrict__ diag64)
+{
+    __shared__ double As[64 * AS_LD];
+    __shared__ double Bs[16 * BS_LD];
+    TILE_IDS;
+    int ib = jb + 1 + blockIdx.x;
+    double *Ab = L + (size_t)ib * 64 * Npad + jb * 64;
+    d4_t acc[2][2] = {};
+    gemm_tile_64<true>(Ab, Npad, diag64 + (size_t)jb * 4096, 64, 0, 64, acc, As, Bs);
+    // every read of this tile happened before the last barrier inside gemm_tile_64
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ab[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
+}
+
+// trailing update: A[i][k] -= L[i][jb] L[k][jb]^T for jb < k <= i
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double *__restrict__ L, int Npad, int jb)
+{
+    __shared__ double As[64 * AS_LD];
+    __shared__ double Bs[64 * AS_LD];
+    TILE_IDS;
+    int tix = blockIdx.x;
+    int ii = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= tix) ii++;
+    while (ii * (ii + 1) / 2 > tix) ii--;
+    int kk = tix - ii * (ii + 1) / 2;
+    int i = jb + 1 + ii, k = jb + 1 + kk;
+    const double *Ai = L + (size_t)i * 64 * Npad + jb * 64;
+    const double *Ak = L + (size_t)k * 64 * Npad + jb * 64;
+    double *C = L + (size_t)i * 64 * Npad + k * 64;
+    d4_t acc[2][2] = {};
+    gemm_tile_64<true>(Ai, Npad, Ak, Npad, 0, 64, acc, As, Bs);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                size_t o = (size_t)TILE_ROW(m, r) * Npad + TILE_COL(n);
+                C[o] -= acc[m][n][r];
+            }
+}
+
+int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s)
+{
+    int nb = Npad / 64;
+    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    for (int jb = 0; jb < nb; jb++) {
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, L, Npad, jb, diag64, info_dev);
+        int m = nb - jb - 1;
+        if (m > 0) {
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3(m), dim3(256), 0, s, L, Npad, jb, diag64);
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(m * (m + 1) / 2), dim3(256), 0, s, L, Npad, jb);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// W = L^-1 by recursive doubling over 64-blocks:
+//   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22]
+// level s: nodes of 2s blocks; T = L21 W11, then W21 = -W22 T.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trinv_place_diag_kernel(const double *__restrict__ diag64,
+                                                               double *__restrict__ W, int Npad)
+{
+    int jb = blockIdx.x;
+    const double *Db = diag64 + (size_t)jb * 4096;
+    double *Wb = W + (size_t)jb * 64 * Npad + jb * 64;
+    for (int e = threadIdx.x; e < 4096; e += 256) Wb[(size_t)(e >> 6) * Npad + (e & 63)] = Db[e];
+}
+
+__global__ __launch_bounds__(256) void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W,
+                                                      double *__restrict__ T, int Npad, int s, int nb)
+{
+    __shared__ double As[64 * AS_LD];
+    __shared__ double Bs[16 * BS_LD];
+    TILE_IDS;
+    int o = blockIdx.y * 2 * s;
+    int r = min(s, nb - o - s);
+    int ti = blockIdx.x / s, tj = blockIdx.x % s;
+    if (ti >= r) return;
+    const double *A = L + (size_t)(o + s + ti) * 64 * Npad + (size_t)o * 64;
+    const double *B = W + (size_t)o * 64 * Npad + (size_t)(o + tj) * 64;
+    d4_t acc[2][2] = {};
+    gemm_tile_64<false>(A, Npad, B, Npad, tj * 64, s * 64, acc, As, Bs);
+    double *C = T + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + tj) * 64;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
+}
+
+__global__ __launch_bounds__(256) void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T,
+                                                      int Npad, int s, int nb)
+{
+    __shared__ double As[64 * AS_LD];
+    __shared__ double Bs[16 * BS_LD];
+    TILE_IDS;
+    int o = blockIdx.y * 2 * s;
+    int r = min(s, nb - o - s);
+    int ti = blockIdx.x / s, tj = blockIdx.x % s;
+    if (ti >= r) return;
+    const double *A = W + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + s) * 64;
+    const double *B = T + (size_t)(o + s) * 64 * Npad + (size_t)(o + tj) * 64;
+    d4_t acc[2][2] = {};
+    gemm_tile_64<false>(A, Npad, B, Npad, 0, (ti + 1) * 64, acc, As, Bs);
+    double *C = W + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + tj) * 64;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = -acc[m][n][q];
+}
+
+int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s)
+{
+    int nb = Npad / 64;
+    HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * (size_t)Npad * Npad, s));
+    hipLaunchKernelGGL(trinv_place_diag_kernel, dim3(nb), dim3(256), 0, s, diag64, W, Npad);
+    for (int sz = 1; sz < nb; sz *= 2) {
+        int nodes = (nb + 2 * sz - 1) / (2 * sz);
+        dim3 grid(sz * sz, nodes);
+        hipLaunchKernelGGL(trinv_T_kernel, grid, dim3(256), 0, s, L, W, T, Npad, sz, nb);
+        hipLaunchKernelGGL(trinv_W_kernel, grid, dim3(256), 0, s, W, T, Npad, sz, nb);
+    }
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// pack W into MFMA A-fragment order for the sweep:
+//   Wp[((g*nk8 + j)*64 + lane)*2 + h] = W[16g + (lane&15)][8j + 4h + (lane>>4)]
+// so that one 16-byte load per lane yields the A operands of two consecutive
+// k4-steps of row-block g.  mode 1 applies W[i][j] = S[N-1-j][N-1-i]
+// (turns the upper factor G^T of the legacy invR = G G^T into a lower one).
+// ------------------------------------------------------------------------
+__global__ void pack_w_kernel(const double *S, int N, int Npad, int mode, double *Wout,
+                              double *__restrict__ Wp)
+{
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t total = (size_t)Npad * Npad;
+    if (e >= total) return;
+    int h = (int)(e & 1);
+    int lane = (int)((e >> 1) & 63);
+    size_t gj = e >> 7;
+    int nk8 = Npad / 8;
+    int j = (int)(gj % nk8), g = (int)(gj / nk8);
+    int row = 16 * g + (lane & 15), col = 8 * j + 4 * h + (lane >> 4);
+    double v = 0.0;
+    if (row < N && col <= row) {
+        v = (mode == 0) ? S[(size_t)row * Npad + col] : S[(size_t)(N - 1 - col) * Npad + (N - 1 - row)];
+    }
+    Wp[e] = v;
+    if (Wout) Wout[(size_t)row * Npad + col] = v;
+}
+
+int launch_pack_w(const double *S, int N, int Npad, int mode, double *Wout, double *Wp, hipStream_t s)
+{
+    size_t total = (size_t)Npad * Npad;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, S, N, Npad, mode,
+                       Wout, Wp);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// alpha = W^T (W y), for y and for the all-ones vector (prior-mean term)
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_lower2_kernel(const double *__restrict__ W, int N, int Npad,
+                                                          const double *__restrict__ y, double *__restrict__ t2)
+{
+    int lane = threadIdx.x & 63;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Npad) return;
+    const double *w = W + (size_t)row * Npad;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = lane; k <= row && k < N; k += 64) {
+        double v = w[k];
+        s0 += v * y[k];
+        s1 += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if (lane == 0) { t2[row] = s0; t2[Npad + row] = s1; }
+}
+
+// partial[c][j] = sum_{i in chunk c, i >= j} W[i][j] t[i]; 256 columns x 64 rows per block
+__global__ __launch_bounds__(256) void gemvT_lower2_kernel(const double *__restrict__ W, int Npad,
+                                                           const double *__restrict__ t2,
+                                                           double *__restrict__ partial)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    int c = blockIdx.y;
+    if (j >= Npad) return;
+    double s0 = 0.0, s1 = 0.0;
+    int i0 = c * 64;
+    for (int i = max(i0, j); i < i0 + 64; i++) {
+        double v = W[(size_t)i * Npad + j];
+        s0 += v * t2[i];
+        s1 += v * t2[Npad + i];
+    }
+    int nch = Npad / 64;
+    partial[(size_t)c * Npad + j] = s0;
+    partial[(size_t)(nch + c) * Npad + j] = s1;
+}
+
+__global__ void alpha_reduce_kernel(const double *__restrict__ partial, int Npad, double *__restrict__ aY,
+                                    double *__restrict__ a1)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Npad) return;
+    int nch = Npad / 64;
+    double s0 = 0.0, s1 = 0.0;
+    for (int c = 0; c < nch; c++) {
+        s0 += partial[(size_t)c * Npad + j];
+        s1 += partial[(size_t)(nch + c) * Npad + j];
+    }
+    aY[j] = s0; a1[j] = s1;
+}
+
+// tmp2: 2*Npad (t vectors) + 2*(Npad/64)*Npad (partials) doubles
+int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2, double *alphaY,
+                 double *alpha1, hipStream_t s)
+{
+    double *t2 = tmp2, *partial = tmp2 + 2 * (size_t)Npad;
+    hipLaunchKernelGGL(gemv_lower2_kernel, dim3((Npad + 3) / 4), dim3(256), 0, s, W, N, Npad, y, t2);
+    dim3 grid((Npad + 255) / 256, Npad / 64);
+    hipLaunchKernelGGL(gemvT_lower2_kernel, grid, dim3(256), 0, s, W, Npad, t2, partial);
+    hipLaunchKernelGGL(alpha_reduce_kernel, dim3((Npad + 255) / 256), dim3(256), 0, s, partial, Npad, alphaY, alpha1);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// z = L^-1 y by blocked forward substitution (one workgroup), plus
+// |z|^2 and sum_i log L_ii over the first N rows -- the two scalars the
+// marginal likelihood needs (ego/gaussianprocess/trainhyper.py:60-68).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fwd_quad_logdet_kernel(const double *__restrict__ L, int N, int Npad,
+                                                              const double *__restrict__ diag64,
+                                                              const double *__restrict__ y, double *__restrict__ z,
+                                                              double *__restrict__ out2)
+{
+    __shared__ double rhs[64];
+    __shared__ double red[256];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int nb = Npad / 64;
+    double quad = 0.0, logdet = 0.0;
+    for (int jb = 0; jb < nb; jb++) {
+        // s[r] = sum_{k < 64 jb} L[64 jb + r][k] z[k]; wave wv takes rows wv*16 .. +15
+        for (int rr = 0; rr < 16; rr++) {
+            int r = wv * 16 + rr;
+            const double *row = L + (size_t)(jb * 64 + r) * Npad;
+            double sacc = 0.0;
+            for (int k = lane; k < jb * 64; k += 64) sacc += row[k] * z[k];
+            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+            if (lane == 0) {
+                int gi = jb * 64 + r;
+                rhs[r] = ((gi < N) ? y[gi] : 0.0) - sacc;
+            }
+        }
+        __syncthreads();
+        if (t < 64) {
+            const double *Dr = diag64 + (size_t)jb * 4096 + t * 64;
+            double v = 0.0;
+            for (int c = 0; c <= t; c++) v += Dr[c] * rhs[c];
+            int gi = jb * 64 + t;
+            z[gi] = v;
+            if (gi < N) { quad += v * v; logdet -= log(Dr[t]); }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    red[t] = (t < 64) ? quad : 0.0;
+    __syncthreads();
+    if (t == 0) { double s = 0.0; for (int i = 0; i < 64; i++) s += red[i]; out2[0] = s; }
+    __syncthreads();
+    red[t] = (t < 64) ? logdet : 0.0;
+    __syncthreads();
+    if (t == 0) { double s = 0.0; for (int i = 0; i < 64; i++) s += red[i]; out2[1] = s; }
+}
+
+int launch_fwd_quad_logdet(const double *L, int N, int Npad, const double *diag64, const double *y,
+                           double *z, double *out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(fwd_quad_logdet_kernel, dim3(1), dim3(256), 0, s, L, N, Npad, diag64, y, z, out2);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// fp64 MFMA fragment-layout self test: asymmetric integer operands, exact.
+// ------------------------------------------------------------------------
+__global__ void mfma_selftest_kernel(double *out_err)
+{
+    __shared__ double Cm[256];
+    int l = threadIdx.x;
+    // A[i][k] = 3 i + 7 k + 1 ; B[k][j] = 5 k - 2 j + (k == 1 ? 11 : 0)
+    int ai = l & 15, ak = l >> 4;
+    double a = 3.0 * ai + 7.0 * ak + 1.0;
+    int bk = l >> 4, bj = l & 15;
+    double b = 5.0 * bk - 2.0 * bj + (bk == 1 ? 11.0 : 0.0);
+    d4_t acc = {0, 0, 0, 0};
+    acc = mfma_f64(a, b, acc);
+    for (int r = 0; r < 4; r++) Cm[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+    __syncthreads();
+    double err = 0.0;
+    for (int e = l; e < 256; e += 64) {
+        int i = e >> 4, j = e & 15;
+        double ref = 0.0;
+        for (int k = 0; k < 4; k++) ref += (3.0 * i + 7.0 * k + 1.0) * (5.0 * k - 2.0 * j + (k == 1 ? 11.0 : 0.0));
+        err = fmax(err, fabs(ref - Cm[e]));
+    }
+    for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o));
+    if (l == 0) out_err[0] = err;
+}
+
+int launch_mfma_selftest(double *out_err, hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, s, out_err);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,347 @@
+// sweep.hip -- the fused candidate sweep on gfx950: for every candidate c
+//   k*_i = k(x_i, c);  mu = m(c) + aY.k* - m(c) a1.k*;  q = |W k*|^2;
+//   s2 = clamp(1+noise-q);  acq = EI/PI/UCB(mu, sqrt(s2));  arg-max over c.
+// It is the batched form of GP_Maximizer::posterior + negei/negpi/negucb
+// (cpp/optimizeGP.cpp:57-236) and of GaussianProcess.posterior
+// (ego/gaussianprocess/__init__.py:169-228).  K(X, X*) never touches HBM.
+//
+// Main kernel (sweep_mfma_kernel): one 512-thread workgroup per 64 candidates.
+//   * the N x 64 block of k* is produced 32 rows at a time into LDS, already in
+//     fp64-MFMA B-fragment order; observation rows are wave-uniform (scalar
+//     loads), the candidate sits in registers, one lane per candidate;
+//   * W = L^-1 is streamed from L2 in A-fragment order (pack_w_kernel), one
+//     16-byte load per lane per two k4-steps, and never staged in LDS: each
+//     wave owns distinct rows;
+//   * V = W K* is accumulated 512 rows at a time (8 waves x 4 row-blocks of 16
+//     x 4 candidate blocks of 16 = 128 accumulator VGPRs per lane); row blocks
+//     are interleaved over the waves so the triangular part stays balanced and
+//     the zero upper-triangular tiles are skipped;
+//   * the epilogue squares and reduces V down the rows, finishes mu/s2/acq and
+//     does a wave-level (max, lowest index) reduction -> one partial per tile.
+// Small batches (M <= 16) go through a row-parallel GEMV kernel instead.
+#include "ibo_common.h"
+
+#define TC 64          // candidates per workgroup
+#define NWAVE 8
+#define KC 32          // k rows of K* per LDS stage
+#define PANEL 512      // rows of V accumulated per pass = NWAVE * 4 * 16
+
+__device__ __forceinline__ double prior_mu_dev(const PriorDev &p, int D, const double *x)
+{
+    double m = 0.0;
+    for (int i = 0; i < p.nb; i++) {
+        double d = 0.0;
+        for (int j = 0; j < D; j++) {
+            double t = (x[j] - p.lowerb[j]) / p.width[j] - p.means[(size_t)i * D + j];
+            d += t * t;
+        }
+        m += p.beta[i] * exp(-p.theta * d);
+    }
+    return m;
+}
+
+// finish one candidate: returns the acquisition value, writes optional outputs
+__device__ __forceinline__ double finish_candidate(const SweepArgs &a, const double *x, double q, double muY,
+                                                   double mu1, int64_t gidx, bool valid, bool &excluded)
+{
+    double m = 0.0;
+    if (a.prior.nb > 0) m = prior_mu_dev(a.prior, a.kp.D, x);
+    double mu = (a.prior.nb > 0) ? (m + muY - m * mu1) : muY;
+    double s2 = 1.0 + a.noise - q;
+    if (s2 < a.clamp_lo) s2 = a.clamp_lo;
+    else if (s2 > 10.0) s2 = 10.0;
+    double val = (a.acq == 3) ? mu : acq_value_dev(a.acq, a.erf_mode, mu, sqrt(s2), a.ymax, a.parm);
+    excluded = false;
+    for (int e = 0; e < a.n_excl; e++) {
+        double d2 = 0.0;
+        for (int j = 0; j < a.kp.D; j++) { double t = x[j] - a.excl[(size_t)e * a.kp.D + j]; d2 += t * t; }
+        if (!(sqrt(d2) > a.excl_radius)) excluded = true;
+    }
+    if (valid) {
+        if (a.out_mu) a.out_mu[gidx] = mu;
+        if (a.out_s2) a.out_s2[gidx] = s2;
+        if (a.out_acq) a.out_acq[gidx] = val;
+    }
+    return val;
+}
+
+__device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(v, o);
+        int64_t oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+template <int FAM, int DP>
+__global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
+{
+    __shared__ double lds_k[2][KC * TC];          // K* stage, B-fragment order
+    __shared__ double lds_c[TC * DP];             // candidate coordinates
+    __shared__ double lds_q[NWAVE][TC];
+    __shared__ double lds_m[2][NWAVE][TC];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tile0 = (int64_t)blockIdx.x * TC;
+    const int D = a.kp.D;
+
+    for (int e = tid; e < TC * DP; e += 512) {
+        int c = e / DP, d = e - c * DP;
+        int64_t gi = tile0 + c;
+        if (gi > a.M - 1) gi = a.M - 1;
+        lds_c[e] = (d < D) ? a.cand[gi * D + d] : 0.0;
+    }
+    __syncthreads();
+    double cx[DP];
+#pragma unroll
+    for (int d = 0; d < DP; d++) cx[d] = lds_c[lane * DP + d];
+
+    const int Npad = a.Npad;
+    const int nk8 = Npad >> 3;
+    const int nRB = Npad >> 4;
+    const int npanel = (Npad + PANEL - 1) / PANEL;
+    const double2 *Wp2 = (const double2 *)a.Wp;
+    double muY = 0.0, mu1 = 0.0;
+    double qacc[4] = {0.0, 0.0, 0.0, 0.0};      // lanes 0..15 hold sums for candidate block cb
+
+    for (int p = 0; p < npanel; p++) {
+        const bool last = (p == npanel - 1);
+        const int kend = min((p + 1) * PANEL, Npad);
+        const int nchunk = kend / KC;
+        int g[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) g[i] = p * (PANEL / 16) + wave + NWAVE * i;
+        d4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) acc[i][cb] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+        // produce K* rows [k0, k0+KC) into stage b; this wave does rows k0+4*wave .. +3
+        auto gen = [&](int k0, int b) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int k = k0 + wave * 4 + kk;
+                const double *xr = a.Xp + (size_t)k * DP;
+                double z = 0.0;
+#pragma unroll
+                for (int d = 0; d < DP; d++) {
+                    double t = xr[d] - cx[d];
+                    z += a.kp.w[d] * (t * t);
+                }
+                double kv = cov_from_z<FAM>(z, a.kp.sf2);
+                lds_k[b][(wave * 4 + (lane >> 4)) * 64 + kk * 16 + (lane & 15)] = kv;
+                if (last) {
+                    muY += a.alphaY[k] * kv;
+                    mu1 += a.alpha1[k] * kv;
+                }
+            }
+        };
+
+        gen(0, 0);
+        __syncthreads();
+        for (int t = 0; t < nchunk; t++) {
+            const int b = t & 1;
+            const int k0 = t * KC;
+            if (t + 1 < nchunk) gen(k0 + KC, b ^ 1);
+#pragma unroll
+            for (int jj = 0; jj < KC / 8; jj++) {
+                const int j = (k0 >> 3) + jj;
+                double2 af[4];
+                bool act[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    // row-block g[i] has non-zeros in columns <= 16 g[i] + 15
+                    act[i] = (g[i] < nRB) && (8 * j <= 16 * g[i] + 15);
+                    if (act[i]) af[i] = Wp2[((size_t)g[i] * nk8 + j) * 64 + lane];
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int s4 = jj * 2 + h;
+                    double bf[4];
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++) bf[cb] = lds_k[b][(s4 * 4 + cb) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (act[i]) {
+                            const double av = h ? af[i].y : af[i].x;
+#pragma unroll
+                            for (int cb = 0; cb < 4; cb++) acc[i][cb] = mfma_f64(av, bf[cb], acc[i][cb]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // |V|^2 down the rows of this panel: acc[i][cb][r] is row (lane>>4)+4r, column lane&15
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s += acc[i][cb][r] * acc[i][cb][r];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            qacc[cb] += s;
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) lds_q[wave][cb * 16 + lane] = qacc[cb];
+    }
+    lds_m[0][wave][lane] = muY;
+    lds_m[1][wave][lane] = mu1;
+    __syncthreads();
+    if (wave == 0) {
+        double q = 0.0, my = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; w++) { q += lds_q[w][lane]; my += lds_m[0][w][lane]; m1 += lds_m[1][w][lane]; }
+        int64_t li = tile0 + lane;
+        bool valid = li < a.M;
+        double xq[DP];
+#pragma unroll
+        for (int d = 0; d < DP; d++) xq[d] = cx[d];
+        bool excl;
+        double val = finish_candidate(a, xq, q, my, m1, li, valid, excl);
+        int64_t idx = a.index_base + li;
+        if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
+        wave_argmax(val, idx);
+        if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+    }
+}
+
+// ------------------------------------------------------------------------
+// small-batch path: grid (row chunks of 64, M).  Each workgroup rebuilds k*
+// for its candidate in LDS and reduces 64 rows of W k*.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_gemv_kernel(SweepArgs a)
+{
+    extern __shared__ double ks[];      // Npad
+    __shared__ double red[4][3];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t c = blockIdx.y;
+    const int rc = blockIdx.x;
+    const int D = a.kp.D, Npad = a.Npad, DP = a.DP;
+    const double *x = a.cand + c * D;
+    const int kmax = min(Npad, rc * 64 + 64);       // rows of this chunk need k < kmax only
+    const int kneed = (rc == 0) ? Npad : kmax;      // chunk 0 also forms the mean
+    double py = 0.0, p1 = 0.0;
+    for (int k = t; k < kneed; k += 256) {
+        const double *xr = a.Xp + (size_t)k * DP;
+        double z = 0.0;
+        for (int d = 0; d < D; d++) { double u = xr[d] - x[d]; z += a.kp.w[d] * (u * u); }
+        double kv = cov_from_z_rt(a.kp.family, z, a.kp.sf2);
+        ks[k] = kv;
+        if (rc == 0) { py += a.alphaY[k] * kv; p1 += a.alpha1[k] * kv; }
+    }
+    __syncthreads();
+    double qs = 0.0;
+    for (int rr = 0; rr < 16; rr++) {
+        int row = rc * 64 + wv * 16 + rr;
+        if (row >= Npad) break;
+        const double *w = a.W + (size_t)row * Npad;
+        double s = 0.0;
+        for (int k = lane; k <= row; k += 64) s += w[k] * ks[k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        qs += s * s;
+    }
+    for (int o = 32; o > 0; o >>= 1) { py += __shfl_xor(py, o); p1 += __shfl_xor(p1, o); }
+    if (lane == 0) { red[wv][0] = qs; red[wv][1] = py; red[wv][2] = p1; }
+    __syncthreads();
+    if (t == 0) {
+        a.qpart[(size_t)rc * a.M + c] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        if (rc == 0) {
+            a.mupart[c] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+            a.mupart[a.M + c] = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void sweep_gemv_finish_kernel(SweepArgs a, int nrc)
+{
+    const int lane = threadIdx.x;
+    int64_t li = (int64_t)blockIdx.x * 64 + lane;
+    bool valid = li < a.M;
+    int64_t ci = valid ? li : a.M - 1;
+    double q = 0.0;
+    for (int rc = 0; rc < nrc; rc++) q += a.qpart[(size_t)rc * a.M + ci];
+    double xq[IBO_DMAX];
+    for (int d = 0; d < a.kp.D; d++) xq[d] = a.cand[ci * a.kp.D + d];
+    bool excl;
+    double val = finish_candidate(a, xq, q, a.mupart[ci], a.mupart[a.M + ci], li, valid, excl);
+    int64_t idx = a.index_base + li;
+    if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
+    wave_argmax(val, idx);
+    if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+}
+
+// final (max, lowest index) over the per-tile partials: one workgroup, fixed order
+__global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restrict__ pv,
+                                                           const int64_t *__restrict__ pi, int64_t n,
+                                                           double *out_v, int64_t *out_i)
+{
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
+    double v = -INFINITY;
+    int64_t i = INT64_MAX;
+    for (int64_t e = threadIdx.x; e < n; e += 256) {
+        double ov = pv[e]; int64_t oi = pi[e];
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    wave_argmax(v, i);
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (sv[w] > v || (sv[w] == v && si[w] < i)) { v = sv[w]; i = si[w]; }
+        out_v[0] = v;
+        out_i[0] = (i == INT64_MAX) ? -1 : i;
+    }
+}
+
+template <int FAM>
+static int launch_mfma_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    dim3 grid((unsigned)ntiles), block(512);
+    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4>), grid, block, 0, s, a);
+    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16>), grid, block, 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    int64_t ntiles = (a.M + TC - 1) / TC;
+    int rc;
+    if (e0) (void)hipEventRecord(e0, s);
+    if (a.kp.family == FAM_SE) rc = launch_mfma_fam<FAM_SE>(a, ntiles, s);
+    else if (a.kp.family == FAM_M3) rc = launch_mfma_fam<FAM_M3>(a, ntiles, s);
+    else rc = launch_mfma_fam<FAM_M5>(a, ntiles, s);
+    if (e1) (void)hipEventRecord(e1, s);
+    if (rc) return rc;
+    return launch_argmax_final(a, ntiles, s);
+}
+
+int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    int nrc = a.Npad / 64;
+    dim3 grid(nrc, (unsigned)a.M);
+    if (e0) (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(sweep_gemv_kernel, grid, dim3(256), sizeof(double) * a.Npad, s, a);
+    if (e1) (void)hipEventRecord(e1, s);
+    int64_t ntiles = (a.M + 63) / 64;
+    hipLaunchKernelGGL(sweep_gemv_finish_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, a, nrc);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return launch_argmax_final(a, ntiles, s);
+}
+
+int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, a.part_val, a.part_idx, ntiles,
+                       a.result_val, a.result_idx);
+    return (int)hipGetLastError();
+}

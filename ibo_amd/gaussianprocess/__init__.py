@@ -1,0 +1,407 @@
+"""
+Gaussian-process models with the reference's API (ego/gaussianprocess/__init__.py)
+on the MI355X backend.
+
+    GaussianProcess(kernel, X=None, Y=None, prior=None, noise=.1, gnoise=1e-4, G=None)
+        .addData(X, Y)  .posterior(x, getvar=True)  .posteriors(X)  .mu(x)  .negmu(x)
+        .getYfromX(qx)  .done(x)   attributes X, Y, R, L, noise, kernel, prior, ...
+    PrefGaussianProcess(kernel, prefs=None, **kw)
+        .addPreferences(prefs)  .addObservationPoint(x)   attributes preferences, C
+
+Everything numerical -- K(X,X), Cholesky, L^-1, posterior mean/variance -- runs
+in libibo_hip on the GPU; this file holds the bookkeeping the reference keeps
+in Python (data accumulation, preference indexing, the MAP optimiser's control
+flow).  There is no NumPy fallback: without the library or a GPU, fitting raises.
+"""
+import ctypes
+from time import time
+
+import numpy as np
+
+from .. import _lib
+from .._lib import NotPositiveDefinite
+from .kernel import GaussianKernel_ard, GaussianKernel_iso, MaternKernel3, MaternKernel5  # noqa: F401
+
+LinAlgError = np.linalg.LinAlgError
+
+
+# ---------------------------------------------------------------------------
+# scalar helpers kept for API compatibility (ego/gaussianprocess/__init__.py:55-77):
+# Numerical-Recipes erf (fractional error 1.2e-7) and the CDF/PDF built on it.
+# The device twin is erf_nr_dev in csrc/ibo_common.h.
+# ---------------------------------------------------------------------------
+def erf(z):
+    t = 1.0 / (1.0 + 0.5 * abs(z))
+    poly = 0.17087277
+    for c in (-0.82215223, 1.48851587, -1.13520398, 0.27886807, -0.18628806, 0.09678418, 0.37409196, 1.00002368):
+        poly = c + t * poly
+    ans = 1 - t * np.exp(-z * z - 1.26551223 + t * poly)
+    return ans if z >= 0.0 else -ans
+
+
+def CDF(x):
+    return 0.5 * (1 + erf(x * 0.707106))
+
+
+def PDF(x):
+    return np.exp(-(x ** 2 / 2)) * 0.398942
+
+
+class _DeviceGP(object):
+    """owner of one ibo_gp_t handle"""
+
+    def __init__(self, device=None):
+        self.device = _lib.default_device() if device is None else device
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib.ibo_gp_create(self.device, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            try:
+                _lib.lib.ibo_gp_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class GaussianProcess(object):
+
+    def __init__(self, kernel, X=None, Y=None, prior=None, noise=.1, gnoise=1e-4, G=None, device=None):
+        self.kernel = kernel
+        self.prior = prior
+        self.noise = noise
+        self.gnoise = np.array(gnoise, ndmin=1)
+        self._device = device
+        self._dev = None            # _DeviceGP, created at the first fit
+        self._cache = {}
+
+        if (X is None and Y is not None) or (X is not None and Y is None):
+            raise ValueError
+
+        self.X = np.zeros((0, 0))
+        self.Y = np.zeros((0))
+        self.G = None
+        self.name = 'GP'
+        self.starttime = time()
+
+        if G is not None:
+            raise NotImplementedError("gradient observations are dead code in the reference "
+                                      "(covWithGradients is never defined) and are not supported")
+        if X is not None:
+            self.addData(X, Y)
+
+        self.augR = None
+        self.augL = None
+        self.augX = None
+        self._augdev = None
+        self.selected = None
+        self.endtime = None
+
+    # ------------------------------------------------------------------ device plumbing
+    def _handle(self):
+        if self._dev is None:
+            self._dev = _DeviceGP(self._device)
+        return self._dev.h
+
+    def _fit_device(self, A=None, dev=None, X=None):
+        """(re)fit on the GPU: R, L = chol(R or A), W = L^-1, alpha (csrc/abi.hip fit_impl)"""
+        X = self.X if X is None else X
+        ktype, hyper, sf2, _ = self.kernel._ibo_spec()
+        h = self._handle() if dev is None else dev.h
+        N, D = X.shape
+        Xc = _lib.f64(X)
+        Yc = _lib.f64(self.Y) if len(self.Y) == N else np.zeros(N)
+        info = ctypes.c_int(0)
+        if A is None:
+            rc = _lib.lib.ibo_gp_fit(h, ktype, N, D, _lib.dp(Xc), _lib.dp(Yc), _lib.dp(hyper), len(hyper), sf2,
+                                     float(self.noise), ctypes.byref(info))
+        else:
+            Ac = _lib.f64(A)
+            rc = _lib.lib.ibo_gp_fit_with_matrix(h, ktype, N, D, _lib.dp(Xc), _lib.dp(Yc), _lib.dp(hyper), len(hyper),
+                                                 sf2, float(self.noise), _lib.dp(Ac), ctypes.byref(info))
+        _lib.check(rc)
+        if dev is None:
+            self._cache = {}
+            self._push_prior()
+
+    def _push_prior(self):
+        p = self.prior
+        h = self._handle()
+        if p is None or getattr(p, "means", None) is None:
+            _lib.check(_lib.lib.ibo_gp_set_prior(h, 0, None, None, 0.0, None, None))
+            return
+        means = _lib.f64(np.array(p.means).reshape(len(p.beta), -1))
+        beta = _lib.f64(p.beta); lo = _lib.f64(p.lowerb); wd = _lib.f64(p.width)
+        _lib.check(_lib.lib.ibo_gp_set_prior(h, len(beta), _lib.dp(means), _lib.dp(beta), float(p.theta),
+                                             _lib.dp(lo), _lib.dp(wd)))
+
+    def _get_matrix(self, name):
+        if name not in self._cache:
+            N = len(self.X)
+            out = np.empty((N, N))
+            fn = getattr(_lib.lib, "ibo_gp_get_" + name)
+            _lib.check(fn(self._handle(), _lib.dp(out)))
+            self._cache[name] = out
+        return self._cache[name]
+
+    @property
+    def R(self):
+        if len(self.X) == 0:
+            return None
+        return self._get_matrix("R")
+
+    @R.setter
+    def R(self, v):          # the reference initialises self.R = None
+        if v is not None:
+            self._cache["R"] = v
+
+    @property
+    def L(self):
+        return self._get_matrix("L")
+
+    @L.setter
+    def L(self, v):
+        self._cache["L"] = v
+
+    def last_fit_ms(self):
+        ms = ctypes.c_float(0)
+        _lib.check(_lib.lib.ibo_gp_last_fit_ms(self._handle(), ctypes.byref(ms)))
+        return ms.value
+
+    def _eval(self, Q, acq=_lib.ACQ_NONE, parm=0.0, erf_mode=_lib.ERF_NR, clamp_lo=_lib.CLAMP_PY,
+              want=("mu", "s2"), ymax=None):
+        """host points in, host arrays out, through the device sweep (PCIe-inclusive)"""
+        Q = _lib.f64(np.atleast_2d(Q))
+        M, D = Q.shape
+        cand = _lib.DeviceArray.from_host(Q, self._dev.device)
+        outs = {k: _lib.DeviceArray((M,), self._dev.device) for k in want}
+        bv = ctypes.c_double(); bi = ctypes.c_int64()
+        _lib.check(_lib.lib.ibo_acq_sweep(
+            self._handle(), M, cand.ptr, acq, float(parm), erf_mode, clamp_lo,
+            float('nan') if ymax is None else float(ymax), 0, None, 0.0, 0,
+            outs["mu"].ptr if "mu" in outs else None, outs["s2"].ptr if "s2" in outs else None,
+            outs["acq"].ptr if "acq" in outs else None, ctypes.byref(bv), ctypes.byref(bi)))
+        res = {k: v.to_host() for k, v in outs.items()}
+        res["best_val"], res["best_idx"] = bv.value, bi.value
+        return res
+
+    # ------------------------------------------------------------------ reference API
+    def posterior(self, X, getvar=True):
+        """posterior mean (and variance) at ONE point (ego/gaussianprocess/__init__.py:169-228)"""
+        if len(self.X) == 0:
+            if self.prior is None:
+                return (0.0, 1.0) if getvar else 0.0
+            return (self.prior.mu(X), 1.0) if getvar else self.prior.mu(X)
+        X = np.array(X, dtype=float, ndmin=2)
+        mu, s2 = self._posterior_arrays(X[:1], getvar)
+        if getvar:
+            return mu[0], s2[0]
+        return mu[0]
+
+    def _posterior_arrays(self, Q, getvar=True):
+        Q = _lib.f64(np.atleast_2d(Q))
+        M = len(Q)
+        mu = np.empty(M)
+        s2 = np.empty(M) if getvar else None
+        _lib.check(_lib.lib.ibo_posterior_batch(self._handle(), M, _lib.dp(Q), _lib.CLAMP_PY, _lib.dp(mu),
+                                                _lib.dp(s2) if getvar else None))
+        if getvar and self._augdev is not None:
+            # variance from the augmented factor (addObservationPoint), :214-223
+            mu2 = np.empty(M)
+            _lib.check(_lib.lib.ibo_posterior_batch(self._augdev.h, M, _lib.dp(Q), _lib.CLAMP_PY, _lib.dp(mu2),
+                                                    _lib.dp(s2)))
+        return mu, s2
+
+    def posteriors(self, X):
+        """arrays of posterior means and variances (:231-244) -- one batched GPU call"""
+        if len(self.X) == 0:
+            pairs = [self.posterior(x) for x in X]
+            return np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+        Q = np.array([np.atleast_1d(np.asarray(x, dtype=float)) for x in X])
+        return self._posterior_arrays(Q, True)
+
+    def mu(self, x):
+        return self.posterior(x, getvar=False)
+
+    def negmu(self, x):
+        return -self.mu(x)
+
+    def addData(self, X, Y, G=None):
+        """append observations and refit (:267-308).  X (N,D) or (D,); Y vector or scalar."""
+        if G is not None:
+            raise NotImplementedError("gradient observations are not supported")
+        X = np.array(X, dtype=float, ndmin=2)
+        Y = np.array(Y, dtype=float, ndmin=1).flatten()
+        assert len(Y) == len(X), 'wrong number of Y-observations given'
+        if len(self.X) == 0 and len(self.gnoise) == 1:
+            self.gnoise = np.tile(self.gnoise, X.shape[1])
+        if len(self.X) == 0:
+            self.X = np.copy(X)
+            self.Y = np.copy(Y)
+        else:
+            self.X = np.r_[self.X, X]
+            self.Y = np.r_[self.Y, Y]
+        # the reference extends L block-wise; refitting from R gives the same R and a
+        # factor that is identical for batch and sequential construction
+        self._fit_device()
+
+    def getYfromX(self, qx):
+        for x, y in zip(self.X, self.Y):
+            if np.all(qx == x):
+                return y
+        return None
+
+    def done(self, x):
+        self.selected = x
+        self.endtime = time()
+
+    def __deepcopy__(self, memo):
+        from copy import deepcopy
+        g = GaussianProcess(deepcopy(self.kernel, memo), prior=self.prior, noise=self.noise, device=self._device)
+        if len(self.X):
+            g.addData(self.X.copy(), self.Y.copy())
+        return g
+
+
+class PrefGaussianProcess(GaussianProcess):
+    """GP trained on pairwise preferences (ego/gaussianprocess/__init__.py:331-527)."""
+
+    def __init__(self, kernel, prefs=None, **kwargs):
+        super(PrefGaussianProcess, self).__init__(kernel, **kwargs)
+        self.preferences = []
+        self.C = None
+        if prefs is not None:
+            self.addPreferences(prefs)
+
+    @staticmethod
+    def _S_and_grad(y, inds, Rinv):
+        """MAP functional (:351-385) and its analytic gradient.
+        S(y) = -sum (d+1) log(Phi((y_v-y_u)/sqrt 2) + 1e-10) + y^T R^-1 y / 2"""
+        v = np.array([i[0] for i in inds]); u = np.array([i[1] for i in inds])
+        w = np.array([i[2] + 1.0 for i in inds])
+        z = (y[v] - y[u]) / np.sqrt(2)
+        # keep the reference's CDF definition (NR erf with truncated 1/sqrt2) so S is the same function
+        cdf = np.array([CDF(zz) for zz in z])
+        pdf = np.exp(-(z * 0.707106) ** 2) * (2 / np.sqrt(np.pi)) * 0.5 * 0.707106
+        Ry = Rinv.dot(y)
+        S = -np.sum(w * np.log(cdf + 1e-10)) + 0.5 * y.dot(Ry)
+        gz = -w * pdf / (cdf + 1e-10) / np.sqrt(2)
+        g = Ry.copy()
+        np.add.at(g, v, gz)
+        np.add.at(g, u, -gz)
+        return S, g
+
+    def addPreferences(self, prefs, useC=True, showPrefLikelihood=False):
+        """add (x_preferred, x_unpreferred, degree) triples and refit from ALL preferences (:347-498)"""
+        from scipy.optimize import minimize
+        self.preferences.extend(prefs)
+
+        x2ind = {}
+        prefinds = []
+        vs = set()
+        for v, u, d in self.preferences:
+            v = tuple(np.asarray(v, dtype=float)); u = tuple(np.asarray(u, dtype=float))
+            vs.add(v)
+            if v not in x2ind:
+                x2ind[v] = len(x2ind)
+            if u not in x2ind:
+                x2ind[u] = len(x2ind)
+            prefinds.append((x2ind[v], x2ind[u], d))
+        newX = np.array([x for x, _ in sorted(x2ind.items(), key=lambda t: t[1])], dtype=float)
+
+        lastY = {}
+        for x, y in zip(self.X, self.Y):
+            lastY[tuple(x)] = y
+        if len(self.Y) > 0:
+            ymax, ymin = max(self.Y), min(self.Y)
+        else:
+            ymax, ymin = .5, -.5
+        start = []
+        for x in newX:
+            if tuple(x) in lastY:
+                start.append(lastY[tuple(x)])
+            else:
+                start.append(ymax if tuple(x) in vs else ymin)
+
+        # K(X,X), Cholesky and L^-1 on the GPU (:432-438)
+        self.X = newX
+        self.Y = np.array(start, dtype=float)
+        self.C = None
+        self._augdev = None
+        self.augR = self.augL = self.augX = None
+        self._fit_device()
+        N = len(newX)
+        W = np.empty((N, N))
+        _lib.check(_lib.lib.ibo_gp_get_W(self._handle(), _lib.dp(W)))
+        Rinv = W.T.dot(W)
+
+        # MAP by quasi-Newton on S (:442).  The reference runs fmin_bfgs with numerical
+        # gradients (gtol 1e-5); the analytic gradient reaches the same convex optimum.
+        res = minimize(self._S_and_grad, np.array(start, dtype=float), args=(prefinds, Rinv), jac=True,
+                       method="BFGS", options=dict(gtol=1e-7, maxiter=2000))
+        Y = res.x
+        for r, c, _ in prefinds:                      # order fix-up (:445-457)
+            if Y[r] <= Y[c]:
+                if not any(c1 == r for _, c1, _ in prefinds):
+                    Y[r] = Y[c] + .1
+        self._set_map(Y, prefinds)
+
+    def _set_map(self, Y, prefinds):
+        """everything downstream of the MAP (:459-498): C matrix, L = chol(R + C^-1)"""
+        self.Y = np.array(Y, dtype=float)
+        _lib.check(_lib.lib.ibo_gp_set_y(self._handle(), _lib.dp(_lib.f64(self.Y))))
+        mu = self._posterior_arrays(self.X, getvar=False)[0]      # L = chol(R) at this point
+        n = len(self.X)
+        C = np.eye(n) * 5
+        for v, u, _ in prefinds:
+            d = (mu[v] - mu[u]) / (np.sqrt(2) * np.sqrt(self.noise))
+            cdf = max(CDF(d), 1e-10)
+            pdf = max(PDF(d), 1e-10)
+            w = 1.0 / (2 * self.noise) * (pdf ** 2 / cdf ** 2 + d * pdf / cdf)
+            C[v, u] -= w; C[u, v] -= w
+            C[v, v] += w; C[u, u] += w
+        self.C = C
+        R = self.R.copy()
+        for i in range(11):
+            try:
+                self._fit_device(A=R + np.linalg.inv(self.C))
+                break
+            except NotPositiveDefinite:
+                print('[addPreferences] GP.C matrix is ill-conditioned, adding regularizer delta = %d' % (i + 1))
+                self.C += np.eye(n)
+        self._cache["R"] = R
+
+    def addObservationPoint(self, X):
+        """add a point to observe at, without its observation (:502-519)"""
+        X = np.array(X, dtype=float, ndmin=2)
+        if self.augR is None:
+            self.augR = self.R.copy()
+            self.augX = self.X.copy()
+        ktype, hyper, sf2, _ = self.kernel._ibo_spec()
+        augX = np.r_[self.augX, X]
+        n = len(augX)
+        K = np.empty((n, n))
+        Xc = _lib.f64(augX)
+        _lib.check(_lib.lib.ibo_cov_matrix(self._dev.device, ktype, Xc.shape[1], _lib.dp(hyper), len(hyper), sf2, n,
+                                           _lib.dp(Xc), 0, None, _lib.DIAG_UNIT_PLUS_NOISE, float(self.noise),
+                                           _lib.dp(K)))
+        self.augR = K
+        invC = np.zeros_like(K)
+        m = self.C.shape[0]
+        invC[:m, :m] = np.linalg.inv(self.C)
+        self.augX = augX
+        if self._augdev is None:
+            self._augdev = _DeviceGP(self._dev.device)
+        self._fit_device(A=K + invC, dev=self._augdev, X=augX)
+        Lh = np.empty((n, n))
+        _lib.check(_lib.lib.ibo_gp_get_L(self._augdev.h, _lib.dp(Lh)))
+        self.augL = Lh
+
+    def addData(self, X, Y, G=None):
+        if getattr(self, "preferences", None) is None:      # called from the base constructor
+            return GaussianProcess.addData(self, X, Y, G)
+        raise NotImplementedError("can't (yet) add explicit ratings to preference GP")

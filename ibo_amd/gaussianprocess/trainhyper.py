@@ -1,0 +1,96 @@
+"""
+Marginal likelihood of the GP hyper-parameters (ego/gaussianprocess/trainhyper.py).
+
+    marginalLikelihood(kernel, X, Y, nhyper, computeGradient=True, useCholesky=True, noise=1e-3)
+    nlml(loghyper, Kernel, X, Y)     dnlml(loghyper, Kernel, X, Y)     nlmlMulti(...)
+    nlml_grid(KernelClass, thetas, X, Y, noise=1e-3)      <- new: a whole theta grid in one call
+
+The value (K assembly, Cholesky, L^-1 Y, log det) is computed on the GPU by
+ibo_nlml_grid.  The gradient needs K^-1 - alpha alpha^T against dK/dtheta_i; K^-1
+comes from the device factorisation and the contraction is assembled on the host
+(row (f)-2 of SURVEY 8: the gradient is not on this round's accelerated path).
+"""
+import numpy as np
+from numpy.linalg import LinAlgError
+
+from .. import _lib
+
+
+def _spec_rows(kernels):
+    specs = [k._ibo_spec() for k in kernels]
+    ktype = specs[0][0]
+    thetas = _lib.f64(np.array([s[1] for s in specs]))
+    sf2 = _lib.f64([s[2] for s in specs])
+    return ktype, thetas, sf2
+
+
+def nlml_values(kernels, X, Y, noise=1e-3, device=None):
+    """NLML for a list of kernel objects of one class (a theta grid); NaN where K is not PD."""
+    X = _lib.f64(np.vstack(X)); Y = _lib.f64(Y)
+    N, D = X.shape
+    ktype, thetas, sf2 = _spec_rows(kernels)
+    out = np.empty(len(kernels))
+    dev = _lib.default_device() if device is None else device
+    _lib.check(_lib.lib.ibo_nlml_grid(dev, ktype, N, D, _lib.dp(X), _lib.dp(Y), len(kernels), _lib.dp(thetas),
+                                      thetas.shape[1], _lib.dp(sf2), float(noise), _lib.dp(out)))
+    return out
+
+
+def nlml_grid(Kernel, thetas, X, Y, noise=1e-3, device=None):
+    """NLML at every row of `thetas` (hyper-parameters, NOT logs); returns (values, argmin)."""
+    vals = nlml_values([Kernel(np.asarray(t, dtype=float)) for t in thetas], X, Y, noise, device)
+    return vals, int(np.nanargmin(vals))
+
+
+def marginalLikelihood(kernel, X, Y, nhyper, computeGradient=True, useCholesky=True, noise=1e-3):
+    """negative log marginal likelihood and (optionally) its partial derivatives w.r.t.
+    each log hyper-parameter (trainhyper.py:47-95).  useCholesky is accepted for
+    signature compatibility; the device path always factors."""
+    NX = len(X)
+    assert NX == len(Y)
+    v = nlml_values([kernel], X, Y, noise)[0]
+    if not np.isfinite(v):
+        raise LinAlgError("covariance matrix is not positive definite for hyperparameters %s"
+                          % (kernel.hyperparams,))
+    if not computeGradient:
+        return v
+    # gradient: W = K^-1 - alpha alpha^T, dnlml_i = sum(W * dK/dtheta_i) / 2   (:70-71)
+    Xa = _lib.f64(np.vstack(X)); Ya = _lib.f64(Y)
+    K = kernel.covMatrix(Xa) + np.eye(NX) * noise
+    from . import GaussianProcess          # device factorisation of an explicit matrix
+    g = GaussianProcess.__new__(GaussianProcess)
+    GaussianProcess.__init__(g, kernel, noise=0.0)
+    g.X, g.Y = Xa, Ya
+    g._fit_device(A=K)
+    Wl = np.empty((NX, NX))
+    _lib.check(_lib.lib.ibo_gp_get_W(g._handle(), _lib.dp(Wl)))
+    Kinv = Wl.T.dot(Wl)
+    alpha = Kinv.dot(Ya)
+    Wm = Kinv - np.outer(alpha, alpha)
+    d = np.array([np.sum(Wm * kernel.derivative(Xa, i)) / 2.0 for i in range(nhyper)])
+    return v, d
+
+
+def nlml(loghyper, kernel, X, Y, *args):
+    """NLML as a function of LOG hyper-parameters (trainhyper.py:99-115); 100 when not PD."""
+    k = kernel(np.exp(loghyper))
+    try:
+        ml = marginalLikelihood(k, X, Y, len(loghyper), computeGradient=False)
+    except LinAlgError as e:
+        print(e)
+        ml = 100
+        print('returning nlml = 100')
+    return ml
+
+
+def nlmlMulti(loghyper, kernel, X, Y, *args):
+    k = kernel(np.exp(loghyper))
+    ml = 0.0
+    for x, y in zip(X, Y):
+        ml += marginalLikelihood(k, x, y, len(loghyper))[0]
+    return ml
+
+
+def dnlml(loghyper, kernel, X, Y):
+    k = kernel(np.exp(loghyper))
+    return marginalLikelihood(k, X, Y, len(loghyper), computeGradient=True)[1]

@@ -1,0 +1,126 @@
+"""
+Multi-GPU candidate sweep: the candidate array is cut into contiguous row blocks,
+one per rank (one process per GPU); every rank holds the whole fitted GP
+(refitting redundantly is cheaper than broadcasting L^-1 at these N) and sweeps
+its own block with no data-path communication.  One exchange per sweep then
+agrees on the arg-max: each rank writes (value, global index, valid, payload)
+into its own slot of a zero buffer, a single all-reduce(sum) gathers the slots
+(RCCL has no MAXLOC), and every rank applies the same deterministic reduction:
+largest value, ties to the lowest global index (numpy.argmax order).
+
+The transport is pluggable: `RcclArgmax` is libibo_hip's RCCL path over xGMI
+(csrc/comm.hip); `TorchArgmax` runs the identical slot protocol over any
+torch.distributed backend -- it exists so the protocol is testable on CPU with
+gloo (tests/test_multigpu_gloo.py) and is not used on the GPU path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_bounds(M, world_size, rank):
+    """contiguous block [start, stop) of rank `rank` among `world_size`;
+    the first M % world_size ranks take one extra row"""
+    base, rem = divmod(int(M), int(world_size))
+    start = rank * base + min(rank, rem)
+    stop = start + base + (1 if rank < rem else 0)
+    return start, stop
+
+
+def reduce_slots(buf, world_size, npayload):
+    """final reduction over the gathered slot buffer -> (val, idx, payload, rank);
+    idx = -1 when no rank had an admissible candidate.  Mirrors slot_argmax in csrc/comm.hip."""
+    slot = 3 + npayload
+    buf = np.asarray(buf, dtype=float).reshape(world_size, slot)
+    best = None
+    for r in range(world_size):
+        v, i, ok = buf[r, 0], int(buf[r, 1]), buf[r, 2]
+        if ok == 0.0:
+            continue
+        if best is None or v > best[0] or (v == best[0] and i < best[1]):
+            best = (v, i, buf[r, 3:].copy(), r)
+    if best is None:
+        return 0.0, -1, np.zeros(npayload), -1
+    return best
+
+
+def fill_slot(world_size, rank, val, idx, payload):
+    npayload = len(payload)
+    slot = 3 + npayload
+    buf = np.zeros(world_size * slot)
+    if idx is not None and idx >= 0 and val == val:
+        buf[rank * slot:rank * slot + 3] = (val, float(idx), 1.0)
+        buf[rank * slot + 3:(rank + 1) * slot] = payload
+    return buf
+
+
+class TorchArgmax(object):
+    """slot protocol over torch.distributed (CPU/gloo tests)"""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def argmax(self, val, idx, payload=()):
+        import torch
+        payload = np.asarray(payload, dtype=float).reshape(-1)
+        t = torch.from_numpy(fill_slot(self.world_size, self.rank, val, idx, payload))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return reduce_slots(t.numpy(), self.world_size, len(payload))
+
+
+class RcclArgmax(object):
+    """slot protocol over RCCL/xGMI through libibo_hip (one communicator per process)"""
+
+    def __init__(self, world_size, rank, unique_id, device=None):
+        self.world_size, self.rank = world_size, rank
+        self.device = _lib.default_device() if device is None else device
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib.ibo_comm_init(self.device, world_size, rank, unique_id, ctypes.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib.ibo_comm_get_unique_id(buf))
+        return buf.raw
+
+    def argmax(self, val, idx, payload=()):
+        payload = _lib.f64(np.asarray(payload, dtype=float).reshape(-1))
+        n = len(payload)
+        bv = ctypes.c_double(); bi = ctypes.c_int64(); br = ctypes.c_int()
+        bp = np.zeros(max(n, 1))
+        _lib.check(_lib.lib.ibo_comm_argmax(self.h, float(val), int(idx), _lib.dp(payload) if n else None, n,
+                                            ctypes.byref(bv), ctypes.byref(bi), _lib.dp(bp), ctypes.byref(br)))
+        return bv.value, bi.value, bp[:n], br.value
+
+    def barrier(self):
+        _lib.check(_lib.lib.ibo_comm_barrier(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib.ibo_comm_destroy(self.h)
+            self.h = None
+
+
+def sharded_sweep(model, local_candidates, start, comm, **sweep_kw):
+    """sweep this rank's block (rows [start, start+len)) and agree on the global arg-max.
+    Returns dict(best_val, best_idx (global), best_x, best_rank, kernel_ms)."""
+    from .acquisition import sweep
+    r = sweep(model, local_candidates, index_base=start, **sweep_kw)
+    D = local_candidates.shape[1]
+    if r["best_idx"] >= 0:
+        li = r["best_idx"] - start
+        if isinstance(local_candidates, _lib.DeviceArray):
+            x = local_candidates.view_rows(li, li + 1).to_host()[0]
+        else:
+            x = np.asarray(local_candidates[li], dtype=float)
+    else:
+        x = np.zeros(D)
+    v, i, p, rk = comm.argmax(r["best_val"], r["best_idx"], x)
+    return dict(best_val=v, best_idx=i, best_x=p, best_rank=rk, kernel_ms=r["kernel_ms"], local=r)

@@ -1,0 +1,271 @@
+/*
+ * ibo_abi.h -- C ABI of libibo_hip.so, the MI355X (gfx950) implementation of the
+ * GP-posterior + acquisition hot path of misterwindupbird/IBO.
+ *
+ * Two groups of entry points:
+ *
+ *  (A) LEGACY symbols -- byte-for-byte the signatures the reference's Python
+ *      binds with ctypes today, so the .so is a drop-in for cpp/libs/libego:
+ *        acqmaxGP   replaces  cpp/optimizeGP.cpp:262-283
+ *                   bound at  ego/acquisition/__init__.py:343-364
+ *        direct     replaces  cpp/direct.cpp:329 (cpp/direct.h:76)
+ *                   bound at  ego/utils/optimize.py:320-333
+ *
+ *  (B) HANDLE-BASED symbols (ibo_*) -- re-entrant, explicit status codes,
+ *      batch/candidate-array aware (the legacy ABI has no notion of a
+ *      candidate array).  These are what ibo_amd's Python host code calls and
+ *      what a maintainer would bind to move GaussianProcess.addData /
+ *      posterior(s) / maximize* / fastUCBGallery onto the GPU.
+ *
+ * Conventions: all matrices row-major fp64; "host" pointers are ordinary
+ * process memory borrowed for the duration of the call; "dev" pointers are HIP
+ * device memory on the handle's device (from ibo_dev_alloc or any hipMalloc).
+ * Every ibo_* function returns an IBO_* status; ibo_last_error() describes the
+ * last failure on the calling thread.  No torch / C++ types cross this line.
+ */
+#ifndef IBO_ABI_H
+#define IBO_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IBO_ABI_VERSION 1
+
+/* status codes */
+#define IBO_OK              0
+#define IBO_ERR_ARG         1   /* bad argument (null pointer, size, enum)            */
+#define IBO_ERR_HIP         2   /* HIP runtime error (see ibo_last_error)              */
+#define IBO_ERR_NOT_PD      3   /* matrix not positive definite (numpy LinAlgError)    */
+#define IBO_ERR_STATE       4   /* call order (e.g. sweep before fit)                  */
+#define IBO_ERR_NO_DEVICE   5   /* no gfx950 device visible -- there is NO CPU fallback */
+#define IBO_ERR_COMM        6   /* RCCL error                                          */
+
+/* kernel type codes == the reference's (ego/acquisition/__init__.py:323-333) */
+#define IBO_K_SE_ARD   0        /* hyper = D length scales                             */
+#define IBO_K_SE_ISO   1        /* hyper = [theta]                                     */
+#define IBO_K_MATERN3  2        /* hyper = [theta]  (magnitude goes in sf2)            */
+#define IBO_K_MATERN5  3        /* hyper = [theta]  (magnitude goes in sf2)            */
+
+/* acquisition codes == the reference's (ego/acquisition/__init__.py:309-321) */
+#define IBO_ACQ_EI   0
+#define IBO_ACQ_PI   1
+#define IBO_ACQ_UCB  2
+#define IBO_ACQ_NONE 3          /* posterior only                                      */
+
+/* erf flavour: libm as cpp/optimizeGP.cpp:200-204, or the
+ * Numerical-Recipes fit with truncated constants of
+ * ego/gaussianprocess/__init__.py:55-77 */
+#define IBO_ERF_LIBM 0
+#define IBO_ERF_NR   1
+
+/* diagonal rule for the covariance matrix */
+#define IBO_DIAG_UNIT_PLUS_NOISE 0   /* 1+noise : GaussianProcess._computeCorrelations,
+                                        ego/gaussianprocess/__init__.py:138            */
+#define IBO_DIAG_KERNEL_PLUS_NOISE 1 /* k(x,x)+noise : marginalLikelihood,
+                                        ego/gaussianprocess/trainhyper.py:55           */
+
+typedef struct ibo_gp ibo_gp_t;       /* a fitted GP resident on one GPU */
+typedef struct ibo_comm ibo_comm_t;   /* an RCCL communicator (one rank per GPU) */
+
+/* ---------------------------------------------------------------- library */
+int         ibo_abi_version(void);
+const char *ibo_last_error(void);
+int         ibo_device_count(int *count);
+/* name/arch string of a device ("gfx950...") into buf */
+int         ibo_device_name(int device, char *buf, size_t buflen);
+/* self-test of the fp64 MFMA fragment layout on the device (returns IBO_OK or
+ * IBO_ERR_HIP with a message); cheap, used by smoke() */
+int         ibo_selftest_mfma(int device, double *max_abs_err);
+/* tuning/testing knobs: "sweep_path" = 0 auto (GEMV kernel for M <= 16, MFMA tile
+ * kernel otherwise), 1 force GEMV, 2 force MFMA.  Env IBO_SWEEP_IMPL=gemv|mfma too. */
+int         ibo_set_option(const char *key, int value);
+
+/* ---------------------------------------------------------------- device memory */
+int ibo_dev_alloc(int device, size_t bytes, void **dev_ptr);
+int ibo_dev_free(int device, void *dev_ptr);
+int ibo_memcpy_h2d(int device, void *dev_dst, const void *host_src, size_t bytes);
+int ibo_memcpy_d2h(int device, void *host_dst, const void *dev_src, size_t bytes);
+int ibo_device_synchronize(int device);
+
+/* ---------------------------------------------------------------- model (fit) */
+int ibo_gp_create(int device, ibo_gp_t **out);
+int ibo_gp_destroy(ibo_gp_t *gp);
+
+/*
+ * Fit: replaces GaussianProcess._computeCorrelations + linalg.cholesky
+ * (ego/gaussianprocess/__init__.py:134-149,294-299) and the per-call
+ * linalg.inv(R) of cdirectGP (ego/acquisition/__init__.py:385-388).
+ *   R = K(X,X) with diagonal 1+noise;  L = chol(R);  W = L^-1 (explicit,
+ *   kept in an MFMA-fragment layout);  alphaY = R^-1 Y, alpha1 = R^-1 1.
+ * hyper: nhyper doubles per kernel type (see IBO_K_*); sf2 multiplies the
+ * kernel (1 for SE kernels, magnitude^2 for SV / Matern in the Python model).
+ * On IBO_ERR_NOT_PD *info (optional) receives the 1-based failing pivot.
+ */
+int ibo_gp_fit(ibo_gp_t *gp, int ktype, int N, int D,
+               const double *X_host, const double *Y_host,
+               const double *hyper_host, int nhyper, double sf2, double noise,
+               int *info);
+
+/*
+ * Same, but factor a caller-supplied symmetric matrix A (N x N, host) in place
+ * of R: PrefGaussianProcess uses A = R + C^-1
+ * (ego/gaussianprocess/__init__.py:487-498, ego/acquisition/__init__.py:385-386).
+ * R itself is still built (ibo_gp_get_R) because callers read GP.R.
+ */
+int ibo_gp_fit_with_matrix(ibo_gp_t *gp, int ktype, int N, int D,
+                           const double *X_host, const double *Y_host,
+                           const double *hyper_host, int nhyper, double sf2, double noise,
+                           const double *A_host, int *info);
+
+/* replace Y (and the alpha vectors) without refactoring: the preference GP's
+ * C-matrix loop re-reads mu with L fixed (ego/gaussianprocess/__init__.py:476) */
+int ibo_gp_set_y(ibo_gp_t *gp, const double *Y_host);
+
+/* signal variance used for the CROSS-covariances k(x_i, c) of later sweeps only.
+ * libego evaluates k* with sf2 = 1 for kernel types 0-2 whatever the Python
+ * kernel's magnitude (cpp/optimizeGP.cpp:303-310) while R was built with it; a
+ * drop-in maximize* sets this to reproduce that, then restores it. */
+int ibo_gp_set_kstar_sf2(ibo_gp_t *gp, double sf2);
+
+/* RBF-network mean prior m(x) = sum_i beta_i exp(-theta |(x-lowerb)/width - mean_i|^2)
+ * (ego/gaussianprocess/prior.py:60-66, cpp/optimizeGP.cpp:116-133); nb = 0 clears it */
+int ibo_gp_set_prior(ibo_gp_t *gp, int nb, const double *means_host, const double *beta_host,
+                     double theta, const double *lowerb_host, const double *width_host);
+
+/* copy the public attributes back (N x N row-major each) */
+int ibo_gp_get_R(ibo_gp_t *gp, double *R_host);
+int ibo_gp_get_L(ibo_gp_t *gp, double *L_host);
+/* W = L^-1 (N x N, lower triangular), and R^-1 = W^T W if wanted by a caller */
+int ibo_gp_get_W(ibo_gp_t *gp, double *W_host);
+int ibo_gp_info(ibo_gp_t *gp, int *N, int *D, int *device, double *max_y);
+/* milliseconds of the last fit, device-side (hipEvent) */
+int ibo_gp_last_fit_ms(ibo_gp_t *gp, float *ms);
+
+/* covariance matrix only (no factorisation): Kernel.covMatrix / _computeCorrelations.
+ * A2 may be NULL (square K(A1,A1) with the chosen diagonal rule) or a second
+ * point set (cross-covariance K(A1,A2), n1 x n2, no diagonal rule). */
+int ibo_cov_matrix(int device, int ktype, int D, const double *hyper_host, int nhyper, double sf2,
+                   int n1, const double *A1_host, int n2, const double *A2_host,
+                   int diag_rule, double noise, double *K_host);
+
+/* ---------------------------------------------------------------- posterior / sweep */
+/*
+ * Batched posterior: replaces GaussianProcess.posterior / posteriors / mu
+ * (ego/gaussianprocess/__init__.py:169-254).  clamp_lo = 1e-7 reproduces the
+ * Python clip(.., 10e-8, 10), 1e-8 the native clamp (cpp/optimizeGP.cpp:150-157).
+ * Host buffers in and out (PCIe-inclusive).  s2_host may be NULL.
+ */
+int ibo_posterior_batch(ibo_gp_t *gp, int64_t M, const double *Q_host, double clamp_lo,
+                        double *mu_host, double *s2_host);
+
+/*
+ * Fused candidate sweep: the batched equivalent of M calls of
+ * GP_Maximizer::negei/negpi/negucb (cpp/optimizeGP.cpp:57-236), i.e. what
+ * maximizeEI/PI/UCB evaluate inside DIRECT and what fastUCBGallery's
+ * latin-hypercube step evaluates (ego/acquisition/gallery.py:111-116).
+ *
+ *   cand_dev     M x D candidates, DEVICE memory, row-major
+ *   acq          IBO_ACQ_*;  parm = xi (EI/PI) or the sigma multiplier (UCB)
+ *   ymax         incumbent; pass NAN to use max(Y) as acqmaxGP does (:316-321)
+ *   excl_host    n_excl x D points (host) -- candidates with
+ *                min_j |c - excl_j|_2 <= excl_radius are left out of the argmax
+ *                (the gallery's 0.5-distance rule, gallery.py:102,113); n_excl=0: none
+ *   index_base   added to the local row index to form the reported index
+ *                (global index of this rank's shard)
+ *   mu_dev, s2_dev, acq_dev   optional DEVICE outputs (M doubles each) or NULL
+ *   best_val, best_idx        HOST outputs: maximum of the (positive) acquisition
+ *                and the FIRST index attaining it (numpy.argmax order, and the
+ *                strict '<' of cpp/direct.cpp:124).  best_idx = -1 if every
+ *                candidate is excluded.
+ * Blocking.  The posterior part costs N^2 + 3ND + 4N flops per candidate.
+ */
+int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
+                  int acq, double parm, int erf_mode, double clamp_lo, double ymax,
+                  int n_excl, const double *excl_host, double excl_radius,
+                  int64_t index_base,
+                  double *mu_dev, double *s2_dev, double *acq_dev,
+                  double *best_val, int64_t *best_idx);
+
+/* device-side duration (hipEvent, ms) of the dominant kernel of the last
+ * ibo_acq_sweep / ibo_posterior_batch on this handle, and its name */
+int ibo_last_sweep_kernel_ms(ibo_gp_t *gp, float *ms, const char **kernel_name);
+
+/* ---------------------------------------------------------------- DIRECT on the GPU objective */
+/*
+ * maximise an acquisition over a box with the reference's DIRECT
+ * (cpp/direct.cpp:329-581) -- tree logic on the host, every batch of new
+ * sample points evaluated by the sweep kernel.  compat != 0 reproduces the
+ * reference's trajectory quirks incl. the dimension-0 stall;
+ * compat == 0 applies the fixed-dimension test to dimension 0 as well.
+ * opt = maximum of the acquisition, optx[D] its location, nsamples optional.
+ */
+int ibo_direct_max(ibo_gp_t *gp, int D, const double *lb, const double *ub,
+                   int acq, double parm, int erf_mode, double clamp_lo,
+                   int maxiter, int maxtime, int maxsample, int compat,
+                   double *opt, double *optx, int64_t *nsamples);
+
+/* DIRECT minimisation of a HOST callback with the reference's semantics
+ * (cpp/direct.cpp:329; what ego.utils.optimize.cdirect wraps), plus the sample
+ * counter and the compat switch.  Host-side only: no GPU is touched. */
+int ibo_direct_host(double (*objective)(int, double *), int ndim, const double *lb, const double *ub,
+                    int maxiter, int maxtime, int maxsample, int compat,
+                    double *fmin, double *xmin, int64_t *nsamples);
+
+/* ---------------------------------------------------------------- marginal likelihood grid */
+/*
+ * nlml[t] for n_theta hyper-parameter rows (each nhyper doubles):
+ * marginalLikelihood(..., computeGradient=False) of
+ * ego/gaussianprocess/trainhyper.py:47-75 (K = covMatrix + noise I).
+ * A non-positive-definite K yields NAN in that slot (the reference's nlml()
+ * wrapper maps the LinAlgError to 100, trainhyper.py:111-114 -- done host side).
+ */
+int ibo_nlml_grid(int device, int ktype, int N, int D,
+                  const double *X_host, const double *Y_host,
+                  int n_theta, const double *thetas_host, int nhyper,
+                  const double *sf2_host /* n_theta or NULL (=1) */, double noise,
+                  double *nlml_host);
+
+/* ---------------------------------------------------------------- multi-GPU arg-max exchange (RCCL) */
+#define IBO_COMM_ID_BYTES 128
+int ibo_comm_get_unique_id(unsigned char id[IBO_COMM_ID_BYTES]);
+int ibo_comm_init(int device, int world_size, int rank,
+                  const unsigned char id[IBO_COMM_ID_BYTES], ibo_comm_t **out);
+int ibo_comm_destroy(ibo_comm_t *comm);
+/*
+ * One all-reduce(sum) over a world_size x (3+npayload) slot buffer (value,
+ * index, valid flag, payload) in which each rank fills only its own slot (RCCL has no MAXLOC), followed by the same
+ * deterministic local reduction on every rank: maximum value, ties to the
+ * lowest global index.  payload (npayload doubles, e.g. the winner's
+ * coordinates) travels in the same buffer.  All outputs are identical on
+ * every rank.
+ */
+int ibo_comm_argmax(ibo_comm_t *comm, double val, int64_t idx,
+                    const double *payload, int npayload,
+                    double *best_val, int64_t *best_idx, double *best_payload, int *best_rank);
+int ibo_comm_barrier(ibo_comm_t *comm);
+
+/* ---------------------------------------------------------------- (A) legacy libego symbols */
+typedef double (*objective_t)(int, double *);
+
+/* cpp/optimizeGP.cpp:262-283.  Returns malloc'd [fmin, xmin[0..ndim)] with
+ * fmin = minimum of the NEGATED acquisition; caller frees with free(). NULL on
+ * unknown acqfunc (as the reference) or on any failure (message on stderr). */
+const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR, double *X, double *Y,
+                       int nx, int acqfunc, int kerneltype, double *hyperparams,
+                       int npbases, double *pbasismeans, double *pbasisbeta, double pbasistheta,
+                       double *pbasislowerb, double *pbasiswidth, double parm, double noise,
+                       int maxiter, int maxtime, int maxsample);
+
+/* cpp/direct.cpp:329: DIRECT minimisation of a host callback (host-side only;
+ * kept so ego.utils.optimize.cdirect keeps working against this library). */
+const double *direct(objective_t objective, int ndim, double *lb, double *ub,
+                     int maxiter, int maxtime, int maxsample);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBO_ABI_H */
