@@ -39,6 +39,7 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
+extern int g_sweep_variant;     // sweep.hip
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
 
 static int use_device(int device)
@@ -124,6 +125,7 @@ extern "C" int ibo_device_name(int device, char *buf, size_t buflen)
 extern "C" int ibo_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "sweep_path")) { g_force_path = value; return IBO_OK; }
+    if (key && !strcmp(key, "sweep_variant")) { g_sweep_variant = value; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
 

@@ -5,15 +5,15 @@
 // (cpp/optimizeGP.cpp:57-236) and of GaussianProcess.posterior
 // (ego/gaussianprocess/__init__.py:169-228).  K(X, X*) never touches HBM.
 //
-// Main kernel (sweep_mfma_kernel): one 512-thread workgroup per 64 candidates.
+// Main kernel (sweep_mfma_kernel): one workgroup (16 waves by default) per 64 candidates.
 //   * the N x 64 block of k* is produced 32 rows at a time into LDS, already in
 //     fp64-MFMA B-fragment order; observation rows are wave-uniform (scalar
 //     loads), the candidate sits in registers, one lane per candidate;
 //   * W = L^-1 is streamed from L2 in A-fragment order (pack_w_kernel), one
 //     16-byte load per lane per two k4-steps, and never staged in LDS: each
 //     wave owns distinct rows;
-//   * V = W K* is accumulated 512 rows at a time (8 waves x 4 row-blocks of 16
-//     x 4 candidate blocks of 16 = 128 accumulator VGPRs per lane); row blocks
+//   * V = W K* is accumulated 512 rows at a time (16 waves x 2 row-blocks of 16
+//     x 4 candidate blocks of 16 = 64 accumulator VGPRs per lane); row blocks
 //     are interleaved over the waves so the triangular part stays balanced and
 //     the zero upper-triangular tiles are skipped;
 //   * the epilogue squares and reduces V down the rows, finishes mu/s2/acq and
@@ -22,8 +22,6 @@
 #include "ibo_common.h"
 
 #define TC 64          // candidates per workgroup
-#define NWAVE 8
-#define KC 32          // k rows of K* per LDS stage
 #define PANEL 512      // rows of V accumulated per pass = NWAVE * 4 * 16
 
 __device__ __forceinline__ double prior_mu_dev(const PriorDev &p, int D, const double *x)
@@ -74,29 +72,41 @@ __device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
     }
 }
 
-template <int FAM, int DP>
-__global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
+// Tile configuration of the main kernel.  NW waves per workgroup, each owning RBW
+// row-blocks (16 rows) x 4 candidate-blocks (16 candidates) of the 512-row panel:
+// NW * RBW = 32.  KCH = rows of K* per LDS stage.  fp64 MFMA issues at one per 64
+// cycles per SIMD but a single wave only reaches ~46 % of that (tools/mfma_f64_peak),
+// so the pipe needs >= 2 waves per SIMD in their MFMA phase at any time:
+// <16, 2> (64 accumulator VGPRs, 4 waves/SIMD) is the default, <8, 4> the first version.
+template <int FAM, int DP, int NW, int RBW, int KCH>
+__global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
 {
-    __shared__ double lds_k[2][KC * TC];          // K* stage, B-fragment order
-    __shared__ double lds_c[TC * DP];             // candidate coordinates
-    __shared__ double lds_q[NWAVE][TC];
-    __shared__ double lds_m[2][NWAVE][TC];
+    static_assert(NW * RBW * 16 == PANEL, "panel is 512 rows");
+    constexpr int KPW = KCH / NW;                  // K* rows generated per wave per stage
+    static_assert(KPW >= 1 && KPW <= 4 && (4 % KPW == 0), "wave generates 1, 2 or 4 rows of a k4-step");
+    __shared__ double lds_k[2][KCH * TC];          // K* stage, B-fragment order
+    __shared__ double lds_c[DP * TC];              // candidate coordinates, [d][candidate]
+    __shared__ double lds_q[NW][TC];
+    __shared__ double lds_m[2][NW][TC];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tile0 = (int64_t)blockIdx.x * TC;
     const int D = a.kp.D;
 
-    for (int e = tid; e < TC * DP; e += 512) {
-        int c = e / DP, d = e - c * DP;
+    for (int e = tid; e < TC * DP; e += NW * 64) {
+        int d = e / TC, c = e - d * TC;
         int64_t gi = tile0 + c;
         if (gi > a.M - 1) gi = a.M - 1;
         lds_c[e] = (d < D) ? a.cand[gi * D + d] : 0.0;
     }
     __syncthreads();
-    double cx[DP];
+    constexpr bool CX_REG = (DP <= 8);             // keep the candidate in registers when it is small
+    double cx[CX_REG ? DP : 1];
+    if (CX_REG) {
 #pragma unroll
-    for (int d = 0; d < DP; d++) cx[d] = lds_c[lane * DP + d];
+        for (int d = 0; d < DP; d++) cx[d] = lds_c[d * TC + lane];
+    }
 
     const int Npad = a.Npad;
     const int nk8 = Npad >> 3;
@@ -104,39 +114,47 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
     const int npanel = (Npad + PANEL - 1) / PANEL;
     const double2 *Wp2 = (const double2 *)a.Wp;
     double muY = 0.0, mu1 = 0.0;
-    double qacc[4] = {0.0, 0.0, 0.0, 0.0};      // lanes 0..15 hold sums for candidate block cb
+    double qacc[4] = {0.0, 0.0, 0.0, 0.0};         // lanes 0..15 hold sums for candidate block cb
 
     for (int p = 0; p < npanel; p++) {
         const bool last = (p == npanel - 1);
         const int kend = min((p + 1) * PANEL, Npad);
-        const int nchunk = kend / KC;
-        int g[4];
+        const int nchunk = (kend + KCH - 1) / KCH;
+        int g[RBW];
+        const double2 *wrow[RBW];
 #pragma unroll
-        for (int i = 0; i < 4; i++) g[i] = p * (PANEL / 16) + wave + NWAVE * i;
-        d4_t acc[4][4];
+        for (int i = 0; i < RBW; i++) {
+            g[i] = p * (PANEL / 16) + wave + NW * i;
+            wrow[i] = Wp2 + ((size_t)min(g[i], nRB - 1) * nk8) * 64 + lane;
+        }
+        d4_t acc[RBW][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < RBW; i++)
 #pragma unroll
             for (int cb = 0; cb < 4; cb++) acc[i][cb] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-        // produce K* rows [k0, k0+KC) into stage b; this wave does rows k0+4*wave .. +3
+        // produce K* rows [k0, k0+KCH) into stage b; this wave does rows k0 + KPW*wave .. +KPW-1
         auto gen = [&](int k0, int b) {
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int k = k0 + wave * 4 + kk;
-                const double *xr = a.Xp + (size_t)k * DP;
-                double z = 0.0;
+            for (int kk = 0; kk < KPW; kk++) {
+                const int kl = wave * KPW + kk;            // row within the stage
+                const int k = k0 + kl;
+                double kv = 0.0;
+                if (k < Npad) {
+                    const double *xr = a.Xp + (size_t)k * DP;
+                    double z = 0.0;
 #pragma unroll
-                for (int d = 0; d < DP; d++) {
-                    double t = xr[d] - cx[d];
-                    z += a.kp.w[d] * (t * t);
+                    for (int d = 0; d < DP; d++) {
+                        double t = xr[d] - (CX_REG ? cx[CX_REG ? d : 0] : lds_c[d * TC + lane]);
+                        z += a.kp.w[d] * (t * t);
+                    }
+                    kv = cov_from_z<FAM>(z, a.kp.sf2);
+                    if (last) {
+                        muY += a.alphaY[k] * kv;
+                        mu1 += a.alpha1[k] * kv;
+                    }
                 }
-                double kv = cov_from_z<FAM>(z, a.kp.sf2);
-                lds_k[b][(wave * 4 + (lane >> 4)) * 64 + kk * 16 + (lane & 15)] = kv;
-                if (last) {
-                    muY += a.alphaY[k] * kv;
-                    mu1 += a.alpha1[k] * kv;
-                }
+                lds_k[b][((kl >> 2) * 4 + (lane >> 4)) * 64 + (kl & 3) * 16 + (lane & 15)] = kv;
             }
         };
 
@@ -144,18 +162,25 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
         __syncthreads();
         for (int t = 0; t < nchunk; t++) {
             const int b = t & 1;
-            const int k0 = t * KC;
-            if (t + 1 < nchunk) gen(k0 + KC, b ^ 1);
+            const int k0 = t * KCH;
+            // A operands of the first k8-step of this stage: issue before the VALU-heavy gen
+            double2 af[RBW];
+            bool act[RBW];
 #pragma unroll
-            for (int jj = 0; jj < KC / 8; jj++) {
+            for (int i = 0; i < RBW; i++) {
+                act[i] = (g[i] < nRB) && (k0 <= 16 * g[i] + 15);
+                af[i] = act[i] ? wrow[i][(size_t)(k0 >> 3) * 64] : (double2){0.0, 0.0};
+            }
+            if (t + 1 < nchunk) gen(k0 + KCH, b ^ 1);
+#pragma unroll
+            for (int jj = 0; jj < KCH / 8; jj++) {
                 const int j = (k0 >> 3) + jj;
-                double2 af[4];
-                bool act[4];
+                double2 afn[RBW];
+                bool actn[RBW];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    // row-block g[i] has non-zeros in columns <= 16 g[i] + 15
-                    act[i] = (g[i] < nRB) && (8 * j <= 16 * g[i] + 15);
-                    if (act[i]) af[i] = Wp2[((size_t)g[i] * nk8 + j) * 64 + lane];
+                for (int i = 0; i < RBW; i++) {      // prefetch the next k8-step of this stage
+                    actn[i] = (jj + 1 < KCH / 8) && (g[i] < nRB) && (8 * (j + 1) <= 16 * g[i] + 15) && (8 * (j + 1) < Npad);
+                    afn[i] = actn[i] ? wrow[i][(size_t)(j + 1) * 64] : (double2){0.0, 0.0};
                 }
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -164,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
 #pragma unroll
                     for (int cb = 0; cb < 4; cb++) bf[cb] = lds_k[b][(s4 * 4 + cb) * 64 + lane];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < RBW; i++) {
                         if (act[i]) {
                             const double av = h ? af[i].y : af[i].x;
 #pragma unroll
@@ -172,6 +197,8 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
                         }
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < RBW; i++) { af[i] = afn[i]; act[i] = actn[i]; }
             }
             __syncthreads();
         }
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
         for (int cb = 0; cb < 4; cb++) {
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < RBW; i++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) s += acc[i][cb][r] * acc[i][cb][r];
             s += __shfl_xor(s, 16);
@@ -198,12 +225,12 @@ __global__ __launch_bounds__(512, 2) void sweep_mfma_kernel(SweepArgs a)
     if (wave == 0) {
         double q = 0.0, my = 0.0, m1 = 0.0;
 #pragma unroll
-        for (int w = 0; w < NWAVE; w++) { q += lds_q[w][lane]; my += lds_m[0][w][lane]; m1 += lds_m[1][w][lane]; }
+        for (int w = 0; w < NW; w++) { q += lds_q[w][lane]; my += lds_m[0][w][lane]; m1 += lds_m[1][w][lane]; }
         int64_t li = tile0 + lane;
         bool valid = li < a.M;
         double xq[DP];
 #pragma unroll
-        for (int d = 0; d < DP; d++) xq[d] = cx[d];
+        for (int d = 0; d < DP; d++) xq[d] = lds_c[d * TC + lane];
         bool excl;
         double val = finish_candidate(a, xq, q, my, m1, li, valid, excl);
         int64_t idx = a.index_base + li;
@@ -302,14 +329,24 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
     }
 }
 
+int g_sweep_variant = 2;     // 0: <16,2,32>  1: <8,4,32>  2: <16,2,64> (default)  (ibo_set_option("sweep_variant"))
+
+template <int FAM, int NW, int RBW, int KCH>
+static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    dim3 grid((unsigned)ntiles), block(NW * 64);
+    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, NW, RBW, KCH>), grid, block, 0, s, a);
+    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, NW, RBW, KCH>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, NW, RBW, KCH>), grid, block, 0, s, a);
+    return (int)hipGetLastError();
+}
+
 template <int FAM>
 static int launch_mfma_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
-    dim3 grid((unsigned)ntiles), block(512);
-    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4>), grid, block, 0, s, a);
-    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16>), grid, block, 0, s, a);
-    return (int)hipGetLastError();
+    if (g_sweep_variant == 1) return launch_mfma_cfg<FAM, 8, 4, 32>(a, ntiles, s);
+    if (g_sweep_variant == 0) return launch_mfma_cfg<FAM, 16, 2, 32>(a, ntiles, s);
+    return launch_mfma_cfg<FAM, 16, 2, 64>(a, ntiles, s);
 }
 
 int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1)

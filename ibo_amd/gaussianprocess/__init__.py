@@ -348,11 +348,16 @@ class PrefGaussianProcess(GaussianProcess):
             if Y[r] <= Y[c]:
                 if not any(c1 == r for _, c1, _ in prefinds):
                     Y[r] = Y[c] + .1
-        self._set_map(Y, prefinds)
+        self._set_map(Y, prefinds, plain_fitted=True)
 
-    def _set_map(self, Y, prefinds):
-        """everything downstream of the MAP (:459-498): C matrix, L = chol(R + C^-1)"""
+    def _set_map(self, Y, prefinds, plain_fitted=False):
+        """everything downstream of the MAP (:459-498): C matrix, L = chol(R + C^-1).
+        The C-matrix loop reads mu with L = chol(R) (:476), so the device must hold the
+        plain factorisation at this point."""
         self.Y = np.array(Y, dtype=float)
+        if not plain_fitted:
+            self.C = None
+            self._fit_device()
         _lib.check(_lib.lib.ibo_gp_set_y(self._handle(), _lib.dp(_lib.f64(self.Y))))
         mu = self._posterior_arrays(self.X, getvar=False)[0]      # L = chol(R) at this point
         n = len(self.X)

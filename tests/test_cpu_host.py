@@ -1,0 +1,170 @@
+"""
+CPU-side tests (`-m "not gpu"`): the C-ABI library loads and exports every symbol
+include/ibo_abi.h declares, compute entry points fail loudly without a GPU, and the
+host logic (latin hypercube, both DIRECT implementations, kernel scalars, shard
+arithmetic) matches the golden vectors / the oracle.  No GPU compute is called.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ibo_abi.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(ibo_[A-Za-z0-9_]+|acqmaxGP|direct)\s*\(", txt))
+    return sorted(n for n in names if n not in ("ibo_gp", "ibo_comm"))
+
+
+def test_library_exports_every_declared_symbol():
+    from ibo_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(_lib.lib, s), "libibo_hip.so does not export %s" % s
+        assert s in _lib.EXPORTED, "%s is declared in ibo_abi.h but not bound in ibo_amd/_lib.py" % s
+    assert _lib.lib.ibo_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from ibo_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    with pytest.raises(_lib.IBOError) as e:
+        GaussianProcess(GaussianKernel_ard([.5, .5]), np.random.rand(5, 2), np.random.rand(5))
+    assert e.value.code == _lib.ERR_NO_DEVICE
+    with pytest.raises(_lib.IBOError):
+        GaussianKernel_ard([.5, .5]).covMatrix(np.random.rand(4, 2))
+    # the legacy symbol reports failure the way the reference does for bad input: NULL
+    z = np.zeros(4)
+    dp = _lib.dp
+    assert not _lib.lib.acqmaxGP(1, dp(z), dp(z), dp(z), dp(z), dp(z), 1, 0, 0, dp(z), 0, dp(z), dp(z), 0.0, dp(z),
+                                 dp(z), .01, .1, 1, 1, 10)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ibo_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# the checker", ""), "%s mentions the oracle" % f
+
+
+def test_lhc_bit_exact():
+    from ibo_amd.utils.latinhypercube import lhcSample
+    g = load_golden("g9_lhc")
+    for seed, n in ((22, 5), (23, 5), (0, 10), (7, 12)):
+        got = np.array(lhcSample(g["s%d_bounds" % seed].tolist(), n, seed=seed))
+        assert np.array_equal(got, g["s%d" % seed])
+    s = lhcSample([[0., 1.]], 100, seed=20)                  # ego/unittest_IBO.py:51-62
+    assert sorted(int(v[0] * 100) for v in s) == list(range(100))
+
+
+def shekel5(g):
+    A, C = g["shekel_A"], g["shekel_C"]
+    return lambda x: -sum(1. / (np.dot(x - a, x - a) + c) for a, c in zip(A, C))
+
+
+def test_direct_known_answers(oracle):
+    from ibo_amd.utils.optimize import direct, cdirect
+    g = load_golden("g4_direct")
+    f = shekel5(g)
+    b = g["shekel_bounds"].tolist()
+    fm, xm, ns = cdirect(f, b, maxiter=20, return_samples=True)
+    assert np.array_equal(np.r_[fm, xm], g["shekel_cdirect"])
+    assert ns == oracle.cdirect(f, b, maxiter=20)[2]
+    assert abs(fm + 10.1532) < 1e-3 and np.all(np.abs(xm - 4.0) < 1e-3)
+    fm, xm = direct(f, b, maxiter=20)
+    assert np.array_equal(np.r_[fm, xm], g["shekel_direct"])
+
+    def foo(x, a1, a2):
+        return -np.sum(np.sin(np.array(x) * a1) + np.array(x) * a2)
+    b3 = [[0., 5.]] * 3
+    assert np.array_equal(np.r_[cdirect(foo, b3, args=[3.0, 0.0], maxiter=10)], np.r_[g["foo_c1"][0], g["foo_c1"][1:]])
+    fm, xm = cdirect(foo, b3, args=[-2.0, 2.0], maxiter=10)
+    assert np.array_equal(np.r_[fm, xm], g["foo_c2"])
+    fm, xm = direct(foo, b3, args=[3.0, 0.0], maxiter=20)
+    assert np.array_equal(np.r_[fm, xm], g["foo_d1"])
+    with pytest.raises(ValueError):
+        direct(f, b)
+    (fm2, xm2), rep = direct(foo, b3, args=[3.0, 0.0], maxiter=3, debug=True)
+    assert rep["samples"] > 0 and len(rep["rectangles"]) > 3
+    foo3 = lambda x: float(np.sum((np.array(x) - .3) ** 2))
+    for row, bb in zip(g["fixed_counts"], ([[0., 1.]] * 3, [[0., 1.], [.5, .5], [0., 1.]], [[.5, .5], [0., 1.], [0., 1.]])):
+        fm, xm, ns = cdirect(foo3, bb, maxiter=50, maxsample=10000, return_samples=True)
+        assert ns == int(row[0]) and np.array_equal(np.r_[fm, xm], row[1:])
+    fm, xm, ns = cdirect(foo3, [[.5, .5], [0., 1.], [0., 1.]], maxiter=50, maxsample=10000, compat=False,
+                         return_samples=True)
+    assert ns > 1000 and abs(fm - .04) < 1e-9
+
+
+def test_legacy_direct_symbol_against_compiled_reference(oracle):
+    """`direct` with the reference's exact signature (cpp/direct.h:76), same answers as _ref/libego.so"""
+    from ibo_amd import _lib
+    g = load_golden("g4_direct")
+    f = shekel5(g)
+    b = np.array(g["shekel_bounds"])
+    lb, ub = _lib.f64(b[:, 0]), _lib.f64(b[:, 1])
+    cnt = [0]
+
+    def obj(n, x):
+        cnt[0] += 1
+        return float(f(np.array([x[i] for i in range(n)])))
+    r = _lib.lib.direct(_lib.OBJECTIVE(obj), 4, _lib.dp(lb), _lib.dp(ub), 25, 30, 100000)
+    res = np.array([r[i] for i in range(5)])
+    libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]; libc.free(r)
+    if oracle.RefLib.available():
+        ref = oracle.RefLib().direct(f, b.tolist(), maxiter=25, maxsample=100000)
+        assert cnt[0] == ref[2]
+        assert np.array_equal(res, np.r_[ref[0], ref[1]])
+    o = oracle.cdirect(f, b.tolist(), maxiter=25, maxsample=100000)
+    assert cnt[0] == o[2] and np.array_equal(res, np.r_[o[0], o[1]])
+
+
+def test_kernel_scalars_and_specs(oracle):
+    from ibo_amd.gaussianprocess import kernel as K, CDF, PDF, erf
+    rs = np.random.RandomState(3)
+    a, b = rs.rand(5), rs.rand(5)
+    for ours, kind, hyp in ((K.GaussianKernel_ard([.3, .4, .5, .6, .7]), "ard", [.3, .4, .5, .6, .7]),
+                            (K.GaussianKernel_iso([.4]), "iso", [.4]),
+                            (K.SVGaussianKernel_iso([.4, 1.3]), "sviso", [.4, 1.3]),
+                            (K.SVGaussianKernel_ard([.3, .4, .5, .6, .7, .8]), "svard", [.3, .4, .5, .6, .7, .8]),
+                            (K.MaternKernel3([.6, .9]), "m3", [.6, .9]), (K.MaternKernel5([.5, 1.2]), "m5", [.5, 1.2])):
+        ok = oracle.Kern(kind, hyp)
+        np.testing.assert_allclose(ours.cov(a, b), ok.cov(a, b), rtol=1e-14)
+        kt, h, sf2, sf2n = ours._ibo_spec()
+        assert kt == ok.ktype and abs(sf2 - ok.sf2_py) < 1e-15 and abs(sf2n - ok.sf2_native) < 1e-15
+        assert np.array_equal(ours.hyperparams, np.array(hyp))
+        with pytest.raises(ValueError):
+            ours.hyperparams[0] = 5.0                     # read-only (kernel.py:32-40)
+    assert K.GaussianKernel_ard([1e-9, 1e9])._theta.tolist() == [1e-4, 1e4]      # clip (kernel.py:141)
+    for z in (-3.1, -.2, 0.0, .7, 2.5):
+        assert erf(z) == oracle.lib().orc_erf_nr(z)
+        assert abs(CDF(z) - 0.5 * (1 + oracle.lib().orc_erf_nr(z * 0.707106))) < 1e-16
+    assert PDF(0.3) == np.exp(-(0.3 ** 2 / 2)) * 0.398942
+
+
+def test_shard_bounds_and_slot_reduce():
+    from ibo_amd.multigpu import shard_bounds, fill_slot, reduce_slots
+    for M, W in ((4194304, 8), (10, 3), (7, 8), (1 << 20, 1)):
+        cuts = [shard_bounds(M, W, r) for r in range(W)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == M
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+        assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+    assert shard_bounds(4194304, 8, 3) == (3 * 524288, 4 * 524288)
+    W = 4
+    bufs = [fill_slot(W, 0, 1.5, 40, [1., 2.]), fill_slot(W, 1, 2.5, 300, [3., 4.]),
+            fill_slot(W, 2, 2.5, 200, [5., 6.]), fill_slot(W, 3, float('nan'), -1, [0., 0.])]
+    v, i, p, r = reduce_slots(sum(bufs), W, 2)
+    assert (v, i, r) == (2.5, 200, 2) and p.tolist() == [5., 6.]       # tie -> lowest global index
+    v, i, p, r = reduce_slots(sum(fill_slot(W, k, 0.0, -1, [0.]) for k in range(W)), W, 1)
+    assert i == -1 and r == -1
+    v, i, p, r = reduce_slots(fill_slot(1, 0, -3.0, 0, []), 1, 0)
+    assert (v, i, r) == (-3.0, 0, 0)

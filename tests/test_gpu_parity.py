@@ -204,6 +204,29 @@ def test_sweep_vs_oracle_ragged(ibo, oracle, N, D, kind, M):
     assert r["best_idx"] == sw["best_idx"]
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_sweep_tile_variants_agree(ibo, oracle, variant):
+    """every tile configuration of the MFMA kernel against the oracle (N spans 3 panels)"""
+    from ibo_amd.gaussianprocess import GaussianProcess, kernel as K
+    from ibo_amd.acquisition import sweep
+    from ibo_amd import _lib
+    N, D, M = 1100, 6, 333
+    X, Y = synth(31, N, D)
+    cand = np.random.RandomState(32).rand(M, D)
+    hyper = [.35 + .03 * d for d in range(D)]
+    ogp = oracle.GP(oracle.Kern("ard", hyper), X, Y, noise=.1)
+    o_mu, o_s2 = ogp.posteriors(cand)
+    GP = GaussianProcess(K.GaussianKernel_ard(hyper), X, Y, noise=.1)
+    _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", variant))
+    try:
+        r = sweep(GP, cand, acq='ucb', parm=1.2, native=True, outputs=("mu", "s2", "acq"))
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 2))
+    close(r["mu"], o_mu, atol=1e-9); close(r["s2"], o_s2)
+    o = o_mu + 1.2 * np.sqrt(o_s2)
+    close(r["acq"], o); assert r["best_idx"] == int(np.argmax(o))
+
+
 def test_sweep_exclusion_and_index_base(ibo):
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard

@@ -1,0 +1,61 @@
+"""
+The N>1 arg-max exchange on CPU: two processes, gloo backend, the same slot
+protocol RCCL runs on the GPUs (ibo_amd/multigpu.py, csrc/comm.hip).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ibo_amd.multigpu import TorchArgmax, shard_bounds
+    comm = TorchArgmax()
+    # a synthetic "acquisition" over a sharded candidate array: each rank scans its block
+    M, D = 1001, 3
+    cand = np.random.RandomState(5).rand(M, D)
+    vals = np.sin(7 * cand.sum(1))
+    vals[[17, 600, 900]] = 2.0                         # three-way tie across ranks -> index 17 must win
+    a, b = shard_bounds(M, world, rank)
+    li = int(np.argmax(vals[a:b]))
+    out = [comm.argmax(vals[a + li], a + li, cand[a + li])]
+    # a rank with nothing admissible (everything excluded) must not win
+    out.append(comm.argmax(float('nan') if rank == 0 else -5.0 - rank, -1 if rank == 0 else 10 + rank, [0.] * D))
+    out.append(comm.argmax(0.0, -1, []))
+    q.put((rank, [(v, i, list(p), r) for v, i, p, r in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_argmax_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                            # identical outcome on every rank
+    cand = np.random.RandomState(5).rand(1001, 3)
+    v, i, p, r = res[0][0]
+    assert (v, i, r) == (2.0, 17, 0) and np.allclose(p, cand[17])
+    v, i, p, r = res[0][1]
+    assert (v, i, r) == (-6.0, 11, 1)
+    assert res[0][2][1] == -1 and res[0][2][3] == -1
