@@ -394,6 +394,18 @@ def test_direct_sample_counts_match_oracle(ibo, oracle):
     assert ns > 17 and x[0] == .5
 
 
+def test_rccl_argmax_world_of_one(ibo):
+    """the RCCL exchange itself (csrc/comm.hip) on the one GPU this box has"""
+    from ibo_amd.multigpu import RcclArgmax
+    comm = RcclArgmax(1, 0, RcclArgmax.unique_id(), device=0)
+    v, i, p, r = comm.argmax(1.25, 123456789012, [0.5, 0.25, 0.125])
+    assert (v, i, r) == (1.25, 123456789012, 0) and p.tolist() == [0.5, 0.25, 0.125]
+    v, i, p, r = comm.argmax(float('nan'), -1, [0.0])
+    assert i == -1 and r == -1
+    comm.barrier()
+    comm.close()
+
+
 def test_errors_are_loud(ibo):
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
