@@ -40,6 +40,7 @@ static int fail(int code, const char *fmt, ...)
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
 extern int g_sweep_variant;     // sweep.hip
+static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
 
 static int use_device(int device)
@@ -85,12 +86,14 @@ struct ibo_gp {
     bool fitted = false;
     int N = 0, D = 0, Npad = 0, DP = 0;
     bool reversed = false;          // legacy invR path stores the observations in reverse order
+    int dot_form = 1;               // SE k* via a_k + b_c + x~.c~; off when |x~|^2 is so large that the
+                                    // cancellation would cost more than 1e-10 (pathological length scales)
     KParams kp;
     double noise = 0.0, maxY = 0.0;
     float fit_ms = 0.f, sweep_ms = 0.f;
     const char *sweep_kernel = "";
     std::vector<double> Yhost;
-    DevBuf<double> Xp, Y, R, A, L, W, T, Wp, diag64, alphaY, alpha1, tmp, cand, outs, excl, qpart, mupart, partv, res_v;
+    DevBuf<double> Xp, Xs, ak, Y, R, A, L, W, T, Wp, diag64, alphaY, alpha1, tmp, cand, outs, excl, qpart, mupart, partv, res_v;
     DevBuf<int64_t> parti, res_i;
     DevBuf<int> info;
     // prior
@@ -126,6 +129,7 @@ extern "C" int ibo_set_option(const char *key, int value)
 {
     if (key && !strcmp(key, "sweep_path")) { g_force_path = value; return IBO_OK; }
     if (key && !strcmp(key, "sweep_variant")) { g_sweep_variant = value; return IBO_OK; }
+    if (key && !strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
 
@@ -196,7 +200,7 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     if (!g) return IBO_OK;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    g->Xp.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
+    g->Xp.release(); g->Xs.release(); g->ak.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
     g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release();
@@ -218,19 +222,33 @@ static int make_kparams(int ktype, int D, const double *hyper, int nhyper, doubl
     case IBO_K_SE_ARD:
         if (nhyper < D) return fail(IBO_ERR_ARG, "SE-ARD needs %d length scales, got %d", D, nhyper);
         kp->family = FAM_SE;
-        for (int d = 0; d < D; d++) kp->w[d] = 1.0 / (hyper[d] * hyper[d]);
+        for (int d = 0; d < D; d++) { kp->w[d] = 1.0 / (hyper[d] * hyper[d]); kp->sw[d] = 1.0 / fabs(hyper[d]); }
         break;
     case IBO_K_SE_ISO:
     case IBO_K_MATERN3:
     case IBO_K_MATERN5:
         if (nhyper < 1) return fail(IBO_ERR_ARG, "kernel needs a length scale");
         kp->family = ktype == IBO_K_SE_ISO ? FAM_SE : (ktype == IBO_K_MATERN3 ? FAM_M3 : FAM_M5);
-        for (int d = 0; d < D; d++) kp->w[d] = 1.0 / (hyper[0] * hyper[0]);
+        for (int d = 0; d < D; d++) { kp->w[d] = 1.0 / (hyper[0] * hyper[0]); kp->sw[d] = 1.0 / fabs(hyper[0]); }
         break;
     default:
         return fail(IBO_ERR_ARG, "unknown kernel type %d", ktype);
     }
     return IBO_OK;
+}
+
+// |x~|^2 bounds the absolute error of y = a_k + b_c + x~.c~ by ~|x~|^2 * 2^-52
+static int dot_form_ok(const KParams &kp, const double *X, int N, int D)
+{
+    double mx = 0.0;
+    for (int i = 0; i < N; i++) {
+        double n2 = 0.0;
+        for (int d = 0; d < D; d++) { double v = X[(size_t)i * D + d] * kp.sw[d]; n2 += v * v; }
+        if (n2 > mx) mx = n2;
+    }
+    const char *e = getenv("IBO_DOT_FORM");
+    if (e) return atoi(e);
+    return mx <= 1e5;
 }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -244,7 +262,8 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
     g->reversed = reverse;
     const int Np = g->Npad, DP = g->DP;
     size_t nn = (size_t)Np * Np;
-    IBO_TRY(g->Xp.ensure((size_t)Np * DP)); IBO_TRY(g->Y.ensure(Np));
+    IBO_TRY(g->Xp.ensure((size_t)Np * DP)); IBO_TRY(g->Xs.ensure((size_t)Np * DP)); IBO_TRY(g->ak.ensure(Np));
+    IBO_TRY(g->Y.ensure(Np));
     IBO_TRY(g->R.ensure((size_t)N * N)); IBO_TRY(g->L.ensure(nn)); IBO_TRY(g->W.ensure(nn));
     IBO_TRY(g->T.ensure(nn)); IBO_TRY(g->Wp.ensure(nn)); IBO_TRY(g->diag64.ensure((size_t)(Np / 64) * 4096));
     IBO_TRY(g->alphaY.ensure(Np)); IBO_TRY(g->alpha1.ensure(Np));
@@ -292,6 +311,8 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     g->kp = kp; g->noise = noise;
     const int Np = g->Npad;
     hipStream_t s = g->stream;
+    KERNEL_TRY(launch_scale_x(kp, g->Xp.p, Np, g->DP, g->Xs.p, g->ak.p, s));
+    g->dot_form = dot_form_ok(kp, X, N, D);
     if (A_host) {
         IBO_TRY(g->A.ensure((size_t)N * N));
         HIP_TRY(hipMemcpyAsync(g->A.p, A_host, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
@@ -339,6 +360,8 @@ static int fit_from_inverse(ibo_gp *g, int ktype, int N, int D, const double *X,
     g->kp = kp; g->noise = noise;
     const int Np = g->Npad;
     hipStream_t s = g->stream;
+    KERNEL_TRY(launch_scale_x(kp, g->Xp.p, Np, g->DP, g->Xs.p, g->ak.p, s));
+    g->dot_form = dot_form_ok(kp, X, N, D);
     IBO_TRY(g->A.ensure((size_t)N * N));
     HIP_TRY(hipMemcpyAsync(g->A.p, invR, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(g->fit0, s));
@@ -475,6 +498,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     SweepArgs a;
     memset(&a, 0, sizeof(a));
     a.kp = g->kp; a.N = g->N; a.Npad = g->Npad; a.DP = g->DP; a.M = M;
+    a.Xs = g->Xs.p; a.ak = g->ak.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = g_dot_override >= 0 ? g_dot_override : g->dot_form;
     a.Xp = g->Xp.p; a.W = g->W.p; a.Wp = g->Wp.p; a.alphaY = g->alphaY.p; a.alpha1 = g->alpha1.p;
     a.cand = cand_dev;
     a.prior.nb = g->nb; a.prior.theta = g->ptheta; a.prior.means = g->pmeans.p; a.prior.beta = g->pbeta.p;

@@ -20,6 +20,7 @@ struct KParams {
     int D;                      // true dimensionality (<= IBO_DMAX)
     double sf2;
     double w[IBO_DMAX];         // zero beyond D
+    double sw[IBO_DMAX];        // sqrt(w): coordinates are pre-scaled for the sweep's k* generation
 };
 
 template <int FAM>
@@ -29,6 +30,47 @@ __device__ __forceinline__ double cov_from_z(double z, double sf2)
     if (FAM == FAM_M3) { double r = sqrt(3.0 * z); return sf2 * (1.0 + r) * exp(-r); }
     double r = sqrt(5.0 * z);
     return sf2 * (1.0 + r + r * r * (1.0 / 3.0)) * exp(-r);
+}
+
+// exp(y) for the k* generation in 16 VALU instructions (the library's takes ~30).
+// Next to a saturated fp64 MFMA pipe EVERY VALU instruction -- fp64, fp32 or integer --
+// costs 7-13 pipe cycles (tools/mfma_f64_peak), so instruction count is sweep time.
+//   t = y log2(e) + 1.5*2^52 puts n = rint(y log2 e) in the low mantissa bits of t;
+//   r = y - n ln2 (two-term Cody-Waite);  degree-10 near-minimax polynomial on
+//   |r| <= ln2/2 (max relative error 4.4e-16, fitted at Chebyshev nodes);
+//   2^n by an integer add into the exponent field.  Valid for -708 <= y <= 709;
+//   smaller y is clamped (result 3e-308 instead of a denormal or 0).
+__device__ __forceinline__ double exp_fast(double y)
+{
+    y = fmax(y, -708.0);
+    const double magic = 6755399441055744.0;               // 1.5 * 2^52
+    const double t = fma(y, 1.4426950408889634074, magic);
+    const double n = t - magic;
+    double r = fma(n, -6.93147180369123816490e-01, y);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 2.76263763215172631873e-07;
+    p = fma(p, r, 2.76401811512398433028e-06);
+    p = fma(p, r, 2.48015043005816596198e-05);
+    p = fma(p, r, 1.98411702694117908236e-04);
+    p = fma(p, r, 1.38888889325245227201e-03);
+    p = fma(p, r, 8.33333338566888577603e-03);
+    p = fma(p, r, 4.16666666665730586749e-02);
+    p = fma(p, r, 1.66666666665543999892e-01);
+    p = fma(p, r, 5.00000000000000555112e-01);
+    p = fma(p, r, 1.00000000000000666134e+00);
+    p = fma(p, r, 1.0);
+    const int hi = __double2hiint(p) + (__double2loint(t) << 20);
+    return __hiloint2double(hi, __double2loint(p));
+}
+
+// k* from pre-scaled coordinates.  SE: y = log sf2 - z/2 fed to exp_fast.
+template <int FAM>
+__device__ __forceinline__ double cov_from_z_fast(double z, double log_sf2, double sf2)
+{
+    if (FAM == FAM_SE) return exp_fast(fma(-0.5, z, log_sf2));
+    if (FAM == FAM_M3) { double r = sqrt(3.0 * z); return sf2 * (1.0 + r) * exp_fast(-r); }
+    double r = sqrt(5.0 * z);
+    return sf2 * fma(r, fma(r, 1.0 / 3.0, 1.0), 1.0) * exp_fast(-r);
 }
 
 __device__ __forceinline__ double cov_from_z_rt(int fam, double z, double sf2)
@@ -101,6 +143,10 @@ struct SweepArgs {
     int N, Npad, DP;
     int64_t M;
     const double *Xp;        // Npad x DP, zero padded
+    const double *Xs;        // Npad x DP, coordinates scaled by sqrt(w_d)  (x~)
+    const double *ak;        // Npad: -|x~_k|^2 / 2
+    double log_sf2;          // log of the k* signal variance
+    int dot_form;            // SE only: y = ak + bc + x~.c~ (D+1 FMAs) instead of the difference form
     const double *W;         // Npad x Npad row-major lower-triangular, q = |W k*|^2
     const double *Wp;        // same matrix in MFMA fragment order (see pack_w_kernel)
     const double *alphaY;    // Npad
@@ -140,5 +186,7 @@ int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2
 // z = L^-1 y (blocked forward substitution), returns |z|^2 and sum(log diag L) in out2[0..1]
 int launch_fwd_quad_logdet(const double *L, int N, int Npad, const double *diag64, const double *y,
                            double *z, double *out2, hipStream_t s);
+// Xs = Xp * sqrt(w), ak = -|Xs_k|^2/2; maxnorm2 (device double) receives max_k |Xs_k|^2
+int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double *Xs, double *ak, hipStream_t s);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);
 int launch_mfma_selftest(double *out_err, hipStream_t s);

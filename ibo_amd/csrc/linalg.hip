@@ -51,6 +51,26 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
     return (int)hipGetLastError();
 }
 
+__global__ void scale_x_kernel(KParams kp, const double *__restrict__ Xp, int Npad, int DP,
+                               double *__restrict__ Xs, double *__restrict__ ak)
+{
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Npad) return;
+    double n2 = 0.0;
+    for (int d = 0; d < DP; d++) {
+        double v = (d < kp.D) ? Xp[(size_t)k * DP + d] * kp.sw[d] : 0.0;
+        Xs[(size_t)k * DP + d] = v;
+        n2 = fma(v, v, n2);
+    }
+    ak[k] = -0.5 * n2;
+}
+
+int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double *Xs, double *ak, hipStream_t s)
+{
+    hipLaunchKernelGGL(scale_x_kernel, dim3((Npad + 255) / 256), dim3(256), 0, s, kp, Xp, Npad, DP, Xs, ak);
+    return (int)hipGetLastError();
+}
+
 __global__ void pad_copy_kernel(const double *__restrict__ src, int N, int lds, double *__restrict__ dst,
                                 int Npad, double pad_diag)
 {

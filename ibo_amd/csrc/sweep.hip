@@ -20,6 +20,7 @@
 //     does a wave-level (max, lowest index) reduction -> one partial per tile.
 // Small batches (M <= 16) go through a row-parallel GEMV kernel instead.
 #include "ibo_common.h"
+#include <type_traits>
 
 #define TC 64          // candidates per workgroup
 #define PANEL 512      // rows of V accumulated per pass = NWAVE * 4 * 16
@@ -78,10 +79,18 @@ __device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
 // cycles per SIMD but a single wave only reaches ~46 % of that (tools/mfma_f64_peak),
 // so the pipe needs >= 2 waves per SIMD in their MFMA phase at any time:
 // <16, 2> (64 accumulator VGPRs, 4 waves/SIMD) is the default, <8, 4> the first version.
-template <int FAM, int DP, int NW, int RBW, int KCH>
+// DOT: squared-exponential k* as exp(a_k + b_c + x~.c~) (D+1 FMAs) instead of the
+// difference form (2D) -- fp64 VALU shares the MFMA pipe, instruction count is time.
+// CBW: candidate-blocks per wave (4: a wave spans the whole tile; 2: waves come in pairs
+// that share row-blocks, each wave owning RBW = 4 row-blocks spread over the panel, which
+// keeps all 16 waves busy until the last stage of the triangular diagonal block).
+template <int FAM, int DP, int NW, int RBW, int CBW, int KCH, bool DOT>
 __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
 {
-    static_assert(NW * RBW * 16 == PANEL, "panel is 512 rows");
+    constexpr int CG = 4 / CBW;                    // candidate groups of waves
+    constexpr int RG = NW / CG;                    // row groups of waves
+    static_assert(RG * RBW * 16 == PANEL, "panel is 512 rows");
+    static_assert(!DOT || FAM == FAM_SE, "dot form is for the squared exponential");
     constexpr int KPW = KCH / NW;                  // K* rows generated per wave per stage
     static_assert(KPW >= 1 && KPW <= 4 && (4 % KPW == 0), "wave generates 1, 2 or 4 rows of a k4-step");
     __shared__ double lds_k[2][KCH * TC];          // K* stage, B-fragment order
@@ -98,126 +107,158 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         int d = e / TC, c = e - d * TC;
         int64_t gi = tile0 + c;
         if (gi > a.M - 1) gi = a.M - 1;
-        lds_c[e] = (d < D) ? a.cand[gi * D + d] : 0.0;
+        lds_c[e] = (d < D) ? a.cand[gi * D + d] * a.kp.sw[d] : 0.0;     // pre-scaled: c~_d = c_d sqrt(w_d)
     }
     __syncthreads();
     constexpr bool CX_REG = (DP <= 8);             // keep the candidate in registers when it is small
     double cx[CX_REG ? DP : 1];
-    if (CX_REG) {
+    double bc;                                      // log sf2 - |c~|^2 / 2   (dot form)
+    {
+        double n2 = 0.0;
 #pragma unroll
-        for (int d = 0; d < DP; d++) cx[d] = lds_c[d * TC + lane];
+        for (int d = 0; d < DP; d++) {
+            double v = lds_c[d * TC + lane];
+            n2 = fma(v, v, n2);
+            if (CX_REG) cx[CX_REG ? d : 0] = v;
+        }
+        bc = fma(-0.5, n2, a.log_sf2);
     }
 
-    const int Npad = a.Npad;
+    const int Npad = a.Npad;                        // multiple of 64 >= KCH: stages never run past it
     const int nk8 = Npad >> 3;
     const int nRB = Npad >> 4;
     const int npanel = (Npad + PANEL - 1) / PANEL;
     const double2 *Wp2 = (const double2 *)a.Wp;
     double muY = 0.0, mu1 = 0.0;
-    double qacc[4] = {0.0, 0.0, 0.0, 0.0};         // lanes 0..15 hold sums for candidate block cb
+    double qacc[CBW];                               // lanes 0..15 hold sums for candidate block cg*CBW + cb
+#pragma unroll
+    for (int cb = 0; cb < CBW; cb++) qacc[cb] = 0.0;
+    // this wave's slot in a stage: rows kl0 .. kl0+KPW-1, written in B-fragment order
+    const int cg = wave % CG, rg = wave / CG;       // this wave's candidate group / row group
+    const int kl0 = wave * KPW;
+    const int wr_off = ((kl0 >> 2) * 4 + (lane >> 4)) * 64 + (kl0 & 3) * 16 + (lane & 15);
 
-    for (int p = 0; p < npanel; p++) {
-        const bool last = (p == npanel - 1);
+    // produce K* rows [k0, k0+KCH) into stage b (LAST: also accumulate the mean)
+    auto gen = [&](int k0, int b, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+#pragma unroll
+        for (int kk = 0; kk < KPW; kk++) {
+            const int k = k0 + kl0 + kk;
+            const double *xr = a.Xs + (size_t)k * DP;
+            double kv;
+            if (DOT) {
+                double y = a.ak[k] + bc;
+#pragma unroll
+                for (int d = 0; d < DP; d++) y = fma(xr[d], CX_REG ? cx[CX_REG ? d : 0] : lds_c[d * TC + lane], y);
+                kv = exp_fast(y);
+            } else {
+                double z = 0.0;
+#pragma unroll
+                for (int d = 0; d < DP; d++) {
+                    double t = xr[d] - (CX_REG ? cx[CX_REG ? d : 0] : lds_c[d * TC + lane]);
+                    z = fma(t, t, z);
+                }
+                kv = cov_from_z_fast<FAM>(z, a.log_sf2, a.kp.sf2);
+            }
+            if (LAST) {
+                muY = fma(a.alphaY[k], kv, muY);
+                mu1 = fma(a.alpha1[k], kv, mu1);
+            }
+            lds_k[b][wr_off + kk * 16] = kv;
+        }
+    };
+
+    auto run_panel = [&](int p, auto last_tag) {
         const int kend = min((p + 1) * PANEL, Npad);
-        const int nchunk = (kend + KCH - 1) / KCH;
+        const int nchunk = kend / KCH;
+        const int nfull = (p * PANEL) / KCH;        // stages strictly left of the diagonal block
         int g[RBW];
+        bool keep[RBW];
         const double2 *wrow[RBW];
 #pragma unroll
         for (int i = 0; i < RBW; i++) {
-            g[i] = p * (PANEL / 16) + wave + NW * i;
+            g[i] = p * (PANEL / 16) + rg + RG * i;
+            keep[i] = g[i] < nRB;                   // row-block exists (last panel may be partial)
             wrow[i] = Wp2 + ((size_t)min(g[i], nRB - 1) * nk8) * 64 + lane;
         }
-        d4_t acc[RBW][4];
+        d4_t acc[RBW][CBW];
 #pragma unroll
         for (int i = 0; i < RBW; i++)
 #pragma unroll
-            for (int cb = 0; cb < 4; cb++) acc[i][cb] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            for (int cb = 0; cb < CBW; cb++) acc[i][cb] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-        // produce K* rows [k0, k0+KCH) into stage b; this wave does rows k0 + KPW*wave .. +KPW-1
-        auto gen = [&](int k0, int b) {
-#pragma unroll
-            for (int kk = 0; kk < KPW; kk++) {
-                const int kl = wave * KPW + kk;            // row within the stage
-                const int k = k0 + kl;
-                double kv = 0.0;
-                if (k < Npad) {
-                    const double *xr = a.Xp + (size_t)k * DP;
-                    double z = 0.0;
-#pragma unroll
-                    for (int d = 0; d < DP; d++) {
-                        double t = xr[d] - (CX_REG ? cx[CX_REG ? d : 0] : lds_c[d * TC + lane]);
-                        z += a.kp.w[d] * (t * t);
-                    }
-                    kv = cov_from_z<FAM>(z, a.kp.sf2);
-                    if (last) {
-                        muY += a.alphaY[k] * kv;
-                        mu1 += a.alpha1[k] * kv;
-                    }
-                }
-                lds_k[b][((kl >> 2) * 4 + (lane >> 4)) * 64 + (kl & 3) * 16 + (lane & 15)] = kv;
-            }
-        };
-
-        gen(0, 0);
+        gen(0, 0, last_tag);
         __syncthreads();
-        for (int t = 0; t < nchunk; t++) {
+        // One stage: A operands are loaded unconditionally (the tiles above the diagonal are
+        // stored as zeros) and prefetched one k8-step ahead; with DIAG the MFMAs of all-zero
+        // tiles are skipped (row-block g has non-zeros in columns <= 16 g + 15).
+        auto stage = [&](int t, auto diag_tag) {
+            constexpr bool DIAG = decltype(diag_tag)::value;
             const int b = t & 1;
-            const int k0 = t * KCH;
-            // A operands of the first k8-step of this stage: issue before the VALU-heavy gen
+            const int j0 = (t * KCH) >> 3;
             double2 af[RBW];
-            bool act[RBW];
 #pragma unroll
-            for (int i = 0; i < RBW; i++) {
-                act[i] = (g[i] < nRB) && (k0 <= 16 * g[i] + 15);
-                af[i] = act[i] ? wrow[i][(size_t)(k0 >> 3) * 64] : (double2){0.0, 0.0};
-            }
-            if (t + 1 < nchunk) gen(k0 + KCH, b ^ 1);
+            for (int i = 0; i < RBW; i++) af[i] = wrow[i][(size_t)j0 * 64];
+            if (t + 1 < nchunk) gen((t + 1) * KCH, b ^ 1, last_tag);
 #pragma unroll
             for (int jj = 0; jj < KCH / 8; jj++) {
-                const int j = (k0 >> 3) + jj;
                 double2 afn[RBW];
-                bool actn[RBW];
+                if (jj + 1 < KCH / 8) {
 #pragma unroll
-                for (int i = 0; i < RBW; i++) {      // prefetch the next k8-step of this stage
-                    actn[i] = (jj + 1 < KCH / 8) && (g[i] < nRB) && (8 * (j + 1) <= 16 * g[i] + 15) && (8 * (j + 1) < Npad);
-                    afn[i] = actn[i] ? wrow[i][(size_t)(j + 1) * 64] : (double2){0.0, 0.0};
+                    for (int i = 0; i < RBW; i++) afn[i] = wrow[i][(size_t)(j0 + jj + 1) * 64];
                 }
+                bool act[RBW];
+#pragma unroll
+                for (int i = 0; i < RBW; i++) act[i] = !DIAG || (8 * (j0 + jj) <= 16 * g[i] + 15);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const int s4 = jj * 2 + h;
-                    double bf[4];
+                    double bf[CBW];
 #pragma unroll
-                    for (int cb = 0; cb < 4; cb++) bf[cb] = lds_k[b][(s4 * 4 + cb) * 64 + lane];
+                    for (int cb = 0; cb < CBW; cb++)
+                        bf[cb] = lds_k[b][((jj * 2 + h) * 4 + cg * CBW + cb) * 64 + lane];
 #pragma unroll
                     for (int i = 0; i < RBW; i++) {
                         if (act[i]) {
                             const double av = h ? af[i].y : af[i].x;
 #pragma unroll
-                            for (int cb = 0; cb < 4; cb++) acc[i][cb] = mfma_f64(av, bf[cb], acc[i][cb]);
+                            for (int cb = 0; cb < CBW; cb++) acc[i][cb] = mfma_f64(av, bf[cb], acc[i][cb]);
                         }
                     }
                 }
+                if (jj + 1 < KCH / 8) {
 #pragma unroll
-                for (int i = 0; i < RBW; i++) { af[i] = afn[i]; act[i] = actn[i]; }
+                    for (int i = 0; i < RBW; i++) af[i] = afn[i];
+                }
             }
             __syncthreads();
-        }
+        };
+        for (int t = 0; t < nfull; t++) stage(t, std::false_type{});
+        for (int t = nfull; t < nchunk; t++) stage(t, std::true_type{});
         // |V|^2 down the rows of this panel: acc[i][cb][r] is row (lane>>4)+4r, column lane&15
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) {
+        for (int cb = 0; cb < CBW; cb++) {
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < RBW; i++)
+            for (int i = 0; i < RBW; i++) {
+                double si = 0.0;
 #pragma unroll
-                for (int r = 0; r < 4; r++) s += acc[i][cb][r] * acc[i][cb][r];
+                for (int r = 0; r < 4; r++) si = fma(acc[i][cb][r], acc[i][cb][r], si);
+                s += keep[i] ? si : 0.0;
+            }
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             qacc[cb] += s;
         }
-    }
+    };
+
+    for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
+    run_panel(npanel - 1, std::true_type{});        // the last panel sees every k: it also forms the mean
+
+    // every wave contributes to CBW candidate blocks only; the others get zeros
+    lds_q[wave][lane] = 0.0;
     if (lane < 16) {
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) lds_q[wave][cb * 16 + lane] = qacc[cb];
+        for (int cb = 0; cb < CBW; cb++) lds_q[wave][(cg * CBW + cb) * 16 + lane] = qacc[cb];
     }
     lds_m[0][wave][lane] = muY;
     lds_m[1][wave][lane] = mu1;
@@ -229,8 +270,11 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         int64_t li = tile0 + lane;
         bool valid = li < a.M;
         double xq[DP];
+        {
+            int64_t gi = valid ? li : a.M - 1;
 #pragma unroll
-        for (int d = 0; d < DP; d++) xq[d] = lds_c[d * TC + lane];
+            for (int d = 0; d < DP; d++) xq[d] = (d < D) ? a.cand[gi * D + d] : 0.0;
+        }
         bool excl;
         double val = finish_candidate(a, xq, q, my, m1, li, valid, excl);
         int64_t idx = a.index_base + li;
@@ -329,24 +373,32 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
     }
 }
 
-int g_sweep_variant = 2;     // 0: <16,2,32>  1: <8,4,32>  2: <16,2,64> (default)  (ibo_set_option("sweep_variant"))
+int g_sweep_variant = 2;     // <NW,RBW,CBW,KCH>  0: <16,2,4,32>  1: <8,4,4,32>  2: <16,2,4,64> (default)  3: <16,4,2,64>  (ibo_set_option("sweep_variant"))
 
-template <int FAM, int NW, int RBW, int KCH>
+template <int FAM, int NW, int RBW, int CBW, int KCH, bool DOT>
 static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     dim3 grid((unsigned)ntiles), block(NW * 64);
-    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, NW, RBW, KCH>), grid, block, 0, s, a);
-    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, NW, RBW, KCH>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, NW, RBW, KCH>), grid, block, 0, s, a);
+    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
+    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
     return (int)hipGetLastError();
+}
+
+template <int FAM, bool DOT>
+static int launch_mfma_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    if (g_sweep_variant == 1) return launch_mfma_cfg<FAM, 8, 4, 4, 32, DOT>(a, ntiles, s);
+    if (g_sweep_variant == 0) return launch_mfma_cfg<FAM, 16, 2, 4, 32, DOT>(a, ntiles, s);
+    if (g_sweep_variant == 3) return launch_mfma_cfg<FAM, 16, 4, 2, 64, DOT>(a, ntiles, s);
+    return launch_mfma_cfg<FAM, 16, 2, 4, 64, DOT>(a, ntiles, s);
 }
 
 template <int FAM>
 static int launch_mfma_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
-    if (g_sweep_variant == 1) return launch_mfma_cfg<FAM, 8, 4, 32>(a, ntiles, s);
-    if (g_sweep_variant == 0) return launch_mfma_cfg<FAM, 16, 2, 32>(a, ntiles, s);
-    return launch_mfma_cfg<FAM, 16, 2, 64>(a, ntiles, s);
+    if (FAM == FAM_SE && a.dot_form) return launch_mfma_var<FAM_SE, true>(a, ntiles, s);
+    return launch_mfma_var<FAM, false>(a, ntiles, s);
 }
 
 int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1)

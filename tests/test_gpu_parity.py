@@ -204,7 +204,7 @@ def test_sweep_vs_oracle_ragged(ibo, oracle, N, D, kind, M):
     assert r["best_idx"] == sw["best_idx"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_sweep_tile_variants_agree(ibo, oracle, variant):
     """every tile configuration of the MFMA kernel against the oracle (N spans 3 panels)"""
     from ibo_amd.gaussianprocess import GaussianProcess, kernel as K
@@ -225,6 +225,35 @@ def test_sweep_tile_variants_agree(ibo, oracle, variant):
     close(r["mu"], o_mu, atol=1e-9); close(r["s2"], o_s2)
     o = o_mu + 1.2 * np.sqrt(o_s2)
     close(r["acq"], o); assert r["best_idx"] == int(np.argmax(o))
+
+
+def test_kstar_dot_form_matches_difference_form(ibo, oracle):
+    """SE k* as exp(a_k + b_c + x~.c~) vs the difference form, incl. far-away candidates and an
+    sf2 != 1 kernel; both against the oracle"""
+    from ibo_amd.gaussianprocess import GaussianProcess, kernel as K
+    from ibo_amd.acquisition import sweep
+    from ibo_amd import _lib
+    N, D, M = 300, 3, 500
+    X, Y = synth(41, N, D)
+    cand = np.random.RandomState(42).rand(M, D)
+    cand[:50] = cand[:50] * 40 - 20                       # far outside the data (demo.py probes (-10,.5,-10))
+    cand[50:60] = X[:10]                                  # exactly on observations
+    for kern, okern in ((K.GaussianKernel_ard([.5, .5, .3]), oracle.Kern("ard", [.5, .5, .3])),
+                        (K.SVGaussianKernel_iso([.4, 1.02]), oracle.Kern("sviso", [.4, 1.02]))):
+        ogp = oracle.GP(okern, X, Y, noise=.1)
+        o_mu, o_s2 = ogp.posteriors(cand)
+        GP = GaussianProcess(kern, X, Y, noise=.1)
+        res = []
+        for form in (1, 0):
+            _lib.check(_lib.lib.ibo_set_option(b"dot_form", form))
+            try:
+                r = sweep(GP, cand, acq='ei', xi=.01, native=False, outputs=("mu", "s2", "acq"))
+            finally:
+                _lib.check(_lib.lib.ibo_set_option(b"dot_form", -1))
+            close(r["mu"], o_mu, atol=1e-9); close(r["s2"], o_s2)
+            res.append(r)
+        close(res[0]["mu"], res[1]["mu"], rtol=1e-9, atol=1e-11); close(res[0]["s2"], res[1]["s2"], rtol=1e-9)
+        assert res[0]["best_idx"] == res[1]["best_idx"]
 
 
 def test_sweep_exclusion_and_index_base(ibo):
