@@ -95,22 +95,23 @@ def main():
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
     from ibo_amd.acquisition import sweep
-    from ibo_amd.multigpu import RcclArgmax
+    from ibo_amd.multigpu import RcclArgmax, exchange_unique_id
 
-    dist = None
+    # No torch in this process: torch bundles its own HIP/HSA runtime and two GPU runtimes in one
+    # process do not coexist (second one finds no device / heap corruption at exit).  The launcher
+    # (torch.distributed.run) only provides RANK/LOCAL_RANK/WORLD_SIZE/MASTER_PORT; rendezvous is a
+    # file in /tmp keyed by the launcher's pid, barriers and the max-over-ranks are RCCL collectives.
+    _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
     comm = None
-    if world > 1:
-        import torch.distributed as dist          # rendezvous + barrier only; the data path is libibo_hip
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        ids = [RcclArgmax.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = RcclArgmax(world, rank, ids[0], device=local_rank)
+    id_path = None
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
+        uid, id_path = exchange_unique_id(world, rank)
+        comm = RcclArgmax(world, rank, uid, device=local_rank)
 
     def barrier():
         _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
 
     X, Y = synth(2, N_OBS, DIM)
@@ -146,11 +147,8 @@ def main():
         best = (v, i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    if comm is not None:
+        elapsed = comm.argmax(elapsed, rank)[0]     # max over ranks (every rank gets it)
 
     if rank == 0:
         total = float(M_PER_GPU) * world * args.steps
@@ -178,10 +176,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(X, Y, cand_host)
         print(json.dumps(out))
     if comm is not None:
+        comm.barrier()
         comm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if rank == 0 and id_path:
+            try:
+                os.unlink(id_path)
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":

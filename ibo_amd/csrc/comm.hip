@@ -84,7 +84,16 @@ extern "C" int ibo_comm_init(int device, int world_size, int rank, const unsigne
     if (!out || !id || world_size < 1 || rank < 0 || rank >= world_size) return IBO_ERR_ARG;
     int rc = load_rccl();
     if (rc) return rc;
-    if (hipSetDevice(device) != hipSuccess) return cfail(IBO_ERR_HIP, "hipSetDevice failed");
+    {
+        int ndev = -1;
+        hipError_t e1 = hipGetDeviceCount(&ndev);
+        hipError_t e2 = hipSetDevice(device);
+        if (e2 != hipSuccess) {
+            fprintf(stderr, "[libibo_hip] comm: hipGetDeviceCount -> %s (%d devices); hipSetDevice(%d) -> %s\n",
+                    hipGetErrorString(e1), ndev, device, hipGetErrorString(e2));
+            return cfail(IBO_ERR_HIP, "hipSetDevice failed");
+        }
+    }
     ibo_comm *c = new ibo_comm();
     c->device = device; c->world = world_size; c->rank = rank; c->dbuf = nullptr; c->cap = 0;
     rccl_unique_id_t u;

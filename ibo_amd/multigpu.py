@@ -108,6 +108,46 @@ class RcclArgmax(object):
             self.h = None
 
 
+def exchange_unique_id(world_size, rank, timeout_s=600.0):
+    """Hand rank 0's RCCL unique id to every rank of a ONE-NODE job without pulling a second
+    GPU runtime into the process (torch bundles its own HIP/HSA; two runtimes in one process
+    fail with "no ROCm-capable device" or corrupt the heap at exit).  All ranks of a
+    torch.distributed.run job are children of the same agent, so the agent's pid + MASTER_PORT
+    name a rendezvous file in /tmp; rank 0 writes it atomically, the others poll for it.
+    Multi-node launches must pass the id by their own means (IBO_COMM_ID_FILE overrides the path)."""
+    import os
+    import time
+    path = os.environ.get("IBO_COMM_ID_FILE") or "/tmp/ibo_rccl_id_%d_%s" % (
+        os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        uid = RcclArgmax.unique_id()
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        tmp = "%s.%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.rename(tmp, path)
+        return uid, path
+    try:
+        born = os.stat("/proc/%d" % os.getppid()).st_ctime - 5.0     # ignore files older than the launcher
+    except OSError:
+        born = 0.0
+    t0 = time.time()
+    while True:
+        try:
+            st = os.stat(path)
+            if st.st_size == _lib.COMM_ID_BYTES and st.st_mtime >= born:
+                with open(path, "rb") as f:
+                    return f.read(), path
+        except OSError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError("timed out waiting for the RCCL unique id at %s" % path)
+        time.sleep(0.01)
+
+
 def sharded_sweep(model, local_candidates, start, comm, **sweep_kw):
     """sweep this rank's block (rows [start, start+len)) and agree on the global arg-max.
     Returns dict(best_val, best_idx (global), best_x, best_rank, kernel_ms)."""

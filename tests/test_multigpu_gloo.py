@@ -59,3 +59,32 @@ def test_sharded_argmax_two_ranks_gloo():
     v, i, p, r = res[0][1]
     assert (v, i, r) == (-6.0, 11, 1)
     assert res[0][2][1] == -1 and res[0][2][3] == -1
+
+
+def _id_worker(rank, world, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_PORT"] = "45678"
+    from ibo_amd import multigpu
+    multigpu.RcclArgmax.unique_id = staticmethod(lambda: bytes(range(128)))     # no RCCL on the CPU box
+    if rank != 0:
+        import time
+        time.sleep(0.3)                                # rank 0 may well be first ...
+    uid, path = multigpu.exchange_unique_id(world, rank, timeout_s=30)
+    q.put((rank, uid, path))
+
+
+def test_unique_id_file_rendezvous():
+    """bench.py's torch-free rendezvous: rank 0 publishes the RCCL id in /tmp, keyed by the launcher pid"""
+    world = 3
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_id_worker, args=(r, world, q)) for r in range(world)]
+    for p in reversed(procs):                          # ... or last
+        p.start()
+    res = [q.get(timeout=60) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(uid == bytes(range(128)) for _, uid, _ in res)
+    assert len(set(path for _, _, path in res)) == 1
+    os.unlink(res[0][2])
