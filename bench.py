@@ -172,6 +172,15 @@ def main():
                          "kernel": "sweep_mfma_kernel", "kernel_ms": kmean * 1e3,
                          "flops_per_eval": f_eval, "evals_per_launch": M_PER_GPU},
         }
+        pmc = os.path.join(ROOT, "profiles", "r01_sweep_pmc.json")
+        if os.path.exists(pmc):
+            # HBM bytes per launch cannot be read live; they come from the committed rocprofv3 --pmc
+            # passes over this same command (tools/profile_bench.sh), FETCH_SIZE x2 (gfx950) + WRITE_SIZE
+            j = json.load(open(pmc))
+            out["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = "profiles/r01_sweep_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+            out["roofline"]["algorithmic_bytes_per_launch"] = (8 * DIM + 16) * M_PER_GPU
+            out["roofline"]["mfma_util_pct_pmc"] = j.get("mfma_util_pct")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, Y, cand_host)
         print(json.dumps(out))

@@ -79,6 +79,7 @@ __device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
 // cycles per SIMD but a single wave only reaches ~46 % of that (tools/mfma_f64_peak),
 // so the pipe needs >= 2 waves per SIMD in their MFMA phase at any time:
 // <16, 2> (64 accumulator VGPRs, 4 waves/SIMD) is the default, <8, 4> the first version.
+// (s_setprio around the MFMA block was tried: -9 %, it pins the compiler's schedule.)
 // DOT: squared-exponential k* as exp(a_k + b_c + x~.c~) (D+1 FMAs) instead of the
 // difference form (2D) -- fp64 VALU shares the MFMA pipe, instruction count is time.
 // CBW: candidate-blocks per wave (4: a wave spans the whole tile; 2: waves come in pairs

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (tools/profile_bench.sh) into profiles/<tag>_kernel_stats.csv and
+profiles/<tag>_sweep_pmc.json (per-launch means for the sweep kernel, with the gfx950 FETCH_SIZE x2
+correction of MI355X_MICROARCH.md applied in `hbm_bytes_per_launch`)."""
+import csv, glob, json, os, shutil, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+st = glob.glob(os.path.join(out, "trace", "*", "*_kernel_stats.csv"))
+if st:
+    shutil.copy(st[0], "profiles/%s_bench_kernel_stats.csv" % tag)
+res = {"kernel": "sweep_mfma_kernel", "source": "rocprofv3 --pmc, python3 bench.py --steps 3 --warmup 1", "counters": {}}
+for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "sweep_mfma" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            res["vgpr"] = r.get("VGPR_Count"); res["lds"] = r.get("LDS_Block_Size"); res["wg"] = r.get("Workgroup_Size")
+    for k, v in acc.items():
+        res["counters"][k] = sum(v) / len(v)
+c = res["counters"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports half the bytes of wide coalesced reads
+    res["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    res["hbm_bytes_per_launch_uncorrected"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+    res["mfma_util_pct"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c:
+    res["mfma_f64_flops_per_launch"] = c["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
+tr = glob.glob(os.path.join(out, "trace", "*", "*_kernel_trace.csv"))
+if tr:
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr[0])) if "sweep_mfma" in r["Kernel_Name"]]
+    res["kernel_trace_mean_ms"] = sum(d) / len(d) / 1e6
+    res["kernel_trace_launches"] = len(d)
+for l in open(os.path.join(out, "bench_trace.log")):
+    if l.startswith("{"):
+        b = json.loads(l)
+        res["bench_under_trace"] = {"value": b["value"], "kernel_ms_hip_events": b["roofline"]["kernel_ms"], "frac": b["roofline"]["frac"]}
+json.dump(res, open("profiles/%s_sweep_pmc.json" % tag, "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1, sort_keys=True))
