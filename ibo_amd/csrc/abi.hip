@@ -520,7 +520,15 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     IBO_TRY(g->res_v.ensure(1)); IBO_TRY(g->res_i.ensure(1));
     a.part_val = g->partv.p; a.part_idx = g->parti.p; a.result_val = g->res_v.p; a.result_idx = g->res_i.p;
     bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16);
-    if (gemv) {
+    // small batches: spread the 128-row panels over the grid too (one tile per 64 candidates alone
+    // would leave most of the 256 CUs idle); above ~128 tiles the plain kernel fills the chip
+    bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256));
+    if (split) {
+        IBO_TRY(g->qpart.ensure((size_t)((g->Npad + 127) / 128) * M)); IBO_TRY(g->mupart.ensure(2 * (size_t)M));
+        a.qpart = g->qpart.p; a.mupart = g->mupart.p;
+        KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
+        g->sweep_kernel = "sweep_mfma_kernel<split>";
+    } else if (gemv) {
         IBO_TRY(g->qpart.ensure((size_t)(g->Npad / 64) * M)); IBO_TRY(g->mupart.ensure(2 * (size_t)M));
         a.qpart = g->qpart.p; a.mupart = g->mupart.p;
         KERNEL_TRY(launch_sweep_gemv(a, s, g->ev0, g->ev1));

@@ -23,7 +23,6 @@
 #include <type_traits>
 
 #define TC 64          // candidates per workgroup
-#define PANEL 512      // rows of V accumulated per pass = NWAVE * 4 * 16
 
 __device__ __forceinline__ double prior_mu_dev(const PriorDev &p, int D, const double *x)
 {
@@ -85,12 +84,16 @@ __device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
 // CBW: candidate-blocks per wave (4: a wave spans the whole tile; 2: waves come in pairs
 // that share row-blocks, each wave owning RBW = 4 row-blocks spread over the panel, which
 // keeps all 16 waves busy until the last stage of the triangular diagonal block).
-template <int FAM, int DP, int NW, int RBW, int CBW, int KCH, bool DOT>
+// SPLIT: small batches (DIRECT's per-iteration batches, a few hundred points) cannot fill 256
+// CUs with one workgroup per 64 candidates, so the row panels (PANEL rows each) are spread over
+// blockIdx.y as well; every workgroup writes its panel's partial |V|^2 (and the last panel the
+// mean) and sweep_gemv_finish_kernel sums the partials in a fixed order.
+template <int FAM, int DP, int NW, int RBW, int CBW, int KCH, bool DOT, int PANEL = 512, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
 {
     constexpr int CG = 4 / CBW;                    // candidate groups of waves
     constexpr int RG = NW / CG;                    // row groups of waves
-    static_assert(RG * RBW * 16 == PANEL, "panel is 512 rows");
+    static_assert(RG * RBW * 16 == PANEL, "waves x row-blocks must tile the panel");
     static_assert(!DOT || FAM == FAM_SE, "dot form is for the squared exponential");
     constexpr int KPW = KCH / NW;                  // K* rows generated per wave per stage
     static_assert(KPW >= 1 && KPW <= 4 && (4 % KPW == 0), "wave generates 1, 2 or 4 rows of a k4-step");
@@ -252,8 +255,14 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         }
     };
 
-    for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
-    run_panel(npanel - 1, std::true_type{});        // the last panel sees every k: it also forms the mean
+    if (SPLIT) {
+        const int p = blockIdx.y;
+        if (p == npanel - 1) run_panel(p, std::true_type{});
+        else run_panel(p, std::false_type{});
+    } else {
+        for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
+        run_panel(npanel - 1, std::true_type{});    // the last panel sees every k: it also forms the mean
+    }
 
     // every wave contributes to CBW candidate blocks only; the others get zeros
     lds_q[wave][lane] = 0.0;
@@ -270,6 +279,13 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         for (int w = 0; w < NW; w++) { q += lds_q[w][lane]; my += lds_m[0][w][lane]; m1 += lds_m[1][w][lane]; }
         int64_t li = tile0 + lane;
         bool valid = li < a.M;
+        if (SPLIT) {
+            if (valid) {
+                a.qpart[(size_t)blockIdx.y * a.M + li] = q;
+                if ((int)blockIdx.y == npanel - 1) { a.mupart[li] = my; a.mupart[a.M + li] = m1; }
+            }
+            return;
+        }
         double xq[DP];
         {
             int64_t gi = valid ? li : a.M - 1;
@@ -395,9 +411,23 @@ static int launch_mfma_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     return launch_mfma_cfg<FAM, 16, 2, 4, 64, DOT>(a, ntiles, s);
 }
 
+template <int FAM, bool DOT>
+static int launch_mfma_split(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    dim3 grid((unsigned)ntiles, (a.Npad + 127) / 128), block(1024);
+    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, 16, 1, 2, 64, DOT, 128, true>), grid, block, 0, s, a);
+    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, 16, 1, 2, 64, DOT, 128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, 16, 1, 2, 64, DOT, 128, true>), grid, block, 0, s, a);
+    return (int)hipGetLastError();
+}
+
 template <int FAM>
 static int launch_mfma_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
+    if (a.qpart) {           // split mode requested by the caller (small batch)
+        if (FAM == FAM_SE && a.dot_form) return launch_mfma_split<FAM_SE, true>(a, ntiles, s);
+        return launch_mfma_split<FAM, false>(a, ntiles, s);
+    }
     if (FAM == FAM_SE && a.dot_form) return launch_mfma_var<FAM_SE, true>(a, ntiles, s);
     return launch_mfma_var<FAM, false>(a, ntiles, s);
 }
@@ -412,6 +442,11 @@ int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
     else rc = launch_mfma_fam<FAM_M5>(a, ntiles, s);
     if (e1) (void)hipEventRecord(e1, s);
     if (rc) return rc;
+    if (a.qpart) {
+        hipLaunchKernelGGL(sweep_gemv_finish_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, a, (a.Npad + 127) / 128);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
     return launch_argmax_final(a, ntiles, s);
 }
 

@@ -80,8 +80,10 @@ int         ibo_device_name(int device, char *buf, size_t buflen);
 /* self-test of the fp64 MFMA fragment layout on the device (returns IBO_OK or
  * IBO_ERR_HIP with a message); cheap, used by smoke() */
 int         ibo_selftest_mfma(int device, double *max_abs_err);
-/* tuning/testing knobs: "sweep_path" = 0 auto (GEMV kernel for M <= 16, MFMA tile
- * kernel otherwise), 1 force GEMV, 2 force MFMA.  Env IBO_SWEEP_IMPL=gemv|mfma too. */
+/* tuning/testing knobs: "sweep_path" = 0 auto (GEMV kernel for M <= 16, panel-split MFMA
+ * kernel up to 8192 candidates, MFMA tile kernel above), 1 force GEMV, 2 force MFMA tile,
+ * 3 force panel-split; "sweep_variant" picks the tile shape; "dot_form" -1 auto / 0 / 1.
+ * Env IBO_SWEEP_IMPL=gemv|mfma too. */
 int         ibo_set_option(const char *key, int value);
 
 /* ---------------------------------------------------------------- device memory */

@@ -156,10 +156,10 @@ def test_g6_sweeps_vs_reference_vectors(ibo, name):
     X, Y = synth(seed, N, D)
     cand = np.random.RandomState(100 + seed).rand(M, D)
     GP = GaussianProcess(our_kernel(g[p + "ktype"], g[p + "hyper"]), X, Y, noise=.1)
-    for path in (2, 1):        # MFMA tile kernel, then the GEMV kernel, on the same inputs
+    for path in (2, 3, 1):     # MFMA tile kernel, its panel-split form (small batches), the GEMV kernel
         _lib.check(_lib.lib.ibo_set_option(b"sweep_path", path))
         try:
-            sub = slice(0, M if path == 2 else min(M, 48))
+            sub = slice(0, M if path != 1 else min(M, 48))
             r = sweep(GP, cand[sub], acq='ei', xi=.01, native=False, outputs=("mu", "s2", "acq"))
             close(r["mu"], g[p + "mu"][sub], atol=1e-9); close(r["s2"], g[p + "s2"][sub])
             close(r["acq"], g[p + "ei_py"][sub], atol=ACQ_ATOL)
