@@ -447,3 +447,83 @@ def test_errors_are_loud(ibo):
     with pytest.raises(np.linalg.LinAlgError):
         GaussianProcess(GaussianKernel_ard([1.]), X, [1., 1., 2.], noise=-1.0)
     assert issubclass(NotPositiveDefinite, np.linalg.LinAlgError)
+
+
+# --------------------------------------------------------------------------- full-size configurations
+def _hartman6(x):
+    A = np.array([[10, 3, 17, 3.5, 1.7, 8], [0.05, 10, 17, 0.1, 8, 14], [3, 3.5, 1.7, 10, 17, 8], [17, 8, 0.05, 10, 0.1, 14]])
+    P = np.array([[0.1312, 0.1696, 0.5569, 0.0124, 0.8283, 0.5886], [0.2329, 0.4135, 0.8307, 0.3736, 0.1004, 0.9991],
+                  [0.2348, 0.1451, 0.3522, 0.2883, 0.3047, 0.6650], [0.4047, 0.8828, 0.8732, 0.5743, 0.1091, 0.0381]])
+    C = np.array([1, 1.2, 3, 3.2])
+    return float(np.sum(C * np.exp(-np.sum(A * (x - P) ** 2, axis=1))))
+
+
+def test_c3_full_size_matern_gallery(ibo, oracle):
+    """BASELINE config 3 on one GPU's shard: N=2048, D=8, Matern-5/2, 2^19 candidates, gallery"""
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import MaternKernel5
+    from ibo_amd.acquisition import sweep
+    from ibo_amd.acquisition.gallery import fastUCBGallery
+    from ibo_amd import DeviceArray
+    N, D, M = 2048, 8, 1 << 19
+    X, Y = synth(3, N, D)
+    GP = GaussianProcess(MaternKernel5([.5, 1.0]), X, Y, noise=.1)
+    cand = np.random.RandomState(103).rand(M, D)
+    dc = DeviceArray.from_host(cand)
+    r = sweep(GP, dc, acq='ei', xi=.3, native=True, outputs=("mu", "s2", "acq"))
+    assert r["best_idx"] == int(np.argmax(r["acq"]))
+    # a slice of the sweep against the oracle (Python-path posterior, then libm EI)
+    ogp = oracle.GP(oracle.Kern("m5", [.5, 1.0]), X, Y, noise=.1)
+    idx = np.r_[np.arange(24), r["best_idx"]]
+    o_mu, o_s2 = ogp.posteriors(cand[idx])
+    close(r["mu"][idx], o_mu, atol=1e-9); close(np.maximum(r["s2"][idx], 1e-7), o_s2)
+    o_ei = oracle.acq_value(oracle.ACQ_EI, oracle.ERF_LIBM, o_mu, np.sqrt(o_s2), Y.max(), .3)
+    close(r["acq"][idx], o_ei, atol=ACQ_ATOL)
+    # contiguous shards (what 8 GPUs would each sweep) combine to the same arg-max
+    cuts = [0, 1 << 17, 3 << 17, M]
+    parts = [sweep(GP, dc.view_rows(a, b), acq='ei', xi=.3, native=True, index_base=a) for a, b in zip(cuts, cuts[1:])]
+    best = max(parts, key=lambda q: (q["best_val"], -q["best_idx"]))
+    assert best["best_idx"] == r["best_idx"]
+    gal = np.array(fastUCBGallery(GP, [[0., 1.]] * D, 4, candidates=dc))
+    assert gal.shape == (4, D) and np.all(gal >= 0) and np.all(gal <= 1)
+    assert min(np.linalg.norm(gal[i] - gal[j]) for i in range(4) for j in range(i)) > .5
+
+
+def test_c4_preference_gp_128_pairs(ibo, oracle):
+    """a larger preference GP (the oracle's BFGS with numerical gradients cannot go much further):
+    the MAP must reach a lower S than the start, everything downstream of it is checked at 1e-6"""
+    from ibo_amd.gaussianprocess import PrefGaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    P = 128
+    hyp = [0.53, 0.57, 2.5, 0.34, 0.27, 0.35]
+    pts = np.random.RandomState(4).rand(2 * P, 6)
+    prefs = []
+    for i in range(P):
+        a, b = pts[2 * i], pts[2 * i + 1]
+        prefs.append((a, b, 0) if _hartman6(a) > _hartman6(b) else (b, a, 0))
+    GP = PrefGaussianProcess(GaussianKernel_ard(hyp), prefs)
+    assert len(GP.X) == 2 * P and GP.C.shape == (2 * P, 2 * P)
+    ogp = oracle.pref_fit(oracle.Kern("ard", hyp), prefs, noise=.1, Y_map=GP.Y)
+    Lr = np.linalg.cholesky(ogp.R)
+    start = np.array([.5 if i in set(v for v, _, _ in ogp.inds) else -.5 for i in range(2 * P)])
+    assert oracle.pref_S(GP.Y, ogp.inds, Lr) < oracle.pref_S(start, ogp.inds, Lr)
+    close(GP.C, ogp.C, atol=1e-9); close(GP.L, ogp.L, atol=1e-9)
+    probe = np.random.RandomState(5).rand(40, 6)
+    mu, s2 = GP.posteriors(probe)
+    o_mu, o_s2 = ogp.posteriors(probe)
+    close(mu, o_mu, atol=1e-9); close(s2, o_s2)
+    assert sum(GP.mu(v) > GP.mu(u) for v, u, _ in prefs) >= 0.9 * P
+
+
+def test_c5_nlml_full_size(ibo, oracle):
+    """N=4096, D=16 ARD marginal likelihood: the GPU grid against NumPy's LAPACK on the oracle's K"""
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid
+    N, D = 4096, 16
+    X, Y = synth(5, N, D)
+    thetas = np.exp(np.random.RandomState(105).uniform(np.log(.1), np.log(3), size=(512, D)))[:3]
+    vals, am = nlml_grid(GaussianKernel_ard, thetas, X, Y, noise=1e-3)
+    ref = oracle.marginal_likelihood(oracle.Kern("ard", thetas[1]), X, Y, D, compute_gradient=False, noise=1e-3)
+    close(vals[1], ref, rtol=1e-9)
+    assert np.all(np.isfinite(vals)) and am == int(np.argmin(vals))
+    assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[1:2], X, Y, noise=1e-3)[0], vals[1:2])   # deterministic
