@@ -485,6 +485,47 @@ extern "C" int ibo_cov_matrix(int device, int ktype, int D, const double *hyper,
     return IBO_OK;
 }
 
+// Solve A X = B for a symmetric positive-definite A (N x N, host) and nrhs right-hand sides
+// (B, X: nrhs x N row-major, host) on the GPU: blocked Cholesky, explicit L^-1, X = L^-T (L^-1 B).
+// Used by the preference GP's Newton iterations (the Hessian of the MAP functional).
+extern "C" int ibo_spd_solve(int device, int N, const double *A_host, int nrhs, const double *B_host,
+                             double *X_host, int *info)
+{
+    if (!A_host || !B_host || !X_host || N < 1 || nrhs < 1) return fail(IBO_ERR_ARG, "bad argument");
+    IBO_TRY(use_device(device));
+    const int Np = round_up(N, 64);
+    const size_t nn = (size_t)Np * Np;
+    DevBuf<double> dA, dL, dW, dT, d64, db, dx, d1, tmp;
+    DevBuf<int> dinfo;
+    IBO_TRY(dA.ensure((size_t)N * N)); IBO_TRY(dL.ensure(nn)); IBO_TRY(dW.ensure(nn)); IBO_TRY(dT.ensure(nn));
+    IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096)); IBO_TRY(db.ensure(Np)); IBO_TRY(dx.ensure(Np)); IBO_TRY(d1.ensure(Np));
+    IBO_TRY(tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64)); IBO_TRY(dinfo.ensure(1));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipMemcpy(dA.p, A_host, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice));
+    KERNEL_TRY(launch_pad_copy(dA.p, N, N, dL.p, Np, 1.0, s));
+    KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
+    int h = 0;
+    HIP_TRY(hipMemcpy(&h, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) *info = h;
+    int rc = IBO_OK;
+    if (h != 0) rc = fail(IBO_ERR_NOT_PD, "matrix is not positive definite (pivot %d)", h);
+    else {
+        KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
+        KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
+        KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));      // zero the pad rows (dT reused as scratch)
+        std::vector<double> bp(Np, 0.0);
+        for (int r = 0; r < nrhs; r++) {
+            for (int i = 0; i < N; i++) bp[i] = B_host[(size_t)r * N + i];
+            HIP_TRY(hipMemcpy(db.p, bp.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
+            KERNEL_TRY(launch_alpha(dW.p, N, Np, db.p, tmp.p, dx.p, d1.p, s));
+            HIP_TRY(hipMemcpy(X_host + (size_t)r * N, dx.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+        }
+    }
+    dA.release(); dL.release(); dW.release(); dT.release(); d64.release(); db.release(); dx.release(); d1.release();
+    tmp.release(); dinfo.release();
+    return rc;
+}
+
 // ------------------------------------------------------------------------ sweep
 static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
                      double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,

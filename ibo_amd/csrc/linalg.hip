@@ -169,49 +169,120 @@ __device__ __forceinline__ void gemm_tile_64(const double *__restrict__ A, int l
 // blocked right-looking Cholesky, NB = 64
 // ------------------------------------------------------------------------
 #define SD 65
+__device__ __forceinline__ double lane_bcast(double x, int l)          // value of lane l, wave-uniform
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Factor the 64x64 diagonal block and invert the factor inside one workgroup, blocked by 16:
+//   per 16-column panel: (i) wave 0 factors the 16x16 diagonal sub-block and inverts it with the
+//   rows in registers (lane = row, operands broadcast with v_readlane, fully unrolled);
+//   (ii) the rows below are multiplied by that inverse (triangular solve as a small GEMM);
+//   (iii) the trailing sub-matrix gets its rank-16 update -- 4 x 4 barriers instead of 64 x 3.
+//   The 64x64 inverse is then assembled from the four 16x16 inverses by recursive doubling.
+// This kernel is the sequential chain of the whole factorisation (N/64 launches).
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, int Npad, int jb,
                                                         double *__restrict__ diag64, int *info)
 {
-    __shared__ double S[64 * SD];
-    __shared__ double V[64 * SD];
-    const int t = threadIdx.x;
+    __shared__ double S[64 * SD];          // the block; ends up holding L (lower)
+    __shared__ double V[64 * SD];          // its inverse
+    __shared__ double T[64 * SD];          // scratch (solved rows / L21 * V11 products)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     double *Lb = L + (size_t)jb * 64 * Npad + jb * 64;
     for (int e = t; e < 4096; e += 256) {
         int r = e >> 6, c = e & 63;
         S[r * SD + c] = Lb[(size_t)r * Npad + c];
+        V[r * SD + c] = 0.0;
     }
-    for (int j = 0; j < 64; j++) {
-        __syncthreads();
-        if (t == 0) {
-            double d = S[j * SD + j];
-            if (!(d > 0.0)) {            // also catches NaN
-                atomicCAS(info, 0, jb * 64 + j + 1);
-                d = 1.0;
+    __syncthreads();
+    for (int b = 0; b < 4; b++) {
+        const int o = 16 * b;
+        if (wv == 0) {
+            // (i) 16x16 Cholesky, lane = row (lanes >= 16 compute on a copy of row 15, unused)
+            const int rr = o + min(lane, 15);
+            double r[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) r[k] = S[rr * SD + o + k];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const double pj = r[j];
+                double d = lane_bcast(pj, j);
+                if (!(d > 0.0)) {                   // also catches NaN
+                    if (lane == 0) atomicCAS(info, 0, jb * 64 + o + j + 1);
+                    d = 1.0;
+                }
+                const double tj = pj / d;
+                r[j] = pj / sqrt(d);
+#pragma unroll
+                for (int k = j + 1; k < 16; k++) r[k] = fma(-tj, lane_bcast(pj, k), r[k]);
             }
-            S[j * SD + j] = sqrt(d);
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) S[rr * SD + o + k] = (k <= lane) ? r[k] : 0.0;
+            }
+            // inverse of the 16x16 factor, lane = column c: x[i] = V16[i][c]
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) acc = fma(-lane_bcast(r[k], i), x[k], acc);
+                x[i] = (i < lane) ? 0.0 : acc / lane_bcast(r[i], i);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) V[(o + i) * SD + o + lane] = x[i];
+            }
         }
         __syncthreads();
-        double djj = S[j * SD + j];
-        if (t > j && t < 64) S[t * SD + j] /= djj;
+        const int nbelow = 64 - o - 16;
+        // (ii) rows below: X[i][c] = sum_{k<=c} A[i][o+k] * V16[c][k]   -> T, then copied back
+        for (int e = t; e < nbelow * 16; e += 256) {
+            int i = o + 16 + (e >> 4), c = e & 15;
+            double acc = 0.0;
+            for (int k = 0; k <= c; k++) acc = fma(S[i * SD + o + k], V[(o + c) * SD + o + k], acc);
+            T[i * SD + c] = acc;
+        }
         __syncthreads();
-        int i = t & 63;
-        if (i > j) {
-            double lij = S[i * SD + j];
-            for (int k = j + 1 + (t >> 6); k <= i; k += 4) S[i * SD + k] -= lij * S[k * SD + j];
+        for (int e = t; e < nbelow * 16; e += 256) {
+            int i = o + 16 + (e >> 4), c = e & 15;
+            S[i * SD + o + c] = T[i * SD + c];
         }
-    }
-    __syncthreads();
-    // inverse of the 64x64 lower-triangular block, one column per thread
-    if (t < 64) {
-        int c = t;
-        for (int i = 0; i < c; i++) V[i * SD + c] = 0.0;
-        for (int i = c; i < 64; i++) {
-            double s = (i == c) ? 1.0 : 0.0;
-            for (int k = c; k < i; k++) s -= S[i * SD + k] * V[k * SD + c];
-            V[i * SD + c] = s / S[i * SD + i];
+        __syncthreads();
+        // (iii) trailing update (lower part): S[i][k] -= sum_c S[i][o+c] S[k][o+c]
+        for (int e = t; e < nbelow * nbelow; e += 256) {
+            int i = o + 16 + e / nbelow, k = o + 16 + e % nbelow;
+            if (k <= i) {
+                double acc = S[i * SD + k];
+#pragma unroll
+                for (int c = 0; c < 16; c++) acc = fma(-S[i * SD + o + c], S[k * SD + o + c], acc);
+                S[i * SD + k] = acc;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
+    // inverse by recursive doubling over 16-blocks: [L11 0; L21 L22]^-1 = [V11 0; -V22 L21 V11, V22]
+    for (int sz = 16; sz < 64; sz *= 2) {
+        const int nodes = 64 / (2 * sz);
+        // T = L21 * V11   (L21: rows o+sz.., cols o..o+sz; V11 lower triangular)
+        for (int e = t; e < nodes * sz * sz; e += 256) {
+            int nd = e / (sz * sz), q = e % (sz * sz), i = q / sz, j = q % sz, o = nd * 2 * sz;
+            double acc = 0.0;
+            for (int k = j; k < sz; k++) acc = fma(S[(o + sz + i) * SD + o + k], V[(o + k) * SD + o + j], acc);
+            T[(o + sz + i) * SD + o + j] = acc;
+        }
+        __syncthreads();
+        // V21 = -V22 * T   (V22 lower triangular)
+        for (int e = t; e < nodes * sz * sz; e += 256) {
+            int nd = e / (sz * sz), q = e % (sz * sz), i = q / sz, j = q % sz, o = nd * 2 * sz;
+            double acc = 0.0;
+            for (int k = 0; k <= i; k++) acc = fma(V[(o + sz + i) * SD + o + sz + k], T[(o + sz + k) * SD + o + j], acc);
+            V[(o + sz + i) * SD + o + j] = -acc;
+        }
+        __syncthreads();
+    }
     double *Db = diag64 + (size_t)jb * 4096;
     for (int e = t; e < 4096; e += 256) {
         int r = e >> 6, c = e & 63;

@@ -278,26 +278,58 @@ class PrefGaussianProcess(GaussianProcess):
             self.addPreferences(prefs)
 
     @staticmethod
-    def _S_and_grad(y, inds, Rinv):
-        """MAP functional (:351-385) and its analytic gradient.
-        S(y) = -sum (d+1) log(Phi((y_v-y_u)/sqrt 2) + 1e-10) + y^T R^-1 y / 2"""
-        v = np.array([i[0] for i in inds]); u = np.array([i[1] for i in inds])
-        w = np.array([i[2] + 1.0 for i in inds])
+    def _S_terms(y, v, u, w, Rinv, hess=True):
+        """MAP functional S(y) = -sum (d+1) log(Phi((y_v-y_u)/sqrt 2) + 1e-10) + y^T R^-1 y / 2
+        (:351-385) with gradient and the per-pair Hessian weights.  Phi is the reference's CDF
+        (NR erf, truncated 1/sqrt 2) so S is the same function; its derivative uses the exact pdf."""
         z = (y[v] - y[u]) / np.sqrt(2)
-        # keep the reference's CDF definition (NR erf with truncated 1/sqrt2) so S is the same function
-        cdf = np.array([CDF(zz) for zz in z])
-        pdf = np.exp(-(z * 0.707106) ** 2) * (2 / np.sqrt(np.pi)) * 0.5 * 0.707106
+        cdf = np.array([CDF(zz) for zz in z]) + 1e-10
+        t = z * 0.707106
+        pdf = 0.707106 / np.sqrt(np.pi) * np.exp(-t * t)           # d CDF / dz
         Ry = Rinv.dot(y)
-        S = -np.sum(w * np.log(cdf + 1e-10)) + 0.5 * y.dot(Ry)
-        gz = -w * pdf / (cdf + 1e-10) / np.sqrt(2)
+        S = -np.sum(w * np.log(cdf)) + 0.5 * y.dot(Ry)
+        ratio = pdf / cdf
+        gz = -w * ratio / np.sqrt(2)
         g = Ry.copy()
         np.add.at(g, v, gz)
         np.add.at(g, u, -gz)
-        return S, g
+        if not hess:
+            return S, g, None
+        # -d/dz (pdf/cdf) = 2 t' pdf/cdf * 0.707106 + (pdf/cdf)^2, t' = 0.707106 z; (dz/dy)^2 = 1/2
+        rho = w * (2 * 0.707106 * t * ratio + ratio * ratio) / 2.0
+        return S, g, rho
+
+    def _map_newton(self, start, prefinds, Rinv, tol=1e-9, maxit=100):
+        """minimise the (convex) MAP functional by damped Newton; each step solves
+        (R^-1 + C_pref) delta = -g on the GPU (ibo_spd_solve)."""
+        v = np.array([i[0] for i in prefinds]); u = np.array([i[1] for i in prefinds])
+        w = np.array([i[2] + 1.0 for i in prefinds])
+        y = np.array(start, dtype=float)
+        N = len(y)
+        S, g, rho = self._S_terms(y, v, u, w, Rinv)
+        for it in range(maxit):
+            if np.max(np.abs(g)) < tol * max(1.0, np.max(np.abs(y))):
+                break
+            H = Rinv.copy()
+            np.add.at(H, (v, v), rho); np.add.at(H, (u, u), rho)
+            np.add.at(H, (v, u), -rho); np.add.at(H, (u, v), -rho)
+            delta = np.empty(N)
+            Hc = _lib.f64(H); gc = _lib.f64(-g)
+            _lib.check(_lib.lib.ibo_spd_solve(self._dev.device, N, _lib.dp(Hc), 1, _lib.dp(gc), _lib.dp(delta), None))
+            step = 1.0
+            while True:
+                Sn, gn, rn = self._S_terms(y + step * delta, v, u, w, Rinv)
+                if np.isfinite(Sn) and Sn <= S + 1e-4 * step * g.dot(delta):
+                    break
+                step *= 0.5
+                if step < 1e-10:
+                    return y
+            y = y + step * delta
+            S, g, rho = Sn, gn, rn
+        return y
 
     def addPreferences(self, prefs, useC=True, showPrefLikelihood=False):
         """add (x_preferred, x_unpreferred, degree) triples and refit from ALL preferences (:347-498)"""
-        from scipy.optimize import minimize
         self.preferences.extend(prefs)
 
         x2ind = {}
@@ -339,11 +371,9 @@ class PrefGaussianProcess(GaussianProcess):
         _lib.check(_lib.lib.ibo_gp_get_W(self._handle(), _lib.dp(W)))
         Rinv = W.T.dot(W)
 
-        # MAP by quasi-Newton on S (:442).  The reference runs fmin_bfgs with numerical
-        # gradients (gtol 1e-5); the analytic gradient reaches the same convex optimum.
-        res = minimize(self._S_and_grad, np.array(start, dtype=float), args=(prefinds, Rinv), jac=True,
-                       method="BFGS", options=dict(gtol=1e-7, maxiter=2000))
-        Y = res.x
+        # MAP (:442).  The reference runs fmin_bfgs with numerical gradients (gtol 1e-5) on this
+        # convex functional; Newton with the analytic Hessian reaches the same optimum in ~10 solves.
+        Y = self._map_newton(start, prefinds, Rinv)
         for r, c, _ in prefinds:                      # order fix-up (:445-457)
             if Y[r] <= Y[c]:
                 if not any(c1 == r for _, c1, _ in prefinds):

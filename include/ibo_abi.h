@@ -154,6 +154,14 @@ int ibo_cov_matrix(int device, int ktype, int D, const double *hyper_host, int n
                    int n1, const double *A1_host, int n2, const double *A2_host,
                    int diag_rule, double noise, double *K_host);
 
+/* X = A^-1 B for a symmetric positive-definite A (N x N) and nrhs right-hand sides (B, X:
+ * nrhs x N row-major), all host buffers: blocked Cholesky + explicit L^-1 on the GPU.  The
+ * preference GP's MAP (ego/gaussianprocess/__init__.py:442) runs Newton steps through this:
+ * the Hessian of its functional is R^-1 plus the preference terms.  IBO_ERR_NOT_PD / *info
+ * as ibo_gp_fit. */
+int ibo_spd_solve(int device, int N, const double *A_host, int nrhs, const double *B_host,
+                  double *X_host, int *info);
+
 /* ---------------------------------------------------------------- posterior / sweep */
 /*
  * Batched posterior: replaces GaussianProcess.posterior / posteriors / mu
