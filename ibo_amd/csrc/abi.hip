@@ -679,11 +679,11 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
 {
     if (!X || !Y || !thetas || !nlml_host || N < 1 || n_theta < 1) return fail(IBO_ERR_ARG, "bad argument");
     IBO_TRY(use_device(device));
-    const int Np = round_up(N, 64);
-    DevBuf<double> dX, dY, dK, dL, d64, dz, dout;
+    const int Np = round_up(N + 1, 64);            // room for the appended y row (see aug_row_kernel)
+    DevBuf<double> dX, dY, dK, dL, d64, dout;
     DevBuf<int> dinfo;
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N)); IBO_TRY(dK.ensure((size_t)N * N));
-    IBO_TRY(dL.ensure((size_t)Np * Np)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096)); IBO_TRY(dz.ensure(Np));
+    IBO_TRY(dL.ensure((size_t)Np * Np)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096));
     IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
     hipStream_t s = nullptr;
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
@@ -693,8 +693,9 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
         KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dK.p, N, s));
         KERNEL_TRY(launch_pad_copy(dK.p, N, N, dL.p, Np, 1.0, s));
+        KERNEL_TRY(launch_nlml_aug(dL.p, Np, N, dY.p, s));
         KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p + t, s));
-        KERNEL_TRY(launch_fwd_quad_logdet(dL.p, N, Np, d64.p, dY.p, dz.p, dout.p + 2 * t, s));
+        KERNEL_TRY(launch_nlml_reduce(dL.p, Np, N, dout.p + 2 * t, s));
     }
     std::vector<double> out(2 * (size_t)n_theta);
     std::vector<int> info(n_theta);
@@ -703,7 +704,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     const double half_log_2pi_n = 0.5 * N * log(2.0 * M_PI);
     for (int t = 0; t < n_theta; t++)
         nlml_host[t] = info[t] ? NAN : 0.5 * out[2 * t] + out[2 * t + 1] + half_log_2pi_n;
-    dX.release(); dY.release(); dK.release(); dL.release(); d64.release(); dz.release(); dout.release(); dinfo.release();
+    dX.release(); dY.release(); dK.release(); dL.release(); d64.release(); dout.release(); dinfo.release();
     return IBO_OK;
 }
 

@@ -183,10 +183,9 @@ int launch_pack_w(const double *S, int N, int Npad, int mode, double *Wout, doub
 // alpha = W^T (W y) for two right-hand sides at once (y and the all-ones vector)
 int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2, double *alphaY,
                  double *alpha1, hipStream_t s);
-// z = L^-1 y (blocked forward substitution), returns |z|^2 and sum(log diag L) in out2[0..1]
-int launch_fwd_quad_logdet(const double *L, int N, int Npad, const double *diag64, const double *y,
-                           double *z, double *out2, hipStream_t s);
 // Xs = Xp * sqrt(w), ak = -|Xs_k|^2/2; maxnorm2 (device double) receives max_k |Xs_k|^2
 int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double *Xs, double *ak, hipStream_t s);
+int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s);
+int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);
 int launch_mfma_selftest(double *out_err, hipStream_t s);

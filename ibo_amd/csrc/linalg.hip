@@ -530,58 +530,47 @@ int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2
 }
 
 // ------------------------------------------------------------------------
-// z = L^-1 y by blocked forward substitution (one workgroup), plus
-// |z|^2 and sum_i log L_ii over the first N rows -- the two scalars the
-// marginal likelihood needs (ego/gaussianprocess/trainhyper.py:60-68).
+// Marginal likelihood scalars |L^-1 y|^2 and sum log L_ii (ego/gaussianprocess/trainhyper.py:60-68)
+// without a separate triangular solve: append y as row N of the matrix
+// being factored ([[K, y],[y^T, c]]); after the Cholesky that row IS z = L^-1 y, produced by
+// the factorisation's own trsm/syrk kernels.  c is huge so the extra pivot never fails.
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fwd_quad_logdet_kernel(const double *__restrict__ L, int N, int Npad,
-                                                              const double *__restrict__ diag64,
-                                                              const double *__restrict__ y, double *__restrict__ z,
-                                                              double *__restrict__ out2)
+__global__ void aug_row_kernel(double *__restrict__ L, int Npad, int N, const double *__restrict__ y)
 {
-    __shared__ double rhs[64];
-    __shared__ double red[256];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    int nb = Npad / 64;
-    double quad = 0.0, logdet = 0.0;
-    for (int jb = 0; jb < nb; jb++) {
-        // s[r] = sum_{k < 64 jb} L[64 jb + r][k] z[k]; wave wv takes rows wv*16 .. +15
-        for (int rr = 0; rr < 16; rr++) {
-            int r = wv * 16 + rr;
-            const double *row = L + (size_t)(jb * 64 + r) * Npad;
-            double sacc = 0.0;
-            for (int k = lane; k < jb * 64; k += 64) sacc += row[k] * z[k];
-            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-            if (lane == 0) {
-                int gi = jb * 64 + r;
-                rhs[r] = ((gi < N) ? y[gi] : 0.0) - sacc;
-            }
-        }
-        __syncthreads();
-        if (t < 64) {
-            const double *Dr = diag64 + (size_t)jb * 4096 + t * 64;
-            double v = 0.0;
-            for (int c = 0; c <= t; c++) v += Dr[c] * rhs[c];
-            int gi = jb * 64 + t;
-            z[gi] = v;
-            if (gi < N) { quad += v * v; logdet -= log(Dr[t]); }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    red[t] = (t < 64) ? quad : 0.0;
-    __syncthreads();
-    if (t == 0) { double s = 0.0; for (int i = 0; i < 64; i++) s += red[i]; out2[0] = s; }
-    __syncthreads();
-    red[t] = (t < 64) ? logdet : 0.0;
-    __syncthreads();
-    if (t == 0) { double s = 0.0; for (int i = 0; i < 64; i++) s += red[i]; out2[1] = s; }
+    int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < N) L[(size_t)N * Npad + k] = y[k];
+    else if (k == N) L[(size_t)N * Npad + N] = 1e300;
 }
 
-int launch_fwd_quad_logdet(const double *L, int N, int Npad, const double *diag64, const double *y,
-                           double *z, double *out2, hipStream_t s)
+__global__ __launch_bounds__(256) void nlml_reduce_kernel(const double *__restrict__ L, int Npad, int N,
+                                                          double *__restrict__ out2)
 {
-    hipLaunchKernelGGL(fwd_quad_logdet_kernel, dim3(1), dim3(256), 0, s, L, N, Npad, diag64, y, z, out2);
+    __shared__ double rq[256], rl[256];
+    const int t = threadIdx.x;
+    double q = 0.0, ld = 0.0;
+    for (int k = t; k < N; k += 256) {
+        double z = L[(size_t)N * Npad + k];
+        q = fma(z, z, q);
+        ld += log(L[(size_t)k * Npad + k]);
+    }
+    rq[t] = q; rl[t] = ld;
+    __syncthreads();
+    if (t == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < 256; i++) { a += rq[i]; b += rl[i]; }
+        out2[0] = a; out2[1] = b;
+    }
+}
+
+int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s)
+{
+    hipLaunchKernelGGL(aug_row_kernel, dim3((N + 256) / 256), dim3(256), 0, s, L, Npad, N, y);
+    return (int)hipGetLastError();
+}
+
+int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(nlml_reduce_kernel, dim3(1), dim3(256), 0, s, L, Npad, N, out2);
     return (int)hipGetLastError();
 }
 
