@@ -23,7 +23,7 @@ from .. import _lib
 
 
 def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, candidates=None, seed=None,
-                   lhc_per_round=None):
+                   lhc_per_round=None, comm=None, index_base=0):
     gallery = []
     if len(GP.X) > 0:
         if useBest:
@@ -76,14 +76,23 @@ def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, ca
             S = candidates
         else:
             S = np.array(lhcSample(bounds, samples, seed=None if seed is None else seed + rnd))
-        r = sweep(hallucGP, S, acq='ei', xi=.4, native=False, exclude=np.array(gallery) if gallery else None,
-                  exclude_radius=.5)
-        if r["best_idx"] >= 0 and r["best_val"] > bestUCB:
-            bestUCB = r["best_val"]
-            if isinstance(S, _lib.DeviceArray):
-                bestX = S.view_rows(r["best_idx"], r["best_idx"] + 1).to_host()[0]
-            else:
-                bestX = np.array(S[r["best_idx"]])
+        excl = np.array(gallery) if gallery else None
+        if comm is not None:
+            # S is this rank's block of the candidate array (rows index_base ...): sharded sweep + one exchange
+            from ..multigpu import sharded_sweep
+            r = sharded_sweep(hallucGP, S, index_base, comm, acq='ei', xi=.4, native=False, exclude=excl,
+                              exclude_radius=.5)
+            if r["best_idx"] >= 0 and r["best_val"] > bestUCB:
+                bestUCB = r["best_val"]
+                bestX = np.array(r["best_x"])
+        else:
+            r = sweep(hallucGP, S, acq='ei', xi=.4, native=False, exclude=excl, exclude_radius=.5)
+            if r["best_idx"] >= 0 and r["best_val"] > bestUCB:
+                bestUCB = r["best_val"]
+                if isinstance(S, _lib.DeviceArray):
+                    bestX = S.view_rows(r["best_idx"], r["best_idx"] + 1).to_host()[0]
+                else:
+                    bestX = np.array(S[r["best_idx"]])
 
         if hallucGP.prior is not None:
             ut = EI(hallucGP, xi=.4)

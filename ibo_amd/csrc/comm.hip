@@ -165,6 +165,27 @@ extern "C" int ibo_comm_argmax(ibo_comm_t *c, double val, int64_t idx, const dou
     return IBO_OK;
 }
 
+// in-place sum all-reduce of a host buffer (staged through HBM): the gather of the sharded
+// marginal-likelihood grid (each rank fills its own theta slots, zeros elsewhere)
+extern "C" int ibo_comm_allreduce_sum(ibo_comm_t *c, double *host_buf, int64_t n)
+{
+    if (!c || !host_buf || n < 1) return IBO_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return cfail(IBO_ERR_HIP, "hipSetDevice failed");
+    if ((size_t)n > c->cap) {
+        if (c->dbuf) (void)hipFree(c->dbuf);
+        if (hipMalloc((void **)&c->dbuf, (size_t)n * sizeof(double)) != hipSuccess) return cfail(IBO_ERR_HIP, "hipMalloc failed");
+        c->cap = (size_t)n;
+    }
+    if (hipMemcpyAsync(c->dbuf, host_buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return cfail(IBO_ERR_HIP, "H2D failed");
+    int e = R.all_reduce(c->dbuf, c->dbuf, (size_t)n, RCCL_FLOAT64, RCCL_SUM, c->comm, c->stream);
+    if (e) return cfail(IBO_ERR_COMM, "ncclAllReduce failed", e);
+    if (hipMemcpyAsync(host_buf, c->dbuf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        return cfail(IBO_ERR_HIP, "D2H failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return cfail(IBO_ERR_HIP, "stream sync failed");
+    return IBO_OK;
+}
+
 extern "C" int ibo_comm_barrier(ibo_comm_t *c)
 {
     double v; int64_t i; int r;

@@ -73,6 +73,12 @@ class TorchArgmax(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return reduce_slots(t.numpy(), self.world_size, len(payload))
 
+    def allreduce_sum(self, buf):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.numpy()
+
 
 class RcclArgmax(object):
     """slot protocol over RCCL/xGMI through libibo_hip (one communicator per process)"""
@@ -98,6 +104,11 @@ class RcclArgmax(object):
         _lib.check(_lib.lib.ibo_comm_argmax(self.h, float(val), int(idx), _lib.dp(payload) if n else None, n,
                                             ctypes.byref(bv), ctypes.byref(bi), _lib.dp(bp), ctypes.byref(br)))
         return bv.value, bi.value, bp[:n], br.value
+
+    def allreduce_sum(self, buf):
+        out = _lib.f64(np.array(buf, dtype=np.float64))
+        _lib.check(_lib.lib.ibo_comm_allreduce_sum(self.h, _lib.dp(out), out.size))
+        return out
 
     def barrier(self):
         _lib.check(_lib.lib.ibo_comm_barrier(self.h))
@@ -152,6 +163,7 @@ def sharded_sweep(model, local_candidates, start, comm, **sweep_kw):
     """sweep this rank's block (rows [start, start+len)) and agree on the global arg-max.
     Returns dict(best_val, best_idx (global), best_x, best_rank, kernel_ms)."""
     from .acquisition import sweep
+    sweep_kw.pop('index_base', None)
     r = sweep(model, local_candidates, index_base=start, **sweep_kw)
     D = local_candidates.shape[1]
     if r["best_idx"] >= 0:
@@ -164,3 +176,35 @@ def sharded_sweep(model, local_candidates, start, comm, **sweep_kw):
         x = np.zeros(D)
     v, i, p, rk = comm.argmax(r["best_val"], r["best_idx"], x)
     return dict(best_val=v, best_idx=i, best_x=p, best_rank=rk, kernel_ms=r["kernel_ms"], local=r)
+
+
+def sharded_nlml_grid(Kernel, thetas, X, Y, comm, noise=1e-3, device=None, local_eval=None):
+    """marginal-likelihood grid with the theta-points cut into contiguous blocks, one per rank
+    (SURVEY 8e): each rank evaluates its block on its GPU, one all-reduce(sum) over a zero-padded
+    buffer gathers all values, every rank returns (values, argmin).  local_eval(thetas_block) ->
+    values replaces the GPU evaluation in the CPU protocol test."""
+    thetas = np.asarray(thetas, dtype=float)
+    T = len(thetas)
+    a, b = shard_bounds(T, comm.world_size, comm.rank)
+    buf = np.zeros(2 * T)
+    if b > a:
+        if local_eval is None:
+            from .gaussianprocess.trainhyper import nlml_values
+            vals = nlml_values([Kernel(t) for t in thetas[a:b]], X, Y, noise, device)
+        else:
+            vals = np.asarray(local_eval(thetas[a:b]), dtype=float)
+        ok = np.isfinite(vals)
+        buf[a:b] = np.where(ok, vals, 0.0)
+        buf[T + a:T + b] = ok.astype(float)           # NaN (not positive definite) cannot ride a sum
+    out = comm.allreduce_sum(buf)
+    vals = np.where(out[T:] > 0.5, out[:T], np.nan)
+    return vals, int(np.nanargmin(vals))
+
+
+def sharded_gallery(GP, bounds, N, local_candidates, start, comm, **kw):
+    """fastUCBGallery with the candidate step sharded: every rank holds the model and runs the
+    (sequential, single-GPU) DIRECT step redundantly, sweeps its own candidate block, and the
+    per-round arg-max travels in the one RCCL exchange together with the winner's coordinates,
+    so all ranks hallucinate the same observation and stay in lock-step."""
+    from .acquisition.gallery import fastUCBGallery
+    return fastUCBGallery(GP, bounds, N, candidates=local_candidates, comm=comm, index_base=start, **kw)

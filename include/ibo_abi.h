@@ -256,6 +256,9 @@ int ibo_comm_destroy(ibo_comm_t *comm);
 int ibo_comm_argmax(ibo_comm_t *comm, double val, int64_t idx,
                     const double *payload, int npayload,
                     double *best_val, int64_t *best_idx, double *best_payload, int *best_rank);
+/* in-place ncclAllReduce(sum) of a host buffer: gathers the sharded NLML grid (each rank fills
+ * its own theta slots of a zero buffer) */
+int ibo_comm_allreduce_sum(ibo_comm_t *comm, double *host_buf, int64_t n);
 int ibo_comm_barrier(ibo_comm_t *comm);
 
 /* ---------------------------------------------------------------- (A) legacy libego symbols */

@@ -431,7 +431,25 @@ def test_rccl_argmax_world_of_one(ibo):
     assert (v, i, r) == (1.25, 123456789012, 0) and p.tolist() == [0.5, 0.25, 0.125]
     v, i, p, r = comm.argmax(float('nan'), -1, [0.0])
     assert i == -1 and r == -1
+    np.testing.assert_array_equal(comm.allreduce_sum([1.5, -2.0, 0.0]), [1.5, -2.0, 0.0])
     comm.barrier()
+    # the sharded gallery and NLML grid run through the same exchange (one rank = the whole array)
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.acquisition.gallery import fastUCBGallery
+    from ibo_amd.multigpu import sharded_gallery, sharded_nlml_grid
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid
+    X, Y = synth(51, 80, 3)
+    GP = GaussianProcess(GaussianKernel_ard([.3] * 3), X, Y)
+    cand = np.random.RandomState(52).rand(3000, 3)
+    b = [[0., 1.]] * 3
+    g1 = np.array(fastUCBGallery(GP, b, 4, candidates=cand))
+    g2 = np.array(sharded_gallery(GP, b, 4, cand, 0, comm))
+    np.testing.assert_array_equal(g1, g2)
+    thetas = np.random.RandomState(53).rand(5, 3) + .2
+    v1, a1 = nlml_grid(GaussianKernel_ard, thetas, X, Y)
+    v2, a2 = sharded_nlml_grid(GaussianKernel_ard, thetas, X, Y, comm)
+    np.testing.assert_array_equal(v1, v2); assert a1 == a2
     comm.close()
 
 

@@ -88,3 +88,37 @@ def test_unique_id_file_rendezvous():
     assert all(uid == bytes(range(128)) for _, uid, _ in res)
     assert len(set(path for _, _, path in res)) == 1
     os.unlink(res[0][2])
+
+
+def _nlml_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ibo_amd.multigpu import TorchArgmax, sharded_nlml_grid
+    comm = TorchArgmax()
+    thetas = np.random.RandomState(9).rand(11, 3) + .1
+    f = lambda th: np.where(th[:, 0] > .95, np.nan, np.sum((th - .5) ** 2, axis=1))     # NaN = "not PD" slots
+    vals, am = sharded_nlml_grid(None, thetas, None, None, comm, local_eval=f)
+    q.put((rank, vals.tolist(), am))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_nlml_grid_gather_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nlml_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (v, a)) for r, v, a in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    thetas = np.random.RandomState(9).rand(11, 3) + .1
+    ref = np.where(thetas[:, 0] > .95, np.nan, np.sum((thetas - .5) ** 2, axis=1))
+    for r in range(world):
+        np.testing.assert_array_equal(np.array(res[r][0]), ref)
+        assert res[r][1] == int(np.nanargmin(ref))
