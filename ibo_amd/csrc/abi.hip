@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -93,6 +94,7 @@ struct ibo_gp {
     float fit_ms = 0.f, sweep_ms = 0.f;
     const char *sweep_kernel = "";
     std::vector<double> Yhost;
+    double *pin = nullptr; size_t pin_cap = 0;      // pinned host staging for small host-in/host-out batches
     DevBuf<double> Xp, Xs, ak, Y, R, A, L, W, T, Wp, diag64, alphaY, alpha1, tmp, cand, outs, excl, qpart, mupart, partv, res_v;
     DevBuf<int64_t> parti, res_i;
     DevBuf<int> info;
@@ -204,6 +206,7 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release();
+    if (g->pin) (void)hipHostFree(g->pin);
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
     (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
     (void)hipEventDestroy(g->fit0); (void)hipEventDestroy(g->fit1);
@@ -578,6 +581,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_mfma_kernel";
     }
+    if (!best_val && !best_idx) return IBO_OK;        // internal callers that only want the per-point outputs
     double hv; int64_t hi;
     HIP_TRY(hipMemcpyAsync(&hv, g->res_v.p, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&hi, g->res_i.p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -614,15 +618,34 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
 {
     IBO_TRY(g->cand.ensure((size_t)M * g->D));
     IBO_TRY(g->outs.ensure(3 * (size_t)M));
+    // pinned staging (input points + up to 3 output arrays): pageable copies cost ~15 us each and
+    // DIRECT issues ~100 small batches per maximisation
+    size_t need = (size_t)M * (g->D + 3);
+    if (need > g->pin_cap) {
+        if (g->pin) (void)hipHostFree(g->pin);
+        g->pin = nullptr; g->pin_cap = 0;
+        size_t cap = need < 4096 ? 4096 : need * 2;
+        HIP_TRY(hipHostMalloc((void **)&g->pin, cap * sizeof(double), hipHostMallocDefault));
+        g->pin_cap = cap;
+    }
     hipStream_t s = g->stream;
-    HIP_TRY(hipMemcpyAsync(g->cand.p, Q_host, sizeof(double) * M * g->D, hipMemcpyHostToDevice, s));
-    double *dmu = g->outs.p, *ds2 = g->outs.p + M, *dacq = g->outs.p + 2 * M;
-    IBO_TRY(run_sweep(g, M, g->cand.p, acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0,
-                      mu_host ? dmu : nullptr, s2_host ? ds2 : nullptr, acq_host ? dacq : nullptr, nullptr, nullptr));
-    if (mu_host) HIP_TRY(hipMemcpyAsync(mu_host, dmu, sizeof(double) * M, hipMemcpyDeviceToHost, s));
-    if (s2_host) HIP_TRY(hipMemcpyAsync(s2_host, ds2, sizeof(double) * M, hipMemcpyDeviceToHost, s));
-    if (acq_host) HIP_TRY(hipMemcpyAsync(acq_host, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s));
+    double *pin_in = g->pin, *pin_out = g->pin + (size_t)M * g->D;
+    memcpy(pin_in, Q_host, sizeof(double) * M * g->D);
+    HIP_TRY(hipMemcpyAsync(g->cand.p, pin_in, sizeof(double) * M * g->D, hipMemcpyHostToDevice, s));
+    // outputs are contiguous on the device in the order (mu, s2, acq) restricted to the wanted ones
+    int nout = 0;
+    double *dmu = nullptr, *ds2 = nullptr, *dacq = nullptr;
+    if (mu_host) dmu = g->outs.p + (size_t)M * nout++;
+    if (s2_host) ds2 = g->outs.p + (size_t)M * nout++;
+    if (acq_host) dacq = g->outs.p + (size_t)M * nout++;
+    IBO_TRY(run_sweep(g, M, g->cand.p, acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
+                      nullptr, nullptr));
+    HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    nout = 0;
+    if (mu_host) memcpy(mu_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
+    if (s2_host) memcpy(s2_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
+    if (acq_host) memcpy(acq_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
     return IBO_OK;
 }
 
@@ -642,9 +665,13 @@ static int direct_on_gp(ibo_gp *g, int D, const double *lb, const double *ub, in
                         double *opt, double *optx, int64_t *nsamples)
 {
     if (D != g->D) return fail(IBO_ERR_ARG, "bounds have %d dimensions, model has %d", D, g->D);
-    std::vector<double> neg;
+    const bool dbg = getenv("IBO_DEBUG") != nullptr;
+    double t_eval = 0.0; int n_batches = 0; int64_t n_pts = 0;
     ibo::batch_eval_t ev = [&](const double *pts, int n, double *vals) -> int {
+        struct timespec a0, a1;
+        if (dbg) clock_gettime(CLOCK_MONOTONIC, &a0);
         int rc = eval_host_points(g, n, pts, acq, parm, erf_mode, clamp_lo, nullptr, nullptr, vals);
+        if (dbg) { clock_gettime(CLOCK_MONOTONIC, &a1); t_eval += (a1.tv_sec - a0.tv_sec) * 1e3 + (a1.tv_nsec - a0.tv_nsec) * 1e-6; n_batches++; n_pts += n; }
         if (rc) return rc;
         for (int i = 0; i < n; i++) vals[i] = -vals[i];     // DIRECT minimises the negated acquisition
         return 0;
@@ -652,7 +679,13 @@ static int direct_on_gp(ibo_gp *g, int D, const double *lb, const double *ub, in
     ibo::DirectOptions o;
     o.maxiter = maxiter; o.maxtime = maxtime; o.maxsample = maxsample; o.compat = compat != 0;
     o.per_rectangle = false;
+    struct timespec w0, w1;
+    clock_gettime(CLOCK_MONOTONIC, &w0);
     ibo::DirectResult r = ibo::direct_minimize(ev, D, lb, ub, o);
+    clock_gettime(CLOCK_MONOTONIC, &w1);
+    if (dbg) fprintf(stderr, "[libibo_hip] DIRECT: %d iterations, %lld samples, %d batches (%lld points): %.2f ms total, %.2f ms in GPU evaluation\n",
+                     r.iterations, (long long)r.nsamples, n_batches, (long long)n_pts,
+                     (w1.tv_sec - w0.tv_sec) * 1e3 + (w1.tv_nsec - w0.tv_nsec) * 1e-6, t_eval);
     if (r.status) return r.status;
     if (opt) *opt = -r.fmin;
     if (optx) for (int i = 0; i < D; i++) optx[i] = r.xmin[i];
