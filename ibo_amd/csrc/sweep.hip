@@ -78,7 +78,10 @@ __device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
 // cycles per SIMD but a single wave only reaches ~46 % of that (tools/mfma_f64_peak),
 // so the pipe needs >= 2 waves per SIMD in their MFMA phase at any time:
 // <16, 2> (64 accumulator VGPRs, 4 waves/SIMD) is the default, <8, 4> the first version.
-// (s_setprio around the MFMA block was tried: -9 %, it pins the compiler's schedule.)
+// (s_setprio around the MFMA block was tried: -9 %, it pins the compiler's schedule.  A persistent
+// grid-stride tile loop saves the ~9 us dispatch of each 16-wave workgroup (+2.4 % at N=1024, +12 %
+// at N=256) but wrapping the body in a loop, inline or as a noinline callee, costs hipcc 19-35 % in
+// register allocation / scheduling of the body, so the one-workgroup-per-tile form stays.)
 // DOT: squared-exponential k* as exp(a_k + b_c + x~.c~) (D+1 FMAs) instead of the
 // difference form (2D) -- fp64 VALU shares the MFMA pipe, instruction count is time.
 // CBW: candidate-blocks per wave (4: a wave spans the whole tile; 2: waves come in pairs
@@ -454,6 +457,11 @@ int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
 {
     int nrc = a.Npad / 64;
     dim3 grid(nrc, (unsigned)a.M);
+    if (sizeof(double) * a.Npad > 64 * 1024) {     // up to 160 KiB of LDS per workgroup on gfx950
+        hipError_t e = hipFuncSetAttribute((const void *)sweep_gemv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(double) * a.Npad));
+        if (e != hipSuccess) return (int)e;
+    }
     if (e0) (void)hipEventRecord(e0, s);
     hipLaunchKernelGGL(sweep_gemv_kernel, grid, dim3(256), sizeof(double) * a.Npad, s, a);
     if (e1) (void)hipEventRecord(e1, s);
