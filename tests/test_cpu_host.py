@@ -168,3 +168,24 @@ def test_shard_bounds_and_slot_reduce():
     assert i == -1 and r == -1
     v, i, p, r = reduce_slots(fill_slot(1, 0, -3.0, 0, []), 1, 0)
     assert (v, i, r) == (-3.0, 0, 0)
+
+
+def test_install_as_ego_aliases_every_module():
+    import importlib
+    import ibo_amd
+    ibo_amd.install_as_ego()
+    for name in ("ego", "ego.gaussianprocess", "ego.gaussianprocess.kernel", "ego.gaussianprocess.prior",
+                 "ego.gaussianprocess.trainhyper", "ego.acquisition", "ego.acquisition.gallery", "ego.utils.optimize",
+                 "ego.utils.latinhypercube"):
+        assert importlib.import_module(name) is importlib.import_module(name.replace("ego", "ibo_amd", 1))
+    from ego.acquisition import maximizeEI, maximizePI, maximizeUCB, EI, PI, UCB      # noqa: F401
+    from ego.acquisition.gallery import fastUCBGallery                                 # noqa: F401
+    from ego.gaussianprocess import GaussianProcess, PrefGaussianProcess, CDF, PDF     # noqa: F401
+    from ego.utils.optimize import direct, cdirect                                     # noqa: F401
+    import inspect
+    sig = inspect.signature(maximizeEI)
+    assert [p for p in sig.parameters][:6] == ["model", "bounds", "useCDIRECT", "xi", "maxiter", "maxtime"]
+    assert sig.parameters["maxsample"].default == 10000 and sig.parameters["xi"].default == 0.01
+    assert inspect.signature(fastUCBGallery).parameters["samples"].default == 300
+    sig = inspect.signature(GaussianProcess.__init__)
+    assert sig.parameters["noise"].default == .1 and sig.parameters["gnoise"].default == 1e-4

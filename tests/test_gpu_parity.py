@@ -545,3 +545,57 @@ def test_c5_nlml_full_size(ibo, oracle):
     close(vals[1], ref, rtol=1e-9)
     assert np.all(np.isfinite(vals)) and am == int(np.argmin(vals))
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[1:2], X, Y, noise=1e-3)[0], vals[1:2])   # deterministic
+
+
+def test_add_observation_point_augmented_variance(ibo, oracle):
+    """PrefGaussianProcess.addObservationPoint (ego/gaussianprocess/__init__.py:214-223,502-519): the mean keeps
+    using L = chol(R + C^-1), the variance switches to the factor of the augmented matrix"""
+    from ibo_amd.gaussianprocess import PrefGaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    g = load_golden("g7_prefs")
+    p = "p8/"
+    prefs = [(v, u, d) for v, u, d in zip(g[p + "pref_v"], g[p + "pref_u"], g[p + "pref_d"])]
+    GP = PrefGaussianProcess(GaussianKernel_ard(g[p + "hyper"]), prefs)
+    probe = g[p + "probe"][:10]
+    mu0, s20 = GP.posteriors(probe)
+    newx = np.array([[.3, .4, .5, .6, .7, .8], [.9, .1, .2, .8, .3, .5]])
+    GP.addObservationPoint(newx[0]); GP.addObservationPoint(newx[1])
+    mu1, s21 = GP.posteriors(probe)
+    # reference computation in NumPy from the model's own public matrices
+    ok = oracle.Kern("ard", g[p + "hyper"])
+    augX = np.vstack([GP.X, newx])
+    n, m = len(augX), len(GP.X)
+    augR = np.array([[ok.cov(a, b) for b in augX] for a in augX]); np.fill_diagonal(augR, 1 + GP.noise)
+    invC = np.zeros((n, n)); invC[:m, :m] = np.linalg.inv(GP.C)
+    augL = np.linalg.cholesky(augR + invC)
+    r = np.array([[ok.cov(a, q) for q in probe] for a in augX])
+    s2_ref = np.clip((1 + GP.noise) - np.sum(np.linalg.solve(augL, r) ** 2, axis=0), 10e-8, 10)
+    close(mu1, mu0, rtol=1e-12, atol=1e-14)
+    close(s21, s2_ref); close(GP.augL, augL, atol=1e-9); close(GP.augR, augR, rtol=1e-12)
+    assert np.all(s21 <= s20 + 1e-12)                    # observing more can only shrink the variance
+    assert len(GP.augX) == m + 2
+
+
+def test_sv_ard_kernel_and_ego_alias(ibo, oracle):
+    """signal-variance ARD kernel through the device path, imported under the reference's package name"""
+    import ibo_amd
+    ibo_amd.install_as_ego()
+    from ego.gaussianprocess import GaussianProcess
+    from ego.gaussianprocess.kernel import SVGaussianKernel_ard
+    from ego.acquisition import maximizeEI, EI
+    from ego.utils.latinhypercube import lhcSample
+    hyp = [.4, .5, .6, 1.03]
+    b = [[0., 1.]] * 3
+    X = np.array(lhcSample(b, 30, seed=3)); Y = np.sin(4 * X.sum(1))
+    GP = GaussianProcess(SVGaussianKernel_ard(hyp), X, Y, noise=.1)
+    ogp = oracle.GP(oracle.Kern("svard", hyp), X, Y, noise=.1)
+    close(GP.R, ogp.R, rtol=1e-12)
+    probe = np.array(lhcSample(b, 20, seed=4))
+    mu, s2 = GP.posteriors(probe); o_mu, o_s2 = ogp.posteriors(probe)
+    close(mu, o_mu, atol=1e-10); close(s2, o_s2)
+    # maximizeEI follows libego: k* WITHOUT the magnitude (cpp/optimizeGP.cpp:303-310) on R built with it
+    opt, optx = maximizeEI(GP, b, maxiter=10)
+    o, ox, _ = oracle.acqmax_native(ogp, b, oracle.ACQ_EI, .01, maxiter=10)
+    close(opt, o, atol=ACQ_ATOL); close(optx, ox, rtol=1e-9, atol=1e-12)
+    close(EI(GP).f(probe[0]), oracle.acq_value(oracle.ACQ_EI, oracle.ERF_NR, o_mu[0], np.sqrt(o_s2[0]), Y.max(), .01)[0],
+          atol=ACQ_ATOL)
