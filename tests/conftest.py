@@ -10,8 +10,22 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_built():
+    """The .so files are git-ignored build products: build them when a fresh checkout runs the tests
+    (hipcc cross-compiles gfx950 without a GPU; gcc builds the CPU checker).  Building is not using."""
+    import subprocess
+    lib = os.path.join(ROOT, "ibo_amd", "libibo_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "ibo_amd", "csrc"), "-j4"])
+    orc = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(orc) or (os.path.isdir("/root/reference/cpp") and
+                                   not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libego.so"))):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_built()
 
 
 def load_golden(name):
