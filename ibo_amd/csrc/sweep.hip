@@ -81,7 +81,10 @@ __device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
 // (s_setprio around the MFMA block was tried: -9 %, it pins the compiler's schedule.  A persistent
 // grid-stride tile loop saves the ~9 us dispatch of each 16-wave workgroup (+2.4 % at N=1024, +12 %
 // at N=256) but wrapping the body in a loop, inline or as a noinline callee, costs hipcc 19-35 % in
-// register allocation / scheduling of the body, so the one-workgroup-per-tile form stays.)
+// register allocation / scheduling of the body, so the one-workgroup-per-tile form stays.  Two 8-wave
+// workgroups of 32 candidates per CU -- same work per wave, the idea being that one covers the other's
+// dispatch/epilogue -- measured 66 % at N=1024 and no better at N=256: two k* rows per wave instruction
+// need per-lane observation loads and the 128-VGPR budget then spills 60-200 registers.)
 // DOT: squared-exponential k* as exp(a_k + b_c + x~.c~) (D+1 FMAs) instead of the
 // difference form (2D) -- fp64 VALU shares the MFMA pipe, instruction count is time.
 // CBW: candidate-blocks per wave (4: a wave spans the whole tile; 2: waves come in pairs
