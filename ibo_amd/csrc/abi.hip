@@ -578,8 +578,21 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         KERNEL_TRY(launch_sweep_gemv(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_gemv_kernel";
     } else {
+#ifdef IBO_STAMPS
+        IBO_TRY(g->mupart.ensure((size_t)ntiles * 8 + 16));
+        a.mupart = g->mupart.p;
+#endif
         KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_mfma_kernel";
+#ifdef IBO_STAMPS
+        if (getenv("IBO_STAMP_FILE")) {
+            std::vector<unsigned long long> h((size_t)ntiles * 8);
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(h.data(), g->mupart.p, h.size() * 8, hipMemcpyDeviceToHost));
+            FILE *f = fopen(getenv("IBO_STAMP_FILE"), "wb");
+            if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+#endif
     }
     if (!best_val && !best_idx) return IBO_OK;        // internal callers that only want the per-point outputs
     double hv; int64_t hi;

@@ -112,6 +112,13 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tile0 = (int64_t)blockIdx.x * TC;
     const int D = a.kp.D;
+#ifdef IBO_STAMPS   // diagnostic build (tools/stamp_sweep.py): where does a tile's time go?
+    unsigned long long st[8];
+#define STAMP(i) st[i] = __builtin_amdgcn_s_memrealtime()
+    STAMP(0);
+#else
+#define STAMP(i)
+#endif
 
     for (int e = tid; e < TC * DP; e += NW * 64) {
         int d = e / TC, c = e - d * TC;
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         }
         bc = fma(-0.5, n2, a.log_sf2);
     }
+    STAMP(1);
 
     const int Npad = a.Npad;                        // multiple of 64 >= KCH: stages never run past it
     const int nk8 = Npad >> 3;
@@ -178,7 +186,8 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         }
     };
 
-    auto run_panel = [&](int p, auto last_tag) {
+    auto run_panel = [&](int p, auto last_tag, auto partial_tag) {
+        constexpr bool PARTIAL = decltype(partial_tag)::value;
         const int kend = min((p + 1) * PANEL, Npad);
         const int nchunk = kend / KCH;
         const int nfull = (p * PANEL) / KCH;        // stages strictly left of the diagonal block
@@ -219,7 +228,8 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
                 }
                 bool act[RBW];
 #pragma unroll
-                for (int i = 0; i < RBW; i++) act[i] = !DIAG || (8 * (j0 + jj) <= 16 * g[i] + 15);
+                for (int i = 0; i < RBW; i++)
+                    act[i] = !DIAG || ((!PARTIAL || keep[i]) && 8 * (j0 + jj) <= 16 * g[i] + 15);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     double bf[CBW];
@@ -242,8 +252,12 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
             }
             __syncthreads();
         };
-        for (int t = 0; t < nfull; t++) stage(t, std::false_type{});
-        for (int t = nfull; t < nchunk; t++) stage(t, std::true_type{});
+        // a PARTIAL last panel (N not a multiple of the panel) has waves whose row-blocks do not
+        // exist: it runs every stage through the predicated form so those MFMAs are skipped
+        // (a separate instantiation, so the full-panel code is not perturbed)
+        const int nplain = PARTIAL ? 0 : nfull;
+        for (int t = 0; t < nplain; t++) stage(t, std::false_type{});
+        for (int t = nplain; t < nchunk; t++) stage(t, std::true_type{});
         // |V|^2 down the rows of this panel: acc[i][cb][r] is row (lane>>4)+4r, column lane&15
 #pragma unroll
         for (int cb = 0; cb < CBW; cb++) {
@@ -261,13 +275,20 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         }
     };
 
+    const bool partial_last = (Npad % PANEL) != 0;
     if (SPLIT) {
         const int p = blockIdx.y;
-        if (p == npanel - 1) run_panel(p, std::true_type{});
-        else run_panel(p, std::false_type{});
+        if (p == npanel - 1) {
+            if (partial_last) run_panel(p, std::true_type{}, std::true_type{});
+            else run_panel(p, std::true_type{}, std::false_type{});
+        } else run_panel(p, std::false_type{}, std::false_type{});
     } else {
-        for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
-        run_panel(npanel - 1, std::true_type{});    // the last panel sees every k: it also forms the mean
+        for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{}, std::false_type{});
+        STAMP(2);
+        // the last panel sees every k: it also forms the mean
+        if (partial_last) run_panel(npanel - 1, std::true_type{}, std::true_type{});
+        else run_panel(npanel - 1, std::true_type{}, std::false_type{});
+        STAMP(3);
     }
 
     // every wave contributes to CBW candidate blocks only; the others get zeros
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
     lds_m[0][wave][lane] = muY;
     lds_m[1][wave][lane] = mu1;
     __syncthreads();
+    STAMP(4);
     if (wave == 0) {
         double q = 0.0, my = 0.0, m1 = 0.0;
 #pragma unroll
@@ -304,6 +326,16 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
         wave_argmax(val, idx);
         if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+#ifdef IBO_STAMPS
+        STAMP(5);
+        if (lane == 0 && !SPLIT && a.mupart) {
+            unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_ID
+            unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    // XCC_ID
+            unsigned long long *d = (unsigned long long *)a.mupart + (size_t)blockIdx.x * 8;
+            for (int i = 0; i < 6; i++) d[i] = st[i];
+            d[6] = hw; d[7] = xcc;
+        }
+#endif
     }
 }
 
