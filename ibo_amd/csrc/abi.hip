@@ -579,14 +579,14 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         g->sweep_kernel = "sweep_gemv_kernel";
     } else {
 #ifdef IBO_STAMPS
-        IBO_TRY(g->mupart.ensure((size_t)ntiles * 8 + 16));
+        IBO_TRY(g->mupart.ensure((size_t)ntiles * 16 + 16));
         a.mupart = g->mupart.p;
 #endif
         KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_mfma_kernel";
 #ifdef IBO_STAMPS
         if (getenv("IBO_STAMP_FILE")) {
-            std::vector<unsigned long long> h((size_t)ntiles * 8);
+            std::vector<unsigned long long> h((size_t)ntiles * 16);
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(h.data(), g->mupart.p, h.size() * 8, hipMemcpyDeviceToHost));
             FILE *f = fopen(getenv("IBO_STAMP_FILE"), "wb");

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
     const int64_t tile0 = (int64_t)blockIdx.x * TC;
     const int D = a.kp.D;
 #ifdef IBO_STAMPS   // diagnostic build (tools/stamp_sweep.py): where does a tile's time go?
+    unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0}; unsigned nst[2] = {0, 0};   // shader cycles: k* gen / MFMA / barrier, plain and diagonal stages
     unsigned long long st[8];
 #define STAMP(i) st[i] = __builtin_amdgcn_s_memrealtime()
     STAMP(0);
@@ -213,12 +214,18 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         // tiles are skipped (row-block g has non-zeros in columns <= 16 g + 15).
         auto stage = [&](int t, auto diag_tag) {
             constexpr bool DIAG = decltype(diag_tag)::value;
+#ifdef IBO_STAMPS
+            const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
             const int b = t & 1;
             const int j0 = (t * KCH) >> 3;
             double2 af[RBW];
 #pragma unroll
             for (int i = 0; i < RBW; i++) af[i] = wrow[i][(size_t)j0 * 64];
             if (t + 1 < nchunk) gen((t + 1) * KCH, b ^ 1, last_tag);
+#ifdef IBO_STAMPS
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
             for (int jj = 0; jj < KCH / 8; jj++) {
                 double2 afn[RBW];
@@ -250,7 +257,15 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
                     for (int i = 0; i < RBW; i++) af[i] = afn[i];
                 }
             }
+#ifdef IBO_STAMPS
+            const unsigned long long c2 = __builtin_amdgcn_s_memtime();
             __syncthreads();
+            const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+            cyc[DIAG ? 3 : 0] += c1 - c0; cyc[DIAG ? 4 : 1] += c2 - c1; cyc[DIAG ? 5 : 2] += c3 - c2;
+            nst[DIAG ? 1 : 0] += 1;
+#else
+            __syncthreads();
+#endif
         };
         // a PARTIAL last panel (N not a multiple of the panel) has waves whose row-blocks do not
         // exist: it runs every stage through the predicated form so those MFMAs are skipped
@@ -331,9 +346,11 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         if (lane == 0 && !SPLIT && a.mupart) {
             unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_ID
             unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    // XCC_ID
-            unsigned long long *d = (unsigned long long *)a.mupart + (size_t)blockIdx.x * 8;
+            unsigned long long *d = (unsigned long long *)a.mupart + (size_t)blockIdx.x * 16;
             for (int i = 0; i < 6; i++) d[i] = st[i];
             d[6] = hw; d[7] = xcc;
+            for (int i = 0; i < 6; i++) d[8 + i] = cyc[i];
+            d[14] = nst[0]; d[15] = nst[1];
         }
 #endif
     }

@@ -17,7 +17,7 @@ GP = GaussianProcess(GaussianKernel_ard([.3] * D), X, Y)
 cand = DeviceArray.from_host(np.random.RandomState(102).rand(M, D))
 for _ in range(3):
     r = sweep(GP, cand)
-st = np.fromfile(os.environ["IBO_STAMP_FILE"], dtype=np.uint64).reshape(-1, 8)
+st = np.fromfile(os.environ["IBO_STAMP_FILE"], dtype=np.uint64).reshape(-1, 16)
 t = st[:, :6].astype(np.int64)
 us = 0.01
 names = ["candidate load + setup", "panels before the last", "last panel", "final reduce + barrier", "epilogue (wave 0)"]
@@ -37,3 +37,9 @@ gaps = np.array(gaps)
 print("   distinct CU ids %d; gap exit->next entry on the same CU: median %.2f us, mean %.2f us" % (len(np.unique(cu)), np.median(gaps), gaps.mean()))
 span = (t[:, 5].max() - t[:, 0].min()) * us
 print("   first entry -> last exit: %.1f us; sum(tile)/256 CUs = %.1f us" % (span, (t[:, 5] - t[:, 0]).sum() * us / 256))
+cy = st[:, 8:14].astype(np.float64); ns = st[:, 14:16].astype(np.float64)
+for nm, o, k in (("plain stages   ", 0, 0), ("diagonal stages", 3, 1)):
+    n = np.maximum(ns[:, k], 1)
+    print("   wave 0, %s: %5.1f per tile; shader cycles per stage: k* gen %7.0f  MFMA loop %7.0f  barrier wait %7.0f" %
+          (nm, np.median(ns[:, k]), np.median(cy[:, o] / n), np.median(cy[:, o + 1] / n), np.median(cy[:, o + 2] / n)))
+print("   (one wave issues 128 MFMAs per plain stage: 4 waves/SIMD x 128 x 64 cycles = 32768 cycles if the pipe never idles)")
