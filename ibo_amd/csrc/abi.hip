@@ -529,6 +529,39 @@ extern "C" int ibo_spd_solve(int device, int N, const double *A_host, int nrhs, 
     return rc;
 }
 
+// inverse of a symmetric positive-definite matrix (N x N host in / out): Cholesky, L^-1, W^T W.
+// The preference GP needs C^-1 for L = chol(R + C^-1) (ego/gaussianprocess/__init__.py:488).
+extern "C" int ibo_spd_inverse(int device, int N, const double *A_host, double *Ainv_host, int *info)
+{
+    if (!A_host || !Ainv_host || N < 1) return fail(IBO_ERR_ARG, "bad argument");
+    IBO_TRY(use_device(device));
+    const int Np = round_up(N, 64);
+    const size_t nn = (size_t)Np * Np;
+    DevBuf<double> dA, dL, dW, dT, d64;
+    DevBuf<int> dinfo;
+    IBO_TRY(dA.ensure(nn)); IBO_TRY(dL.ensure(nn)); IBO_TRY(dW.ensure(nn)); IBO_TRY(dT.ensure(nn));
+    IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096)); IBO_TRY(dinfo.ensure(1));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipMemcpy(dA.p, A_host, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice));
+    KERNEL_TRY(launch_pad_copy(dA.p, N, N, dL.p, Np, 1.0, s));
+    KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
+    int h = 0;
+    HIP_TRY(hipMemcpy(&h, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) *info = h;
+    int rc = IBO_OK;
+    if (h != 0) rc = fail(IBO_ERR_NOT_PD, "matrix is not positive definite (pivot %d)", h);
+    else {
+        KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
+        KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
+        KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));      // zero the pad rows (dT reused as scratch)
+        KERNEL_TRY(launch_wtw(dW.p, dT.p, dA.p, Np, s));
+        HIP_TRY(hipMemcpy2D(Ainv_host, sizeof(double) * N, dA.p, sizeof(double) * Np, sizeof(double) * N, N,
+                            hipMemcpyDeviceToHost));
+    }
+    dA.release(); dL.release(); dW.release(); dT.release(); d64.release(); dinfo.release();
+    return rc;
+}
+
 // ------------------------------------------------------------------------ sweep
 static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
                      double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,

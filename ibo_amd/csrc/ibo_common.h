@@ -185,6 +185,8 @@ int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2
                  double *alpha1, hipStream_t s);
 // Xs = Xp * sqrt(w), ak = -|Xs_k|^2/2; maxnorm2 (device double) receives max_k |Xs_k|^2
 int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double *Xs, double *ak, hipStream_t s);
+// C = W^T W (Wt: scratch for the transpose), all Npad x Npad
+int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s);
 int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s);
 int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);

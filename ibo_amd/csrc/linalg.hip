@@ -429,6 +429,53 @@ int launch_trinv(const double *L, int Npad, const double *diag64, double *W, dou
 }
 
 // ------------------------------------------------------------------------
+// A^-1 = W^T W for A = L L^T (W = L^-1 lower triangular): transpose, then one tile GEMM
+//   Ainv[i][j] = sum_{k >= max(i,j)} W[k][i] W[k][j]
+// ------------------------------------------------------------------------
+__global__ void transpose_kernel(const double *__restrict__ A, double *__restrict__ At, int Npad)
+{
+    __shared__ double tile[64][65];
+    int bx = blockIdx.x * 64, by = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        int r = e >> 6, c = e & 63;
+        tile[r][c] = A[(size_t)(by + r) * Npad + bx + c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        int r = e >> 6, c = e & 63;
+        At[(size_t)(bx + r) * Npad + by + c] = tile[c][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W,
+                                                  double *__restrict__ C, int Npad)
+{
+    __shared__ double As[64 * AS_LD];
+    __shared__ double Bs[16 * BS_LD];
+    TILE_IDS;
+    int ti = blockIdx.y, tj = blockIdx.x;
+    const double *A = Wt + (size_t)ti * 64 * Npad;              // rows i of W^T, all k
+    const double *B = W + (size_t)tj * 64;                      // columns j of W
+    d4_t acc[2][2] = {};
+    gemm_tile_64<false>(A, Npad, B, Npad, max(ti, tj) * 64, Npad, acc, As, Bs);
+    double *Ct = C + (size_t)ti * 64 * Npad + (size_t)tj * 64;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) Ct[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
+}
+
+int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s)
+{
+    dim3 g(Npad / 64, Npad / 64);
+    hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, s, W, Wt, Npad);
+    hipLaunchKernelGGL(wtw_kernel, g, dim3(256), 0, s, Wt, W, C, Npad);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
 // pack W into MFMA A-fragment order for the sweep:
 //   Wp[((g*nk8 + j)*64 + lane)*2 + h] = W[16g + (lane&15)][8j + 4h + (lane>>4)]
 // so that one 16-byte load per lane yields the A operands of two consecutive

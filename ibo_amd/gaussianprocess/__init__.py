@@ -380,6 +380,13 @@ class PrefGaussianProcess(GaussianProcess):
                     Y[r] = Y[c] + .1
         self._set_map(Y, prefinds, plain_fitted=True)
 
+    def _inv_spd(self, A):
+        """inverse of the (symmetric positive-definite) C matrix on the GPU"""
+        A = _lib.f64(A)
+        out = np.empty_like(A)
+        _lib.check(_lib.lib.ibo_spd_inverse(self._dev.device, len(A), _lib.dp(A), _lib.dp(out), None))
+        return out
+
     def _set_map(self, Y, prefinds, plain_fitted=False):
         """everything downstream of the MAP (:459-498): C matrix, L = chol(R + C^-1).
         The C-matrix loop reads mu with L = chol(R) (:476), so the device must hold the
@@ -403,7 +410,7 @@ class PrefGaussianProcess(GaussianProcess):
         R = self.R.copy()
         for i in range(11):
             try:
-                self._fit_device(A=R + np.linalg.inv(self.C))
+                self._fit_device(A=R + self._inv_spd(self.C))
                 break
             except NotPositiveDefinite:
                 print('[addPreferences] GP.C matrix is ill-conditioned, adding regularizer delta = %d' % (i + 1))
@@ -427,7 +434,7 @@ class PrefGaussianProcess(GaussianProcess):
         self.augR = K
         invC = np.zeros_like(K)
         m = self.C.shape[0]
-        invC[:m, :m] = np.linalg.inv(self.C)
+        invC[:m, :m] = self._inv_spd(self.C)
         self.augX = augX
         if self._augdev is None:
             self._augdev = _DeviceGP(self._dev.device)

@@ -162,6 +162,10 @@ int ibo_cov_matrix(int device, int ktype, int D, const double *hyper_host, int n
 int ibo_spd_solve(int device, int N, const double *A_host, int nrhs, const double *B_host,
                   double *X_host, int *info);
 
+/* A^-1 of a symmetric positive-definite A (N x N, host in / host out) = W^T W with W = chol(A)^-1.
+ * Replaces linalg.inv(self.C) of the preference GP (ego/gaussianprocess/__init__.py:488,514). */
+int ibo_spd_inverse(int device, int N, const double *A_host, double *Ainv_host, int *info);
+
 /* ---------------------------------------------------------------- posterior / sweep */
 /*
  * Batched posterior: replaces GaussianProcess.posterior / posteriors / mu
