@@ -187,18 +187,24 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         }
     };
 
+    // Panel p covers rows [row0, row1) and needs k in [0, row1).  When Npad is not a multiple of
+    // the panel, the short panel comes FIRST (rows [0, rem)): there it only costs its own few
+    // stages, whereas as the last panel it would regenerate every k* row for a handful of rows.
+    const int rem = Npad % PANEL;
     auto run_panel = [&](int p, auto last_tag, auto partial_tag) {
         constexpr bool PARTIAL = decltype(partial_tag)::value;
-        const int kend = min((p + 1) * PANEL, Npad);
+        const int row0 = (rem == 0) ? p * PANEL : (p == 0 ? 0 : rem + (p - 1) * PANEL);
+        const int row1 = (rem == 0) ? row0 + PANEL : (p == 0 ? rem : row0 + PANEL);
+        const int kend = row1;
         const int nchunk = kend / KCH;
-        const int nfull = (p * PANEL) / KCH;        // stages strictly left of the diagonal block
+        const int nfull = row0 / KCH;               // stages strictly left of the diagonal block
         int g[RBW];
         bool keep[RBW];
         const double2 *wrow[RBW];
 #pragma unroll
         for (int i = 0; i < RBW; i++) {
-            g[i] = p * (PANEL / 16) + rg + RG * i;
-            keep[i] = g[i] < nRB;                   // row-block exists (last panel may be partial)
+            g[i] = (row0 >> 4) + rg + RG * i;
+            keep[i] = 16 * g[i] < row1;             // row-block exists (the short panel has fewer)
             wrow[i] = Wp2 + ((size_t)min(g[i], nRB - 1) * nk8) * 64 + lane;
         }
         d4_t acc[RBW][CBW];
@@ -290,19 +296,23 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
         }
     };
 
-    const bool partial_last = (Npad % PANEL) != 0;
+    // the last panel sees every k: it also forms the mean.  Only panel 0 can be short.
     if (SPLIT) {
         const int p = blockIdx.y;
         if (p == npanel - 1) {
-            if (partial_last) run_panel(p, std::true_type{}, std::true_type{});
+            if (p == 0 && rem) run_panel(p, std::true_type{}, std::true_type{});
             else run_panel(p, std::true_type{}, std::false_type{});
-        } else run_panel(p, std::false_type{}, std::false_type{});
+        } else if (p == 0 && rem) run_panel(p, std::false_type{}, std::true_type{});
+        else run_panel(p, std::false_type{}, std::false_type{});
+    } else if (npanel == 1) {
+        if (rem) run_panel(0, std::true_type{}, std::true_type{});
+        else run_panel(0, std::true_type{}, std::false_type{});
     } else {
-        for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{}, std::false_type{});
+        if (rem) run_panel(0, std::false_type{}, std::true_type{});
+        else run_panel(0, std::false_type{}, std::false_type{});
+        for (int p = 1; p + 1 < npanel; p++) run_panel(p, std::false_type{}, std::false_type{});
         STAMP(2);
-        // the last panel sees every k: it also forms the mean
-        if (partial_last) run_panel(npanel - 1, std::true_type{}, std::true_type{});
-        else run_panel(npanel - 1, std::true_type{}, std::false_type{});
+        run_panel(npanel - 1, std::true_type{}, std::false_type{});
         STAMP(3);
     }
 
