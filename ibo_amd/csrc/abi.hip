@@ -759,23 +759,32 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     if (!X || !Y || !thetas || !nlml_host || N < 1 || n_theta < 1) return fail(IBO_ERR_ARG, "bad argument");
     IBO_TRY(use_device(device));
     const int Np = round_up(N + 1, 64);            // room for the appended y row (see aug_row_kernel)
-    DevBuf<double> dX, dY, dK, dL, d64, dout;
+    // theta-points are independent and each factorisation is a latency-bound chain of small
+    // kernels: run up to four of them concurrently on their own streams and buffers
+    const int NS = n_theta < 4 ? n_theta : 4;
+    DevBuf<double> dX, dY, dout, dL[4], d64[4];
     DevBuf<int> dinfo;
-    IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N)); IBO_TRY(dK.ensure((size_t)N * N));
-    IBO_TRY(dL.ensure((size_t)Np * Np)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096));
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+    IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N));
     IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
-    hipStream_t s = nullptr;
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
+    for (int k = 0; k < NS; k++) {
+        IBO_TRY(dL[k].ensure((size_t)Np * Np)); IBO_TRY(d64[k].ensure((size_t)(Np / 64) * 4096));
+        HIP_TRY(hipStreamCreate(&st[k]));
+        // identity pad once: the factorisation leaves the pad rows/columns as it found them
+        KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL[k].p, Np, 1.0, st[k]));
+    }
     for (int t = 0; t < n_theta; t++) {
+        const int k = t % NS;
         KParams kp;
         IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
-        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dK.p, N, s));
-        KERNEL_TRY(launch_pad_copy(dK.p, N, N, dL.p, Np, 1.0, s));
-        KERNEL_TRY(launch_nlml_aug(dL.p, Np, N, dY.p, s));
-        KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p + t, s));
-        KERNEL_TRY(launch_nlml_reduce(dL.p, Np, N, dout.p + 2 * t, s));
+        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL[k].p, Np, st[k]));
+        KERNEL_TRY(launch_nlml_aug(dL[k].p, Np, N, dY.p, st[k]));
+        KERNEL_TRY(launch_cholesky(dL[k].p, Np, d64[k].p, dinfo.p + t, st[k]));
+        KERNEL_TRY(launch_nlml_reduce(dL[k].p, Np, N, dout.p + 2 * t, st[k]));
     }
+    for (int k = 0; k < NS; k++) HIP_TRY(hipStreamSynchronize(st[k]));
     std::vector<double> out(2 * (size_t)n_theta);
     std::vector<int> info(n_theta);
     HIP_TRY(hipMemcpy(out.data(), dout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
@@ -783,7 +792,8 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     const double half_log_2pi_n = 0.5 * N * log(2.0 * M_PI);
     for (int t = 0; t < n_theta; t++)
         nlml_host[t] = info[t] ? NAN : 0.5 * out[2 * t] + out[2 * t + 1] + half_log_2pi_n;
-    dX.release(); dY.release(); dK.release(); dL.release(); d64.release(); dout.release(); dinfo.release();
+    dX.release(); dY.release(); dout.release(); dinfo.release();
+    for (int k = 0; k < NS; k++) { dL[k].release(); d64[k].release(); (void)hipStreamDestroy(st[k]); }
     return IBO_OK;
 }
 
