@@ -797,6 +797,65 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     return IBO_OK;
 }
 
+// NLML and its gradient w.r.t. the log hyper-parameters for ONE theta: marginalLikelihood(...,
+// computeGradient=True) of ego/gaussianprocess/trainhyper.py:47-75.  modes/dims describe
+// Kernel.derivative(X, h) for h < ngrad (see GradSpec).
+extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *X, const double *Y,
+                             const double *hyper, int nhyper, double sf2, double noise,
+                             int ngrad, const int *modes, const int *dims, double *nlml_host, double *grad_host)
+{
+    if (!X || !Y || !hyper || !modes || !dims || !nlml_host || !grad_host || N < 1) return fail(IBO_ERR_ARG, "bad argument");
+    if (ngrad < 1 || ngrad > IBO_GRAD_MAX) return fail(IBO_ERR_ARG, "ngrad=%d unsupported (1..%d)", ngrad, IBO_GRAD_MAX);
+    IBO_TRY(use_device(device));
+    KParams kp;
+    IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
+    GradSpec gs;
+    gs.nh = ngrad;
+    for (int h = 0; h < ngrad; h++) {
+        if (modes[h] < 0 || modes[h] > 4 || dims[h] < 0 || dims[h] >= D) return fail(IBO_ERR_ARG, "bad derivative spec");
+        gs.mode[h] = modes[h]; gs.dim[h] = dims[h];
+    }
+    const int Np = round_up(N, 64);
+    const size_t nn = (size_t)Np * Np;
+    const int nblk = ((N + 15) / 16) * ((N + 15) / 16);
+    DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout;
+    DevBuf<int> dinfo;
+    IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(Np)); IBO_TRY(dL.ensure(nn)); IBO_TRY(dW.ensure(nn));
+    IBO_TRY(dT.ensure(nn)); IBO_TRY(dKi.ensure(nn)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096));
+    IBO_TRY(dal.ensure(Np)); IBO_TRY(da1.ensure(Np)); IBO_TRY(tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));
+    IBO_TRY(dpart.ensure((size_t)ngrad * nblk)); IBO_TRY(dout.ensure(ngrad)); IBO_TRY(dinfo.ensure(1));
+    hipStream_t s = nullptr;
+    std::vector<double> yp(Np, 0.0);
+    for (int i = 0; i < N; i++) yp[i] = Y[i];
+    HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dY.p, yp.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
+    KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p, Np, 1.0, s));                         // identity pad
+    KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p, Np, s));
+    KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
+    int h = 0;
+    HIP_TRY(hipMemcpy(&h, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+    int rc = IBO_OK;
+    if (h != 0) rc = fail(IBO_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d)", h);
+    else {
+        KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
+        KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
+        KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));                      // zero the pad rows
+        KERNEL_TRY(launch_alpha(dW.p, N, Np, dY.p, tmp.p, dal.p, da1.p, s));
+        KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s));
+        KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, dKi.p, Np, dal.p, dpart.p, dout.p, s));
+        std::vector<double> al(N), dg(N);
+        HIP_TRY(hipMemcpy(al.data(), dal.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(dg.data(), sizeof(double), dL.p, sizeof(double) * (Np + 1), sizeof(double), N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(grad_host, dout.p, sizeof(double) * ngrad, hipMemcpyDeviceToHost));
+        double quad = 0.0, logdet = 0.0;
+        for (int i = 0; i < N; i++) { quad += Y[i] * al[i]; logdet += log(dg[i]); }
+        *nlml_host = 0.5 * quad + logdet + 0.5 * N * log(2.0 * M_PI);
+    }
+    dX.release(); dY.release(); dL.release(); dW.release(); dT.release(); dKi.release(); d64.release(); dal.release();
+    da1.release(); tmp.release(); dpart.release(); dout.release(); dinfo.release();
+    return rc;
+}
+
 // ------------------------------------------------------------------------ legacy libego symbols
 extern "C" const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR, double *X, double *Y, int nx,
                                   int acqfunc, int kerneltype, double *hyperparams, int npbases,

@@ -82,6 +82,15 @@ __device__ __forceinline__ double cov_from_z_rt(int fam, double z, double sf2)
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+// which derivative each hyper-parameter index asks for (nlml_grad_kernel)
+#define IBO_GRAD_MAX 17
+struct GradSpec {
+    int nh;
+    int mode[IBO_GRAD_MAX];     // 0 SE-ARD length scale of dimension dim[h]; 1 SE-iso length scale; 2 signal
+                                // magnitude (2K); 3 Matern-3/2 length scale; 4 Matern-5/2 length scale
+    int dim[IBO_GRAD_MAX];
+};
+
 // fp64 MFMA 16x16x4: D(16x16) += A(16x4) * B(4x16).  Lane l supplies
 // A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; it receives
 // D[row = (l>>4) + 4*r][col = l&15] in element r (cdna_hip_programming.md s3).
@@ -187,6 +196,8 @@ int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2
 int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double *Xs, double *ak, hipStream_t s);
 // C = W^T W (Wt: scratch for the transpose), all Npad x Npad
 int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s);
+int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double *X, int ldx, const double *Kinv, int ldk,
+                     const double *alpha, double *partial, double *out, hipStream_t s);
 int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s);
 int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);

@@ -476,6 +476,73 @@ int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------
+// gradient of the negative log marginal likelihood (ego/gaussianprocess/trainhyper.py:70-71):
+//   dnlml_h = 1/2 sum_ab (K^-1 - alpha alpha^T)_ab * dK_h[a][b]
+// with dK_h as the reference's Kernel.derivative(X, h) builds it (kernel.py:92-106,122-127,
+// 152-166,183-188,212-227,251-266), quirks included (Matern-3/2 uses the unscaled distance).
+// One thread per (a, b); K_ab and every dK_h are recomputed from X, nothing N x N is stored
+// besides K^-1.  Per-block partial sums, reduced in a fixed order by grad_reduce_kernel.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs, int N, const double *__restrict__ X,
+                                                        int ldx, const double *__restrict__ Kinv, int ldk,
+                                                        const double *__restrict__ alpha, double *__restrict__ partial)
+{
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x * 16 + (t & 15);
+    const int a = blockIdx.y * 16 + (t >> 4);
+    double acc[IBO_GRAD_MAX];
+    for (int h = 0; h < gs.nh; h++) acc[h] = 0.0;
+    if (a < N && b < N) {
+        const double *xa = X + (size_t)a * ldx, *xb = X + (size_t)b * ldx;
+        double z = 0.0, d2 = 0.0;
+        for (int d = 0; d < kp.D; d++) { double u = xa[d] - xb[d]; z += kp.w[d] * (u * u); d2 += u * u; }
+        const double kab = cov_from_z_rt(kp.family, z, kp.sf2);
+        const double wm = Kinv[(size_t)a * ldk + b] - alpha[a] * alpha[b];
+        for (int h = 0; h < gs.nh; h++) {
+            double dk;
+            switch (gs.mode[h]) {
+            case 0: { double u = xa[gs.dim[h]] - xb[gs.dim[h]]; dk = kab * kp.w[gs.dim[h]] * (u * u); break; }
+            case 1: dk = kab * z; break;                                   // iso: w * |x_a - x_b|^2
+            case 2: dk = 2.0 * kab; break;                                 // signal magnitude
+            case 3: { double r = sqrt(d2); dk = (a == b) ? 0.0 : kp.sf2 * r * r * exp(-r); break; }
+            default: { double zz = 5.0 * z; dk = (a == b) ? 0.0 : kp.sf2 * (zz + sqrt(zz) * sqrt(zz) * sqrt(zz)) * exp(-sqrt(zz)) / 3.0; break; }
+            }
+            acc[h] = wm * dk;
+        }
+    }
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    for (int h = 0; h < gs.nh; h++) {
+        red[t] = (a < N && b < N) ? acc[h] : 0.0;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+        if (t == 0) partial[(size_t)h * gridDim.x * gridDim.y + blk] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double *__restrict__ partial, int nblk, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int h = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int i = t; i < nblk; i += 256) s += partial[(size_t)h * nblk + i];
+    red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    if (t == 0) out[h] = 0.5 * red[0];
+}
+
+int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double *X, int ldx, const double *Kinv, int ldk,
+                     const double *alpha, double *partial, double *out, hipStream_t s)
+{
+    dim3 grid((N + 15) / 16, (N + 15) / 16);
+    hipLaunchKernelGGL(nlml_grad_kernel, grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(gs.nh), dim3(256), 0, s, partial, (int)(grid.x * grid.y), out);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
 // pack W into MFMA A-fragment order for the sweep:
 //   Wp[((g*nk8 + j)*64 + lane)*2 + h] = W[16g + (lane&15)][8j + 4h + (lane>>4)]
 // so that one 16-byte load per lane yields the A operands of two consecutive

@@ -31,6 +31,10 @@ class Kernel(object):
     def _ibo_spec(self):
         raise NotImplementedError
 
+    # device description of derivative(X, hp) for hp = 0..nhyper-1: list of (mode, dim), see ibo_nlml_grad
+    def _ibo_grad_spec(self, D):
+        raise NotImplementedError
+
     def covMatrix(self, X, device=None):
         """K[i,j] = cov(X[i], X[j]), diagonal included (kernel.py:46-53); GPU-assembled."""
         X = _lib.f64(np.vstack(X))
@@ -76,6 +80,9 @@ class GaussianKernel_iso(Kernel):
     def _ibo_spec(self):
         return _lib.K_SE_ISO, _lib.f64([1.0 / np.sqrt(self._itheta2)]), 1.0, 1.0
 
+    def _ibo_grad_spec(self, D):
+        return [(1, 0)]
+
     def derivative(self, X, hp):
         if hp != 0:
             raise ValueError
@@ -101,6 +108,9 @@ class SVGaussianKernel_iso(SVKernel, GaussianKernel_iso):
         # libego sees kernel type 1 and ignores the magnitude (cpp/optimizeGP.cpp:303-310)
         return _lib.K_SE_ISO, _lib.f64([1.0 / np.sqrt(self._itheta2)]), float(self._sf2), 1.0
 
+    def _ibo_grad_spec(self, D):
+        return [(1, 0), (2, 0)]
+
     def derivative(self, X, hp):
         if hp == 0:
             return GaussianKernel_iso.derivative(self, X, hp)
@@ -122,6 +132,9 @@ class GaussianKernel_ard(Kernel):
 
     def _ibo_spec(self):
         return _lib.K_SE_ARD, _lib.f64(self._theta), 1.0, 1.0
+
+    def _ibo_grad_spec(self, D):
+        return [(0, d) for d in range(D)]
 
     def derivative(self, X, hp):
         NA = np.vstack(X).shape[1]
@@ -148,6 +161,9 @@ class SVGaussianKernel_ard(SVKernel, GaussianKernel_ard):
     def _ibo_spec(self):
         return _lib.K_SE_ARD, _lib.f64(self._theta), float(self._sf2), 1.0
 
+    def _ibo_grad_spec(self, D):
+        return [(0, d) for d in range(D)] + [(2, 0)]
+
     def derivative(self, X, hp):
         if hp < len(self._theta):
             return GaussianKernel_ard.derivative(self, X, hp)
@@ -173,6 +189,9 @@ class MaternKernel3(Kernel):
     def _ibo_spec(self):
         # libego: sf2 = 1 for kernel type 2 whatever the magnitude (cpp/optimizeGP.cpp:303-310)
         return _lib.K_MATERN3, _lib.f64([self._theta]), float(self._sf2), 1.0
+
+    def _ibo_grad_spec(self, D):
+        return [(3, 0), (2, 0)]
 
     def derivative(self, X, hp):
         K = self.covMatrix(X)
@@ -205,6 +224,9 @@ class MaternKernel5(Kernel):
 
     def _ibo_spec(self):
         return _lib.K_MATERN5, _lib.f64([self._theta]), float(self._sf2), float(self._sf2)
+
+    def _ibo_grad_spec(self, D):
+        return [(4, 0), (2, 0)]
 
     def derivative(self, X, hp):
         K = self.covMatrix(X)

@@ -6,9 +6,9 @@ Marginal likelihood of the GP hyper-parameters (ego/gaussianprocess/trainhyper.p
     nlml_grid(KernelClass, thetas, X, Y, noise=1e-3)      <- new: a whole theta grid in one call
 
 The value (K assembly, Cholesky, L^-1 Y, log det) is computed on the GPU by
-ibo_nlml_grid.  The gradient needs K^-1 - alpha alpha^T against dK/dtheta_i; K^-1
-comes from the device factorisation and the contraction is assembled on the host
-(row (f)-2 of SURVEY 8: the gradient is not on this round's accelerated path).
+ibo_nlml_grid; value + gradient for one theta by ibo_nlml_grad (K^-1 = W^T W from the device
+factorisation, then one fused kernel contracts K^-1 - alpha alpha^T with every dK/dtheta_i,
+recomputed from X on the fly).
 """
 import numpy as np
 from numpy.linalg import LinAlgError
@@ -48,27 +48,31 @@ def marginalLikelihood(kernel, X, Y, nhyper, computeGradient=True, useCholesky=T
     signature compatibility; the device path always factors."""
     NX = len(X)
     assert NX == len(Y)
-    v = nlml_values([kernel], X, Y, noise)[0]
-    if not np.isfinite(v):
-        raise LinAlgError("covariance matrix is not positive definite for hyperparameters %s"
-                          % (kernel.hyperparams,))
     if not computeGradient:
+        v = nlml_values([kernel], X, Y, noise)[0]
+        if not np.isfinite(v):
+            raise LinAlgError("covariance matrix is not positive definite for hyperparameters %s"
+                              % (kernel.hyperparams,))
         return v
-    # gradient: W = K^-1 - alpha alpha^T, dnlml_i = sum(W * dK/dtheta_i) / 2   (:70-71)
+    # value and gradient in one device call: Cholesky, L^-1, K^-1 = W^T W, then
+    # dnlml_i = sum((K^-1 - alpha alpha^T) * dK/dtheta_i) / 2   (:70-71)
+    import ctypes
     Xa = _lib.f64(np.vstack(X)); Ya = _lib.f64(Y)
-    K = kernel.covMatrix(Xa) + np.eye(NX) * noise
-    from . import GaussianProcess          # device factorisation of an explicit matrix
-    g = GaussianProcess.__new__(GaussianProcess)
-    GaussianProcess.__init__(g, kernel, noise=0.0)
-    g.X, g.Y = Xa, Ya
-    g._fit_device(A=K)
-    Wl = np.empty((NX, NX))
-    _lib.check(_lib.lib.ibo_gp_get_W(g._handle(), _lib.dp(Wl)))
-    Kinv = Wl.T.dot(Wl)
-    alpha = Kinv.dot(Ya)
-    Wm = Kinv - np.outer(alpha, alpha)
-    d = np.array([np.sum(Wm * kernel.derivative(Xa, i)) / 2.0 for i in range(nhyper)])
-    return v, d
+    N, D = Xa.shape
+    ktype, hyper, sf2, _ = kernel._ibo_spec()
+    spec = kernel._ibo_grad_spec(D)[:nhyper]
+    if len(spec) < nhyper:
+        raise ValueError("kernel has %d hyperparameters, %d gradients requested" % (len(spec), nhyper))
+    modes = (ctypes.c_int * nhyper)(*[m for m, _ in spec])
+    dims = (ctypes.c_int * nhyper)(*[d for _, d in spec])
+    v = ctypes.c_double()
+    g = np.empty(nhyper)
+    try:
+        _lib.check(_lib.lib.ibo_nlml_grad(_lib.default_device(), ktype, N, D, _lib.dp(Xa), _lib.dp(Ya), _lib.dp(hyper),
+                                          len(hyper), sf2, float(noise), nhyper, modes, dims, ctypes.byref(v), _lib.dp(g)))
+    except _lib.NotPositiveDefinite:
+        raise LinAlgError("covariance matrix is not positive definite for hyperparameters %s" % (kernel.hyperparams,))
+    return v.value, g
 
 
 def nlml(loghyper, kernel, X, Y, *args):

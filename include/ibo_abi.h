@@ -243,6 +243,17 @@ int ibo_nlml_grid(int device, int ktype, int N, int D,
                   const double *sf2_host /* n_theta or NULL (=1) */, double noise,
                   double *nlml_host);
 
+/*
+ * NLML and its gradient w.r.t. each LOG hyper-parameter for one theta: marginalLikelihood(...,
+ * computeGradient=True), ego/gaussianprocess/trainhyper.py:47-75, with dK/dtheta_h as
+ * Kernel.derivative(X, h) builds it (ego/gaussianprocess/kernel.py).  modes[h]: 0 SE-ARD length
+ * scale of dimension dims[h]; 1 SE-iso length scale; 2 signal magnitude (2K); 3 Matern-3/2 and
+ * 4 Matern-5/2 length scale.  grad_host receives ngrad values.
+ */
+int ibo_nlml_grad(int device, int ktype, int N, int D, const double *X_host, const double *Y_host,
+                  const double *hyper_host, int nhyper, double sf2, double noise,
+                  int ngrad, const int *modes, const int *dims, double *nlml_host, double *grad_host);
+
 /* ---------------------------------------------------------------- multi-GPU arg-max exchange (RCCL) */
 #define IBO_COMM_ID_BYTES 128
 int ibo_comm_get_unique_id(unsigned char id[IBO_COMM_ID_BYTES]);

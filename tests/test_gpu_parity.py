@@ -371,6 +371,20 @@ def test_g2_g8_marginal_likelihood(ibo):
         Xs, Ys = synth(5, N, 16)
         vals, am = nlml_grid(K.GaussianKernel_ard, g8["n%d_theta" % N], Xs, Ys, noise=1e-3)
         close(vals, g8["n%d_nlml" % N]); assert am == int(np.argmin(g8["n%d_nlml" % N]))
+    Xs, Ys = synth(5, 64, 16)
+    v, d = marginalLikelihood(K.GaussianKernel_ard(g8["n64_grad_theta"]), Xs, Ys, 16, True, noise=1e-3)
+    close(v, g8["n64_grad_nlml"]); close(d, g8["n64_grad"], atol=1e-9)
+    # hyper-parameter learning loop (ego/unittest_GP.py:216-219): BFGS on log-theta with the device
+    # value and gradient must reach the optimum the oracle's own BFGS finds
+    from scipy import optimize
+    from ibo_amd.gaussianprocess.trainhyper import dnlml
+    x0 = np.log([2., 2., .1, 1.])
+    ours = optimize.fmin_bfgs(nlml, x0, dnlml, args=(K.SVGaussianKernel_ard, X, Y), disp=False)
+    import oracle.oracle as orc
+    f_o = lambda lh: orc.marginal_likelihood(orc.Kern("svard", np.exp(lh)), X, Y, 4, False, 1e-3)
+    g_o = lambda lh: orc.marginal_likelihood(orc.Kern("svard", np.exp(lh)), X, Y, 4, True, 1e-3)[1]
+    ref = optimize.fmin_bfgs(f_o, x0, g_o, disp=False)
+    close(f_o(ours), f_o(ref), rtol=1e-6)
     # not-PD -> 100 through the nlml() wrapper (trainhyper.py:111-114)
     Xd = np.vstack([X, X[:1]])
     assert nlml(np.log([2., 2., .1]), lambda h: K.GaussianKernel_ard(h), Xd, np.r_[Y, 1.0]) in (100,) or True
