@@ -177,6 +177,23 @@ class GaussianProcess(object):
         """host points in, host arrays out, through the device sweep (PCIe-inclusive)"""
         Q = _lib.f64(np.atleast_2d(Q))
         M, D = Q.shape
+        if self._augdev is not None and acq != _lib.ACQ_NONE:
+            # augmented variance in force (addObservationPoint): mean and variance come from two
+            # factors, so the acquisition is formed from them as the reference's classes do
+            # (ego/acquisition/__init__.py:68-71,107-110,150-164), per point on the host
+            mu, s2 = self._posterior_arrays(Q, True)
+            ym = np.max(self.Y) if ymax is None else ymax
+            sig = np.sqrt(s2)
+            if acq == _lib.ACQ_UCB:
+                val = mu + parm * sig
+            else:
+                yd = mu - ym - parm
+                Z = yd / sig
+                if acq == _lib.ACQ_PI:
+                    val = np.array([CDF(float(z)) for z in Z])
+                else:
+                    val = np.array([float(d) * CDF(float(z)) + float(s) * PDF(float(z)) for d, z, s in zip(yd, Z, sig)])
+            return {"mu": mu, "s2": s2, "acq": val, "best_val": float(np.max(val)), "best_idx": int(np.argmax(val))}
         cand = _lib.DeviceArray.from_host(Q, self._dev.device)
         outs = {k: _lib.DeviceArray((M,), self._dev.device) for k in want}
         bv = ctypes.c_double(); bi = ctypes.c_int64()

@@ -588,6 +588,11 @@ def test_add_observation_point_augmented_variance(ibo, oracle):
     close(s21, s2_ref); close(GP.augL, augL, atol=1e-9); close(GP.augR, augR, rtol=1e-12)
     assert np.all(s21 <= s20 + 1e-12)                    # observing more can only shrink the variance
     assert len(GP.augX) == m + 2
+    # the acquisition classes see the augmented variance, as the reference's EI.negf -> GP.posterior does
+    from ibo_amd.acquisition import EI
+    e = EI(GP, xi=.05)
+    ref_ei = oracle.acq_value(oracle.ACQ_EI, oracle.ERF_NR, mu1[:3], np.sqrt(s2_ref[:3]), GP.Y.max(), .05)
+    close([e.f(q) for q in probe[:3]], ref_ei, atol=ACQ_ATOL)
 
 
 def test_sv_ard_kernel_and_ego_alias(ibo, oracle):
