@@ -155,7 +155,7 @@ struct SweepArgs {
     const double *Xs;        // Npad x DP, coordinates scaled by sqrt(w_d)  (x~)
     const double *ak;        // Npad: -|x~_k|^2 / 2
     double log_sf2;          // log of the k* signal variance
-    int dot_form;            // SE only: y = ak + bc + x~.c~ (D+1 FMAs) instead of the difference form
+    int dot_form;            // y = ak + bc + x~.c~ (D+1 FMAs) instead of the difference form (2D)
     const double *W;         // Npad x Npad row-major lower-triangular, q = |W k*|^2
     const double *Wp;        // same matrix in MFMA fragment order (see pack_w_kernel)
     const double *alphaY;    // Npad

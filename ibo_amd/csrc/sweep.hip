@@ -85,8 +85,8 @@ __device__ __forceinline__ void wave_argmax(double &v, int64_t &i)
 // workgroups of 32 candidates per CU -- same work per wave, the idea being that one covers the other's
 // dispatch/epilogue -- measured 66 % at N=1024 and no better at N=256: two k* rows per wave instruction
 // need per-lane observation loads and the 128-VGPR budget then spills 60-200 registers.)
-// DOT: squared-exponential k* as exp(a_k + b_c + x~.c~) (D+1 FMAs) instead of the
-// difference form (2D) -- fp64 VALU shares the MFMA pipe, instruction count is time.
+// DOT: the scaled squared distance as -2 (a_k + b_c + x~.c~) (D+1 FMAs) instead of the
+// difference form (2D); for the squared exponential the exp() takes that sum directly -- fp64 VALU shares the MFMA pipe, instruction count is time.
 // CBW: candidate-blocks per wave (4: a wave spans the whole tile; 2: waves come in pairs
 // that share row-blocks, each wave owning RBW = 4 row-blocks spread over the panel, which
 // keeps all 16 waves busy until the last stage of the triangular diagonal block).
@@ -100,7 +100,6 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
     constexpr int CG = 4 / CBW;                    // candidate groups of waves
     constexpr int RG = NW / CG;                    // row groups of waves
     static_assert(RG * RBW * 16 == PANEL, "waves x row-blocks must tile the panel");
-    static_assert(!DOT || FAM == FAM_SE, "dot form is for the squared exponential");
     constexpr int KPW = KCH / NW;                  // K* rows generated per wave per stage
     static_assert(KPW >= 1 && KPW <= 4 && (4 % KPW == 0), "wave generates 1, 2 or 4 rows of a k4-step");
     __shared__ double lds_k[2][KCH * TC];          // K* stage, B-fragment order
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
             n2 = fma(v, v, n2);
             if (CX_REG) cx[CX_REG ? d : 0] = v;
         }
-        bc = fma(-0.5, n2, a.log_sf2);
+        bc = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
     }
     STAMP(1);
 
@@ -169,7 +168,8 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
                 double y = a.ak[k] + bc;
 #pragma unroll
                 for (int d = 0; d < DP; d++) y = fma(xr[d], CX_REG ? cx[CX_REG ? d : 0] : lds_c[d * TC + lane], y);
-                kv = exp_fast(y);
+                if (FAM == FAM_SE) kv = exp_fast(y);
+                else kv = cov_from_z_fast<FAM>(fmax(-2.0 * y, 0.0), a.log_sf2, a.kp.sf2);   // z = |x~ - c~|^2 = -2y
             } else {
                 double z = 0.0;
 #pragma unroll
@@ -490,10 +490,10 @@ template <int FAM>
 static int launch_mfma_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     if (a.qpart) {           // split mode requested by the caller (small batch)
-        if (FAM == FAM_SE && a.dot_form) return launch_mfma_split<FAM_SE, true>(a, ntiles, s);
+        if (a.dot_form) return launch_mfma_split<FAM, true>(a, ntiles, s);
         return launch_mfma_split<FAM, false>(a, ntiles, s);
     }
-    if (FAM == FAM_SE && a.dot_form) return launch_mfma_var<FAM_SE, true>(a, ntiles, s);
+    if (a.dot_form) return launch_mfma_var<FAM, true>(a, ntiles, s);
     return launch_mfma_var<FAM, false>(a, ntiles, s);
 }
 

@@ -239,7 +239,9 @@ def test_kstar_dot_form_matches_difference_form(ibo, oracle):
     cand[:50] = cand[:50] * 40 - 20                       # far outside the data (demo.py probes (-10,.5,-10))
     cand[50:60] = X[:10]                                  # exactly on observations
     for kern, okern in ((K.GaussianKernel_ard([.5, .5, .3]), oracle.Kern("ard", [.5, .5, .3])),
-                        (K.SVGaussianKernel_iso([.4, 1.02]), oracle.Kern("sviso", [.4, 1.02]))):
+                        (K.SVGaussianKernel_iso([.4, 1.02]), oracle.Kern("sviso", [.4, 1.02])),
+                        (K.MaternKernel5([.6, 1.0]), oracle.Kern("m5", [.6, 1.0])),
+                        (K.MaternKernel3([.7, 1.0]), oracle.Kern("m3", [.7, 1.0]))):
         ogp = oracle.GP(okern, X, Y, noise=.1)
         o_mu, o_s2 = ogp.posteriors(cand)
         GP = GaussianProcess(kern, X, Y, noise=.1)
