@@ -89,6 +89,11 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     os.environ["IBO_DEVICE"] = str(local_rank)
+    if world > 1:
+        # one node: RCCL's bootstrap sockets go over loopback (the container hostname may not
+        # resolve); the payload itself travels over xGMI peer-to-peer
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import ibo_amd
     from ibo_amd import _lib, DeviceArray
