@@ -81,6 +81,9 @@ def lib():
                                        c_int, _DP, _DP, c_double, _DP, _DP, c_double, c_double,
                                        c_int, c_double, c_long, _DP, _DP, _DP, _DP, _DP,
                                        POINTER(c_long)]
+        L.orc_sweep_fast.restype = c_int
+        L.orc_sweep_fast.argtypes = [c_int, _DP, _DP, _DP, c_int, c_int, c_int, _DP, c_double, c_double, c_double,
+                                     c_int, c_double, c_double, c_long, _DP, _DP, _DP, POINTER(c_long), POINTER(c_int)]
         L.orc_posterior_chol.restype = c_int
         L.orc_posterior_chol.argtypes = [c_int, c_int, c_int, _DP, _DP, _DP, _DP, c_double, c_double,
                                          c_int, _DP, _DP, c_double, _DP, _DP, c_long, _DP, _DP, _DP]
@@ -329,6 +332,23 @@ def sweep_native(gp, cand, acq=ACQ_EI, parm=0.01, erf_mode=ERF_LIBM, clamp_lo=CL
                                 _dp(mu), _dp(s2), _dp(av), ctypes.byref(bv), ctypes.byref(bi))
     assert rc == 0
     return dict(mu=mu, s2=s2, acq=av, best_val=bv.value, best_idx=bi.value)
+
+
+def sweep_fast(gp, cand, acq=ACQ_EI, parm=0.01, erf_mode=ERF_LIBM, clamp_lo=CLAMP_NATIVE):
+    """best-effort all-core CPU sweep (alpha cached, triangular W = L^-1, OpenMP): same values as
+    sweep_native up to rounding.  Returns dict(acq, best_val, best_idx, threads)."""
+    assert gp.prior is None
+    cand = _f64(np.atleast_2d(cand))
+    M, D = cand.shape
+    N = len(gp.Y)
+    W = _f64(np.linalg.inv(np.linalg.cholesky(gp.factor_matrix())))
+    alpha = _f64(W.T.dot(W.dot(gp.Y)))
+    av = np.empty(M); bv = c_double(); bi = c_long(); nt = c_int()
+    rc = lib().orc_sweep_fast(D, _dp(W), _dp(alpha), _dp(gp.X), N, acq, gp.kern.ktype, _dp(gp.kern.oracle_hyper()),
+                              gp.kern.sf2_native, float(parm), gp.noise, erf_mode, clamp_lo, float(np.max(gp.Y)), M,
+                              _dp(cand), _dp(av), ctypes.byref(bv), ctypes.byref(bi), ctypes.byref(nt))
+    assert rc == 0
+    return dict(acq=av, best_val=bv.value, best_idx=bi.value, threads=nt.value)
 
 
 def acqmax_native(gp, bounds, acq=ACQ_EI, parm=0.01, maxiter=50, maxtime=30, maxsample=10000,

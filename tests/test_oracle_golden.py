@@ -213,3 +213,17 @@ def test_oracle_matches_compiled_reference(oracle):
     b = ref.direct(f, g4["shekel_bounds"].tolist(), maxiter=25)
     assert a[2] == b[2]
     close(np.r_[a[0], a[1]], np.r_[b[0], b[1]], rtol=0, atol=0)
+
+
+def test_best_effort_cpu_sweep_matches_reference_shaped_sweep(oracle):
+    """orc_sweep_fast (bench.py's all-core CPU leg: alpha cached, triangular L^-1, OpenMP) computes the same
+    posterior + EI/UCB as the reference-shaped orc_sweep_native"""
+    from conftest import synth
+    X, Y = synth(5, 96, 3)
+    gp = oracle.GP(oracle.Kern("ard", [.3, .4, .5]), X, Y, noise=.1)
+    cand = np.random.RandomState(6).rand(300, 3)
+    for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_UCB, .3)):
+        a = oracle.sweep_native(gp, cand, acq, parm)
+        b = oracle.sweep_fast(gp, cand, acq, parm)
+        assert np.allclose(a["acq"], b["acq"], rtol=1e-8, atol=1e-13)
+        assert a["best_idx"] == b["best_idx"]
