@@ -118,28 +118,29 @@ __device__ __forceinline__ void gemm_tile_64(const double *__restrict__ A, int l
                                              d4_t (&acc)[2][2], double *As, double *Bs)
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
+    // these tiles are latency-bound (a few chunks of K each): the next chunk's global loads are issued
+    // into registers before the MFMAs of the current one, so only the first latency is exposed
+    const int ra = t >> 2, kqa = (t & 3) * 4;
+    const int kb = t >> 4, cqb = (t & 15) * 4;
+    const double *pa = A + (size_t)ra * lda + kqa;
+    const double *pb = TRANSB ? B + (size_t)ra * ldb + kqa : B + (size_t)kb * ldb + cqb;
+    double2 a0, a1, b0, b1;
+    auto fetch = [&](int k0) {
+        const double2 *p = (const double2 *)(pa + k0);
+        a0 = p[0]; a1 = p[1];
+        const double2 *q = (const double2 *)(TRANSB ? pb + k0 : pb + (size_t)k0 * ldb);
+        b0 = q[0]; b1 = q[1];
+    };
+    if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
         {
-            int r = t >> 2, kq = (t & 3) * 4;
-            const double2 *p = (const double2 *)(A + (size_t)r * lda + k0 + kq);
-            double2 v0 = p[0], v1 = p[1];
-            double *q = As + r * AS_LD + kq;
-            q[0] = v0.x; q[1] = v0.y; q[2] = v1.x; q[3] = v1.y;
-        }
-        if (TRANSB) {
-            int c = t >> 2, kq = (t & 3) * 4;
-            const double2 *p = (const double2 *)(B + (size_t)c * ldb + k0 + kq);
-            double2 v0 = p[0], v1 = p[1];
-            double *q = Bs + c * AS_LD + kq;
-            q[0] = v0.x; q[1] = v0.y; q[2] = v1.x; q[3] = v1.y;
-        } else {
-            int k = t >> 4, cq = (t & 15) * 4;
-            const double2 *p = (const double2 *)(B + (size_t)(k0 + k) * ldb + cq);
-            double2 v0 = p[0], v1 = p[1];
-            double *q = Bs + k * BS_LD + cq;
-            q[0] = v0.x; q[1] = v0.y; q[2] = v1.x; q[3] = v1.y;
+            double *q = As + ra * AS_LD + kqa;
+            q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y;
+            double *w = TRANSB ? Bs + ra * AS_LD + kqa : Bs + kb * BS_LD + cqb;
+            w[0] = b0.x; w[1] = b0.y; w[2] = b1.x; w[3] = b1.y;
         }
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
         for (int k4 = 0; k4 < 4; k4++) {
             double a[2], b[2];
@@ -160,6 +161,39 @@ __device__ __forceinline__ void gemm_tile_64(const double *__restrict__ A, int l
     }
 }
 
+// K = 64 in one stage (the factorisation's trsm / syrk tiles): both 64x64 operand tiles are fetched with
+// every load in flight at once -- one global-memory latency instead of four.  acc += A * B^T.
+// As, Bs: 64 * T64_LD doubles each.
+#define T64_LD 68
+__device__ __forceinline__ void tile64_fetch(const double *__restrict__ A, int lda, double2 (&v)[8])
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = *(const double2 *)(A + (size_t)(8 * u + (t >> 5)) * lda + (t & 31) * 2);
+}
+__device__ __forceinline__ void tile64_stash(double *As, const double2 (&v)[8])
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 8; u++) *(double2 *)(As + (8 * u + (t >> 5)) * T64_LD + (t & 31) * 2) = v[u];
+}
+__device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs, d4_t (&acc)[2][2])
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4++) {
+        double a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * T64_LD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < 2; n++) b[n] = Bs[(wc * 32 + n * 16 + (lane & 15)) * T64_LD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) acc[m][n] = mfma_f64(a[m], b[n], acc[m][n]);
+    }
+}
+
 // C[row][col] for accumulator element (m, n, r) of this lane
 #define TILE_ROW(m, r) (wr * 32 + (m) * 16 + (lane >> 4) + 4 * (r))
 #define TILE_COL(n) (wc * 32 + (n) * 16 + (lane & 15))
@@ -168,7 +202,13 @@ __device__ __forceinline__ void gemm_tile_64(const double *__restrict__ A, int l
 // ------------------------------------------------------------------------
 // blocked right-looking Cholesky, NB = 64
 // ------------------------------------------------------------------------
-#define SD 65
+#define SD 66
+#ifdef IBO_STAMPS      // diagnostic build (tools/chol_diag_bench.hip): where does the diagonal block's time go?
+__device__ unsigned long long g_chol_stamps[32];
+#define CSTAMP(i) do { if (threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSTAMP(i)
+#endif
 __device__ __forceinline__ double lane_bcast(double x, int l)          // value of lane l, wave-uniform
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
@@ -176,133 +216,189 @@ __device__ __forceinline__ double lane_bcast(double x, int l)          // value 
     return __hiloint2double(hi, lo);
 }
 
-// Factor the 64x64 diagonal block and invert the factor inside one workgroup, blocked by 16:
-//   per 16-column panel: (i) wave 0 factors the 16x16 diagonal sub-block and inverts it with the
-//   rows in registers (lane = row, operands broadcast with v_readlane, fully unrolled);
-//   (ii) the rows below are multiplied by that inverse (triangular solve as a small GEMM);
-//   (iii) the trailing sub-matrix gets its rank-16 update -- 4 x 4 barriers instead of 64 x 3.
-//   The 64x64 inverse is then assembled from the four 16x16 inverses by recursive doubling.
+// one wave: 16x16 (+)= A(16xK) * B(Kx16) with both operands in LDS (row stride SD).
+// A element (r,k) = Am[r*SD + k];  B element (k,c) = TB ? Bm[c*SD + k] : Bm[k*SD + c].
+// Result element r of the returned vector is row (lane>>4)+4r, column lane&15.
+template <bool TB, int K>
+__device__ __forceinline__ d4_t lds_mm16(const double *Am, const double *Bm)
+{
+    const int lane = threadIdx.x & 63, ar = lane & 15, q = lane >> 4;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double a[K / 4], b[K / 4];
+#pragma unroll
+    for (int s = 0; s < K / 4; s++) {               // all LDS reads in flight before the first MFMA
+        a[s] = Am[ar * SD + 4 * s + q];
+        b[s] = TB ? Bm[ar * SD + 4 * s + q] : Bm[(4 * s + q) * SD + ar];
+    }
+#pragma unroll
+    for (int s = 0; s < K / 4; s++) acc = mfma_f64(a[s], b[s], acc);
+    return acc;
+}
+#define MM16_ROW(r) ((lane >> 4) + 4 * (r))
+#define MM16_COL (lane & 15)
+
+// Factor the 64x64 diagonal block and invert the factor inside one workgroup, blocked by 16.
+// Everything here is instruction-issue bound on a single wave (~8 cycles per VALU instruction), so the
+// sequential chain is kept as short as it can be:
+//   per 16-column panel: (i) wave 0 factors the whole (64-o) x 16 panel with lane = row, the 16 column
+//   values of a row in registers, the pivot row's values broadcast with v_readlane, fully unrolled;
+//   1/sqrt(pivot) from v_rsq_f64 + one third-order correction (no fp64 divide / sqrt sequences);
+//   (iii) the trailing sub-matrix gets its rank-16 update as 16x16 fp64-MFMA tiles out of LDS.
+//   The four 16x16 diagonal factors are inverted afterwards, one per wave, in right-looking order
+//   (independent updates instead of a dependent dot product), and the 64x64 inverse is assembled
+//   from them by recursive doubling (MFMA).
 // This kernel is the sequential chain of the whole factorisation (N/64 launches).
+__device__ __forceinline__ double rcp_newton(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(y, fma(-d, y, 1.0), y);
+    return fma(y, fma(-d, y, 1.0), y);
+}
+
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, int Npad, int jb,
                                                         double *__restrict__ diag64, int *info)
 {
     __shared__ double S[64 * SD];          // the block; ends up holding L (lower)
     __shared__ double V[64 * SD];          // its inverse
-    __shared__ double T[64 * SD];          // scratch (solved rows / L21 * V11 products)
+    __shared__ double T[64 * SD];          // scratch (L21 * V11 products)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     double *Lb = L + (size_t)jb * 64 * Npad + jb * 64;
-    for (int e = t; e < 4096; e += 256) {
-        int r = e >> 6, c = e & 63;
-        S[r * SD + c] = Lb[(size_t)r * Npad + c];
-        V[r * SD + c] = 0.0;
+    CSTAMP(31);
+    {
+        double v[16];                      // all 16 loads in flight before the first LDS write
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = Lb[(size_t)(4 * u + (t >> 6)) * Npad + (t & 63)];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            S[(4 * u + (t >> 6)) * SD + (t & 63)] = v[u];
+            V[(4 * u + (t >> 6)) * SD + (t & 63)] = 0.0;
+        }
     }
+    CSTAMP(0);
     __syncthreads();
+    CSTAMP(1);
     for (int b = 0; b < 4; b++) {
         const int o = 16 * b;
         if (wv == 0) {
-            // (i) 16x16 Cholesky, lane = row (lanes >= 16 compute on a copy of row 15, unused)
-            const int rr = o + min(lane, 15);
+            // (i) panel factorisation, lane = row o+lane (lanes past row 63 work on a copy of it, unused)
+            const int rr = min(o + lane, 63);
             double r[16];
+            int bad = -1;
 #pragma unroll
             for (int k = 0; k < 16; k++) r[k] = S[rr * SD + o + k];
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const double pj = r[j];
-                double d = lane_bcast(pj, j);
-                if (!(d > 0.0)) {                   // also catches NaN
-                    if (lane == 0) atomicCAS(info, 0, jb * 64 + o + j + 1);
-                    d = 1.0;
-                }
-                const double tj = pj / d;
-                r[j] = pj / sqrt(d);
+                const double d = lane_bcast(r[j], j);
+                // a pivot <= 0 (or NaN) only has to be recorded: it turns the rest of the block into
+                // NaN, nothing traps, and the host reports info.  Keeping the test off the dependent
+                // chain (no select on d) is worth ~10 % of this kernel.
+                bad = (d > 0.0 || bad >= 0) ? bad : j;
+                const double y0 = __builtin_amdgcn_rsq(d);
+                const double l0 = r[j] * y0;
+                const double e = fma(-d * y0, y0, 1.0);               // 1 - d y0^2
+                const double l = fma(l0 * e, fma(0.375, e, 0.5), l0); // r[j] / sqrt(d)
+                r[j] = l;
 #pragma unroll
-                for (int k = j + 1; k < 16; k++) r[k] = fma(-tj, lane_bcast(pj, k), r[k]);
+                for (int k = j + 1; k < 16; k++) r[k] = fma(-l, lane_bcast(l, k), r[k]);
             }
-            if (lane < 16) {
+            if (bad >= 0 && lane == 0) atomicCAS(info, 0, jb * 64 + o + bad + 1);
+            if (o + lane < 64) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) S[rr * SD + o + k] = (k <= lane) ? r[k] : 0.0;
             }
-            // inverse of the 16x16 factor, lane = column c: x[i] = V16[i][c]
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double acc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; k++) acc = fma(-lane_bcast(r[k], i), x[k], acc);
-                x[i] = (i < lane) ? 0.0 : acc / lane_bcast(r[i], i);
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) V[(o + i) * SD + o + lane] = x[i];
-            }
+            CSTAMP(2 + 5 * b);
         }
         __syncthreads();
-        const int nbelow = 64 - o - 16;
-        // (ii) rows below: X[i][c] = sum_{k<=c} A[i][o+k] * V16[c][k]   -> T, then copied back
-        for (int e = t; e < nbelow * 16; e += 256) {
-            int i = o + 16 + (e >> 4), c = e & 15;
-            double acc = 0.0;
-            for (int k = 0; k <= c; k++) acc = fma(S[i * SD + o + k], V[(o + c) * SD + o + k], acc);
-            T[i * SD + c] = acc;
-        }
-        __syncthreads();
-        for (int e = t; e < nbelow * 16; e += 256) {
-            int i = o + 16 + (e >> 4), c = e & 15;
-            S[i * SD + o + c] = T[i * SD + c];
-        }
-        __syncthreads();
-        // (iii) trailing update (lower part): S[i][k] -= sum_c S[i][o+c] S[k][o+c]
-        for (int e = t; e < nbelow * nbelow; e += 256) {
-            int i = o + 16 + e / nbelow, k = o + 16 + e % nbelow;
-            if (k <= i) {
-                double acc = S[i * SD + k];
+        CSTAMP(4 + 5 * b);
+        const int nt = 3 - b;                       // 16-row tiles below the panel
+        // (iii) trailing update: S22 -= X X^T, tiles (it, kt <= it)
+        for (int p = wv; p < nt * (nt + 1) / 2; p += 4) {
+            const int it = (p >= 3) ? 2 : (p >= 1) ? 1 : 0, kt = p - it * (it + 1) / 2;
+            d4_t acc = lds_mm16<true, 16>(S + (o + 16 + 16 * it) * SD + o, S + (o + 16 + 16 * kt) * SD + o);
+            double *C = S + (o + 16 + 16 * it) * SD + o + 16 + 16 * kt;
 #pragma unroll
-                for (int c = 0; c < 16; c++) acc = fma(-S[i * SD + o + c], S[k * SD + o + c], acc);
-                S[i * SD + k] = acc;
-            }
+            for (int r = 0; r < 4; r++) C[MM16_ROW(r) * SD + MM16_COL] -= acc[r];
         }
-        __syncthreads();
+        if (nt > 0) __syncthreads();
+        CSTAMP(6 + 5 * b);
     }
+    // inverse of the 16x16 diagonal factor `wv`: lane i holds row i of the factor, lane c computes
+    // column c of the inverse (x[i] = V16[i][c]); right-looking, so the 15-k updates of a step are independent
+    {
+        const int o = 16 * wv, rr = o + min(lane, 15);
+        double r[16], x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            r[k] = S[rr * SD + o + k];
+            x[k] = (k == lane) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            x[k] *= rcp_newton(lane_bcast(r[k], k));
+#pragma unroll
+            for (int i = k + 1; i < 16; i++) x[i] = fma(-lane_bcast(r[k], i), x[k], x[i]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) V[(o + i) * SD + o + lane] = x[i];
+        }
+    }
+    __syncthreads();
+    CSTAMP(21);
     // inverse by recursive doubling over 16-blocks: [L11 0; L21 L22]^-1 = [V11 0; -V22 L21 V11, V22]
-    for (int sz = 16; sz < 64; sz *= 2) {
-        const int nodes = 64 / (2 * sz);
-        // T = L21 * V11   (L21: rows o+sz.., cols o..o+sz; V11 lower triangular)
-        for (int e = t; e < nodes * sz * sz; e += 256) {
-            int nd = e / (sz * sz), q = e % (sz * sz), i = q / sz, j = q % sz, o = nd * 2 * sz;
-            double acc = 0.0;
-            for (int k = j; k < sz; k++) acc = fma(S[(o + sz + i) * SD + o + k], V[(o + k) * SD + o + j], acc);
-            T[(o + sz + i) * SD + o + j] = acc;
-        }
-        __syncthreads();
-        // V21 = -V22 * T   (V22 lower triangular)
-        for (int e = t; e < nodes * sz * sz; e += 256) {
-            int nd = e / (sz * sz), q = e % (sz * sz), i = q / sz, j = q % sz, o = nd * 2 * sz;
-            double acc = 0.0;
-            for (int k = 0; k <= i; k++) acc = fma(V[(o + sz + i) * SD + o + sz + k], T[(o + sz + k) * SD + o + j], acc);
-            V[(o + sz + i) * SD + o + j] = -acc;
-        }
-        __syncthreads();
+    // level 16: two nodes (o = 0, 32), one tile each
+    if (wv < 2) {
+        const int o = 32 * wv;
+        d4_t acc = lds_mm16<false, 16>(S + (o + 16) * SD + o, V + o * SD + o);
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[(o + 16 + MM16_ROW(r)) * SD + o + MM16_COL] = acc[r];
+        // the same wave consumes its own T tile: LDS operations of one wave complete in order
+        acc = lds_mm16<false, 16>(V + (o + 16) * SD + o + 16, T + (o + 16) * SD + o);
+#pragma unroll
+        for (int r = 0; r < 4; r++) V[(o + 16 + MM16_ROW(r)) * SD + o + MM16_COL] = -acc[r];
     }
+    __syncthreads();
+    // level 32: one node, 2x2 tiles
+    {
+        const int ti = wv >> 1, tj = wv & 1;
+        d4_t acc = lds_mm16<false, 32>(S + (32 + 16 * ti) * SD, V + 16 * tj);
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[(32 + 16 * ti + MM16_ROW(r)) * SD + 16 * tj + MM16_COL] = acc[r];
+        __syncthreads();
+        acc = lds_mm16<false, 32>(V + (32 + 16 * ti) * SD + 32, T + 32 * SD + 16 * tj);
+#pragma unroll
+        for (int r = 0; r < 4; r++) V[(32 + 16 * ti + MM16_ROW(r)) * SD + 16 * tj + MM16_COL] = -acc[r];
+    }
+    __syncthreads();
+    CSTAMP(22);
     double *Db = diag64 + (size_t)jb * 4096;
-    for (int e = t; e < 4096; e += 256) {
-        int r = e >> 6, c = e & 63;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int r = 4 * u + (t >> 6), c = t & 63;
         Lb[(size_t)r * Npad + c] = (c <= r) ? S[r * SD + c] : 0.0;
-        Db[e] = V[r * SD + c];
+        Db[r * 64 + c] = V[r * SD + c];
     }
+    CSTAMP(23);
 }
 
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
 __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, int Npad, int jb,
                                                         const double *__restrict__ diag64)
 {
-    __shared__ double As[64 * AS_LD];
-    __shared__ double Bs[16 * BS_LD];
+    __shared__ double As[64 * T64_LD];
+    __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
     int ib = jb + 1 + blockIdx.x;
     double *Ab = L + (size_t)ib * 64 * Npad + jb * 64;
+    double2 va[8], vb[8];
+    tile64_fetch(Ab, Npad, va);
+    tile64_fetch(diag64 + (size_t)jb * 4096, 64, vb);
+    tile64_stash(As, va);
+    tile64_stash(Bs, vb);
+    __syncthreads();
     d4_t acc[2][2] = {};
-    gemm_tile_64<true>(Ab, Npad, diag64 + (size_t)jb * 4096, 64, 0, 64, acc, As, Bs);
-    // every read of this tile happened before the last barrier inside gemm_tile_64
+    tile64_mma_nt(As, Bs, acc);
+    // the tile is overwritten in place: it was read completely before the barrier
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -314,8 +410,8 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, 
 // trailing update: A[i][k] -= L[i][jb] L[k][jb]^T for jb < k <= i
 __global__ __launch_bounds__(256) void chol_syrk_kernel(double *__restrict__ L, int Npad, int jb)
 {
-    __shared__ double As[64 * AS_LD];
-    __shared__ double Bs[64 * AS_LD];
+    __shared__ double As[64 * T64_LD];
+    __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
     int tix = blockIdx.x;
     int ii = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
@@ -323,20 +419,28 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double *__restrict__ L, 
     while (ii * (ii + 1) / 2 > tix) ii--;
     int kk = tix - ii * (ii + 1) / 2;
     int i = jb + 1 + ii, k = jb + 1 + kk;
-    const double *Ai = L + (size_t)i * 64 * Npad + jb * 64;
-    const double *Ak = L + (size_t)k * 64 * Npad + jb * 64;
     double *C = L + (size_t)i * 64 * Npad + k * 64;
-    d4_t acc[2][2] = {};
-    gemm_tile_64<true>(Ai, Npad, Ak, Npad, 0, 64, acc, As, Bs);
+    double2 va[8], vb[8];
+    tile64_fetch(L + (size_t)i * 64 * Npad + jb * 64, Npad, va);
+    tile64_fetch(L + (size_t)k * 64 * Npad + jb * 64, Npad, vb);
+    double c[2][2][4];                              // the tile being updated: fetched alongside the operands
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                size_t o = (size_t)TILE_ROW(m, r) * Npad + TILE_COL(n);
-                C[o] -= acc[m][n][r];
-            }
+            for (int r = 0; r < 4; r++) c[m][n][r] = C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)];
+    tile64_stash(As, va);
+    tile64_stash(Bs, vb);
+    __syncthreads();
+    d4_t acc[2][2] = {};
+    tile64_mma_nt(As, Bs, acc);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = c[m][n][r] - acc[m][n][r];
 }
 
 int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s)
@@ -607,10 +711,15 @@ __global__ __launch_bounds__(256) void gemvT_lower2_kernel(const double *__restr
     if (j >= Npad) return;
     double s0 = 0.0, s1 = 0.0;
     int i0 = c * 64;
-    for (int i = max(i0, j); i < i0 + 64; i++) {
-        double v = W[(size_t)i * Npad + j];
-        s0 += v * t2[i];
-        s1 += v * t2[Npad + i];
+    // W is stored with explicit zeros above the diagonal: a fixed trip count lets the loads be batched
+    // (a dependent loop from max(i0, j) exposes the memory latency 64 times)
+    if (i0 + 63 >= blockIdx.x * 256) {
+#pragma unroll 16
+        for (int i = i0; i < i0 + 64; i++) {
+            double v = W[(size_t)i * Npad + j];
+            s0 = fma(v, t2[i], s0);
+            s1 = fma(v, t2[Npad + i], s1);
+        }
     }
     int nch = Npad / 64;
     partial[(size_t)c * Npad + j] = s0;

@@ -1,0 +1,55 @@
+// Diagnostic: per-segment cycle stamps of chol_diag_kernel (built with -DIBO_STAMPS) on one 64x64 block.
+//   hipcc --offload-arch=gfx950 -O3 -DIBO_STAMPS -I ibo_amd/csrc tools/chol_diag_bench.hip -o tools/chol_diag_bench
+#include "../ibo_amd/csrc/linalg.hip"
+#include <cstdio>
+#include <vector>
+int main()
+{
+    const int n = 64;
+    std::vector<double> A(n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) A[i * n + j] = (i == j ? 1.1 : 0.0) + exp(-0.5 * (i - j) * (i - j) / 40.0);
+    double *dA, *dD; int *info;
+    hipMalloc(&dA, sizeof(double) * n * n); hipMalloc(&dD, sizeof(double) * n * n); hipMalloc(&info, 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; rep++) {
+        hipMemcpy(dA, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
+        hipMemset(info, 0, 4);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, 0, dA, n, 0, dD, info);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long st[32];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_chol_stamps), sizeof(st));
+        printf("rep %d: %.1f us by events; total stamps %llu ticks\n", rep, ms * 1e3, st[23] - st[31]);
+        printf("  load %llu  sync %llu\n", st[0] - st[31], st[1] - st[0]);
+        unsigned long long prev = st[1];
+        for (int b = 0; b < 4; b++) {
+            printf("  panel %d: chol %llu  sync %llu  (iii) %llu\n", b, st[2 + 5 * b] - prev,
+                   st[4 + 5 * b] - st[2 + 5 * b], st[6 + 5 * b] - st[4 + 5 * b]);
+            prev = st[6 + 5 * b];
+        }
+        printf("  inverses %llu  doubling %llu  store %llu\n", st[21] - prev, st[22] - st[21], st[23] - st[22]);
+    }
+    std::vector<double> Lh(n * n);
+    hipMemcpy(Lh.data(), dA, sizeof(double) * n * n, hipMemcpyDeviceToHost);
+    double err = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = 0;
+            for (int k = 0; k <= j; k++) s += Lh[i * n + k] * Lh[j * n + k];
+            err = fmax(err, fabs(s - A[i * n + j]));
+        }
+    std::vector<double> Vh(n * n);
+    hipMemcpy(Vh.data(), dD, sizeof(double) * n * n, hipMemcpyDeviceToHost);
+    double err2 = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += Vh[i * n + k] * (k >= j ? Lh[k * n + j] : 0.0);
+            err2 = fmax(err2, fabs(s - (i == j)));
+        }
+    printf("max |L L^T - A| = %.3e   max |V L - I| = %.3e\n", err, err2);
+    return 0;
+}
