@@ -41,6 +41,7 @@ static int fail(int code, const char *fmt, ...)
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
 extern int g_sweep_variant;     // sweep.hip
+static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
 
@@ -132,6 +133,8 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "sweep_path")) { g_force_path = value; return IBO_OK; }
     if (key && !strcmp(key, "sweep_variant")) { g_sweep_variant = value; return IBO_OK; }
     if (key && !strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
+    if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
+    if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
 
@@ -759,32 +762,43 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     if (!X || !Y || !thetas || !nlml_host || N < 1 || n_theta < 1) return fail(IBO_ERR_ARG, "bad argument");
     IBO_TRY(use_device(device));
     const int Np = round_up(N + 1, 64);            // room for the appended y row (see aug_row_kernel)
-    // theta-points are independent and each factorisation is a latency-bound chain of small
-    // kernels: run up to four of them concurrently on their own streams and buffers
-    const int NS = n_theta < 4 ? n_theta : 4;
-    DevBuf<double> dX, dY, dout, dL[4], d64[4];
+    // theta-points are independent and one factorisation is a latency-bound chain of small kernels:
+    // B matrices sit side by side in HBM (B x 8 Np^2 bytes -- 4.4 GB for 32 x N=4096, nothing on a 288 GB
+    // part) and every launch of the chain works on all of them (blockIdx.z), so the chain's latency is
+    // paid once per batch and the update kernels fill the chip.
+    const size_t nn = (size_t)Np * Np;
+    int B;
+    {
+        const size_t budget = (size_t)6 << 30;     // bytes of factor storage per batch
+        size_t fit = budget / (nn * sizeof(double));
+        if (fit < 1) fit = 1;
+        if (fit > 32) fit = 32;
+        B = g_nlml_batch > 0 ? g_nlml_batch : (int)fit;
+        if (B > n_theta) B = n_theta;
+    }
+    DevBuf<double> dX, dY, dout, dL, d64;
     DevBuf<int> dinfo;
-    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t s = nullptr;
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N));
     IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
+    IBO_TRY(dL.ensure(nn * B)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096 * B));
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
-    for (int k = 0; k < NS; k++) {
-        IBO_TRY(dL[k].ensure((size_t)Np * Np)); IBO_TRY(d64[k].ensure((size_t)(Np / 64) * 4096));
-        HIP_TRY(hipStreamCreate(&st[k]));
-        // identity pad once: the factorisation leaves the pad rows/columns as it found them
-        KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL[k].p, Np, 1.0, st[k]));
+    // identity pad once: the factorisation leaves the pad rows/columns as it found them
+    for (int k = 0; k < B; k++) KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p + nn * k, Np, 1.0, s));
+    for (int t0 = 0; t0 < n_theta; t0 += B) {
+        const int nb = n_theta - t0 < B ? n_theta - t0 : B;
+        for (int k = 0; k < nb; k++) {
+            const int t = t0 + k;
+            KParams kp;
+            IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
+            KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, s));
+            KERNEL_TRY(launch_nlml_aug(dL.p + nn * k, Np, N, dY.p, s));
+        }
+        KERNEL_TRY(launch_cholesky_batched(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s));
+        for (int k = 0; k < nb; k++) KERNEL_TRY(launch_nlml_reduce(dL.p + nn * k, Np, N, dout.p + 2 * (t0 + k), s));
     }
-    for (int t = 0; t < n_theta; t++) {
-        const int k = t % NS;
-        KParams kp;
-        IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
-        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL[k].p, Np, st[k]));
-        KERNEL_TRY(launch_nlml_aug(dL[k].p, Np, N, dY.p, st[k]));
-        KERNEL_TRY(launch_cholesky(dL[k].p, Np, d64[k].p, dinfo.p + t, st[k]));
-        KERNEL_TRY(launch_nlml_reduce(dL[k].p, Np, N, dout.p + 2 * t, st[k]));
-    }
-    for (int k = 0; k < NS; k++) HIP_TRY(hipStreamSynchronize(st[k]));
+    HIP_TRY(hipStreamSynchronize(s));
     std::vector<double> out(2 * (size_t)n_theta);
     std::vector<int> info(n_theta);
     HIP_TRY(hipMemcpy(out.data(), dout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
@@ -792,8 +806,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     const double half_log_2pi_n = 0.5 * N * log(2.0 * M_PI);
     for (int t = 0; t < n_theta; t++)
         nlml_host[t] = info[t] ? NAN : 0.5 * out[2 * t] + out[2 * t + 1] + half_log_2pi_n;
-    dX.release(); dY.release(); dout.release(); dinfo.release();
-    for (int k = 0; k < NS; k++) { dL[k].release(); d64[k].release(); (void)hipStreamDestroy(st[k]); }
+    dX.release(); dY.release(); dout.release(); dinfo.release(); dL.release(); d64.release();
     return IBO_OK;
 }
 

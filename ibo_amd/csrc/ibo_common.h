@@ -182,6 +182,9 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the
 // inverses of the 64x64 diagonal blocks; info (device int) gets the 1-based failing pivot or 0
 int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s);
+int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
+                            int panel, hipStream_t s);
+void set_chol_panel(int p);
 // W = L^-1 (row-major, ld = Npad) using diag64 from launch_cholesky and a scratch T (Npad x Npad)
 int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s);
 // zero the strict upper triangle (ld = Npad)

@@ -17,27 +17,51 @@
 // ------------------------------------------------------------------------
 // covariance matrix  K[i][j] = k(A1_i, A2_j)
 // ------------------------------------------------------------------------
-__global__ void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
-                                  const double *__restrict__ A2, int ldp, int square, int diag_rule,
-                                  double noise, double *__restrict__ K, int ldk)
+// 16 rows x 64 columns of K per workgroup: the tile's points and the ARD weights are staged in LDS once,
+// a thread keeps one column point against four row points, stores are 512-byte rows.
+// (z is accumulated in the reference's order: sum_d w_d (a_d - b_d)^2.)
+__global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
+                                                         const double *__restrict__ A2, int ldp, int square,
+                                                         int diag_rule, double noise, double *__restrict__ K, int ldk)
 {
-    int j = blockIdx.x * 16 + (threadIdx.x & 15);
-    int i = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (i >= n1 || j >= n2) return;
-    const double *a = A1 + (size_t)i * ldp;
-    const double *b = A2 + (size_t)j * ldp;
-    double z = 0.0;
-    for (int d = 0; d < kp.D; d++) {
-        double t = a[d] - b[d];
-        z += kp.w[d] * (t * t);
+    __shared__ double As[16 * 16], Bs[64 * 17], ws[16];
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 16, D = kp.D;
+#pragma unroll
+    for (int d = 0; d < 16; d++)
+        if (t == d) ws[d] = kp.w[d];
+    for (int e = t; e < 16 * D; e += 256) {
+        int r = e / D, d = e - r * D;
+        As[r * 16 + d] = (i0 + r < n1) ? A1[(size_t)(i0 + r) * ldp + d] : 0.0;
     }
-    double v = cov_from_z_rt(kp.family, z, kp.sf2);
-    if (square && i == j) {
-        // diag_rule 0: the reference never calls the kernel on the diagonal and
-        // hard-wires 1+noise (ego/gaussianprocess/__init__.py:138)
-        v = (diag_rule == 0) ? (1.0 + noise) : (v + noise);
+    for (int e = t; e < 64 * D; e += 256) {
+        int c = e / D, d = e - c * D;
+        Bs[c * 17 + d] = (j0 + c < n2) ? A2[(size_t)(j0 + c) * ldp + d] : 0.0;
     }
-    K[(size_t)i * ldk + j] = v;
+    __syncthreads();
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int d = 0; d < D; d++) {
+        const double b = Bs[tx * 17 + d], w = ws[d];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double u = As[(ty * 4 + r) * 16 + d] - b;
+            z[r] += w * (u * u);
+        }
+    }
+    const int j = j0 + tx;
+    if (j >= n2) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = i0 + ty * 4 + r;
+        if (i >= n1) break;
+        double v = cov_from_z_rt(kp.family, z[r], kp.sf2);
+        if (square && i == j) {
+            // diag_rule 0: the reference never calls the kernel on the diagonal and
+            // hard-wires 1+noise (ego/gaussianprocess/__init__.py:138)
+            v = (diag_rule == 0) ? (1.0 + noise) : (v + noise);
+        }
+        K[(size_t)i * ldk + j] = v;
+    }
 }
 
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
@@ -45,7 +69,7 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
 {
     int square = (A2 == nullptr);
     if (square) { A2 = A1; n2 = n1; }
-    dim3 grid((n2 + 15) / 16, (n1 + 15) / 16);
+    dim3 grid((n2 + 63) / 64, (n1 + 15) / 16);
     hipLaunchKernelGGL(cov_matrix_kernel, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
                        diag_rule, noise, K, ldk);
     return (int)hipGetLastError();
@@ -171,11 +195,13 @@ __device__ __forceinline__ void tile64_fetch(const double *__restrict__ A, int l
 #pragma unroll
     for (int u = 0; u < 8; u++) v[u] = *(const double2 *)(A + (size_t)(8 * u + (t >> 5)) * lda + (t & 31) * 2);
 }
+template <bool NEG = false>
 __device__ __forceinline__ void tile64_stash(double *As, const double2 (&v)[8])
 {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < 8; u++) *(double2 *)(As + (8 * u + (t >> 5)) * T64_LD + (t & 31) * 2) = v[u];
+    for (int u = 0; u < 8; u++)
+        *(double2 *)(As + (8 * u + (t >> 5)) * T64_LD + (t & 31) * 2) = NEG ? make_double2(-v[u].x, -v[u].y) : v[u];
 }
 __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs, d4_t (&acc)[2][2])
 {
@@ -256,12 +282,14 @@ __device__ __forceinline__ double rcp_newton(double d)
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, int Npad, int jb,
-                                                        double *__restrict__ diag64, int *info)
+                                                        double *__restrict__ diag64, int *info,
+                                                        size_t lstride, size_t dstride)
 {
     __shared__ double S[64 * SD];          // the block; ends up holding L (lower)
     __shared__ double V[64 * SD];          // its inverse
     __shared__ double T[64 * SD];          // scratch (L21 * V11 products)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride; info += blockIdx.z;      // batch member
     double *Lb = L + (size_t)jb * 64 * Npad + jb * 64;
     CSTAMP(31);
     {
@@ -383,11 +411,13 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
 
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
 __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, int Npad, int jb,
-                                                        const double *__restrict__ diag64)
+                                                        const double *__restrict__ diag64,
+                                                        size_t lstride, size_t dstride)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
+    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
     int ib = jb + 1 + blockIdx.x;
     double *Ab = L + (size_t)ib * 64 * Npad + jb * 64;
     double2 va[8], vb[8];
@@ -407,55 +437,122 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, 
             for (int r = 0; r < 4; r++) Ab[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
 }
 
-// trailing update: A[i][k] -= L[i][jb] L[k][jb]^T for jb < k <= i
-__global__ __launch_bounds__(256) void chol_syrk_kernel(double *__restrict__ L, int Npad, int jb)
+// update with finished block columns [j0, j1):  A[i][k] -= sum_j L[i][j] L[k][j]^T  for the block columns
+// k in [k0, k1) and the block rows i >= k.  One 64x64 tile per workgroup; the K loop runs in 64-wide stages
+// with the next stage's operands (and, first, the tile itself) in flight.
+// Tile order is XCD-aware: workgroups go round-robin to the 8 XCDs, each with its own 4 MiB L2, so
+// workgroup b belongs to XCD b % 8 and that XCD's 64 consecutive workgroups are given one 8x8 super-block
+// of tiles -- 16 operand strips of 64 x 64(j1-j0) serve 64 tiles out of L2 instead of being re-fetched
+// from the Infinity Cache (with the operands also kept out of scratch, K = 256 updates went from 18 to 35 TFLOP/s at N = 4096).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void chol_update_kernel(double *__restrict__ L, int Npad, int j0, int j1,
+                                                          int k0, int k1, int nsb, size_t lstride)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
-    int tix = blockIdx.x;
-    int ii = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
-    while ((ii + 1) * (ii + 2) / 2 <= tix) ii++;
-    while (ii * (ii + 1) / 2 > tix) ii--;
-    int kk = tix - ii * (ii + 1) / 2;
-    int i = jb + 1 + ii, k = jb + 1 + kk;
+    L += blockIdx.z * lstride;
+    const int nb = Npad / 64;
+    int i, k;
+    if (nsb > 0) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int sb = (q >> 6) * 8 + xcd, lt = q & 63;
+        if (sb >= nsb) return;
+        const int nsr = (nb - k0 + 7) / 8;          // super-block rows; (SK, SI >= SK) numbered column by column
+        int SK = 0, rem = sb;
+        while (rem >= nsr - SK) { rem -= nsr - SK; SK++; }
+        k = k0 + 8 * SK + (lt & 7), i = k0 + 8 * (SK + rem) + (lt >> 3);
+        if (k >= k1 || i >= nb || i < k) return;
+    } else {                                        // few tiles (all resident at once): plain column-by-column numbering
+        int rem = blockIdx.x;
+        k = k0;
+        while (rem >= nb - k) { rem -= nb - k; k++; }
+        i = k + rem;
+    }
     double *C = L + (size_t)i * 64 * Npad + k * 64;
+    const double *Ai = L + (size_t)i * 64 * Npad, *Ak = L + (size_t)k * 64 * Npad;
     double2 va[8], vb[8];
-    tile64_fetch(L + (size_t)i * 64 * Npad + jb * 64, Npad, va);
-    tile64_fetch(L + (size_t)k * 64 * Npad + jb * 64, Npad, vb);
-    double c[2][2][4];                              // the tile being updated: fetched alongside the operands
+    tile64_fetch(Ai + j0 * 64, Npad, va);
+    tile64_fetch(Ak + j0 * 64, Npad, vb);
+    // the accumulators start as the tile itself (fetched alongside the first operands) and the A strip is
+    // negated on its way into LDS: acc = C - A B^T with no second copy of the tile in registers
+    d4_t acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) c[m][n][r] = C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)];
-    tile64_stash(As, va);
-    tile64_stash(Bs, vb);
-    __syncthreads();
-    d4_t acc[2][2] = {};
-    tile64_mma_nt(As, Bs, acc);
+            for (int r = 0; r < 4; r++) acc[m][n][r] = C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)];
+    for (int j = j0; j < j1; j++) {
+        tile64_stash<true>(As, va);
+        tile64_stash(Bs, vb);
+        __syncthreads();
+        if (j + 1 < j1) {
+            tile64_fetch(Ai + (j + 1) * 64, Npad, va);
+            tile64_fetch(Ak + (j + 1) * 64, Npad, vb);
+        }
+        tile64_mma_nt(As, Bs, acc);
+        if (j + 1 < j1) __syncthreads();
+    }
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = c[m][n][r] - acc[m][n][r];
+            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
+}
+
+static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,
+                          hipStream_t s)
+{
+    const int nb = Npad / 64, nsr = (nb - k0 + 7) / 8, nsc = (k1 - k0 + 7) / 8;
+    int tiles = 0;
+    for (int k = k0; k < k1; k++) tiles += nb - k;
+    if ((size_t)tiles * batch <= 512) {
+        hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1, 0, lstride);
+        return;
+    }
+    int nsb = 0;
+    for (int c = 0; c < nsc; c++) nsb += nsr - c;
+    const int groups = (nsb + 7) / 8;                // every XCD gets `groups` super-blocks of 64 workgroups
+    hipLaunchKernelGGL(chol_update_kernel, dim3(groups * 512, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1,
+                       nsb, lstride);
+}
+
+// `batch` matrices, `lstride` doubles apart (diag64: (Npad/64)*4096 apart, info: consecutive ints), are
+// factored by the same launches (blockIdx.z).  panel = 1 is the plain right-looking order (shortest chain:
+// one matrix, small N); panel = P > 1 keeps the per-column updates inside a P-block panel and applies the
+// panel to the rest of the matrix once, with K = 64 P (fewer passes over the trailing matrix: large N, batches).
+static int g_chol_panel = 0;                         // 0 = choose; ibo_set_option("chol_panel", P)
+void set_chol_panel(int p) { g_chol_panel = p; }
+
+int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
+                            int panel, hipStream_t s)
+{
+    const int nb = Npad / 64;
+    const size_t dstride = (size_t)nb * 4096;
+    // the panel width fixes the order of the floating-point sums, so it may depend on the matrix size and
+    // on the entry point but never on how many matrices share the launches
+    const int P = g_chol_panel > 0 ? g_chol_panel : panel;
+    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
+    for (int p0 = 0; p0 < nb; p0 += P) {
+        const int pend = p0 + P < nb ? p0 + P : nb;
+        for (int jb = p0; jb < pend; jb++) {
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, info_dev,
+                               lstride, dstride);
+            const int m = nb - jb - 1;
+            if (m > 0)
+                hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, lstride,
+                                   dstride);
+            if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s);
+        }
+        if (pend < nb) launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
+    }
+    return (int)hipGetLastError();
 }
 
 int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s)
 {
-    int nb = Npad / 64;
-    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
-    for (int jb = 0; jb < nb; jb++) {
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, L, Npad, jb, diag64, info_dev);
-        int m = nb - jb - 1;
-        if (m > 0) {
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3(m), dim3(256), 0, s, L, Npad, jb, diag64);
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(m * (m + 1) / 2), dim3(256), 0, s, L, Npad, jb);
-        }
-    }
-    return (int)hipGetLastError();
+    return launch_cholesky_batched(L, Npad, diag64, info_dev, 1, 0, Npad / 64 > 32 ? 4 : 1, s);
 }
 
 // ------------------------------------------------------------------------

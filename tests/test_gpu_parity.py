@@ -563,6 +563,35 @@ def test_c5_nlml_full_size(ibo, oracle):
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[1:2], X, Y, noise=1e-3)[0], vals[1:2])   # deterministic
 
 
+def test_cholesky_panel_orders_agree(ibo):
+    """the two-level (panel = 4 block columns, K = 256 updates) and the plain right-looking factorisation give
+    the same factor to rounding; the batched NLML grid does not depend on what shares its launches"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid
+    X, Y = synth(9, 1000, 5)
+    Ls = []
+    for panel in (1, 4, 3):
+        _lib.check(_lib.lib.ibo_set_option(b"chol_panel", panel))
+        try:
+            Ls.append(GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05).L)
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"chol_panel", 0))
+    Lr = np.linalg.cholesky(GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05).R)
+    for L in Ls:
+        assert np.abs(L - Lr).max() < 1e-12
+    thetas = np.exp(np.random.RandomState(3).uniform(np.log(.2), np.log(2), size=(7, 5)))
+    vals, _ = nlml_grid(GaussianKernel_ard, thetas, X[:300], Y[:300], noise=.01)
+    for b in (1, 2, 7):
+        _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", b))
+        try:
+            assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas, X[:300], Y[:300], noise=.01)[0], vals)
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 0))
+    assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[4:5], X[:300], Y[:300], noise=.01)[0], vals[4:5])
+
+
 def test_add_observation_point_augmented_variance(ibo, oracle):
     """PrefGaussianProcess.addObservationPoint (ego/gaussianprocess/__init__.py:214-223,502-519): the mean keeps
     using L = chol(R + C^-1), the variance switches to the factor of the augmented matrix"""
