@@ -17,7 +17,7 @@ this package without the built library raises.
 import sys
 
 from . import _lib                                      # noqa: F401  (raises if the .so is missing)
-from ._lib import DeviceArray, IBOError, NotPositiveDefinite, device_count      # noqa: F401
+from ._lib import DeviceArray, IBOError, NotPositiveDefinite, device_count, trim      # noqa: F401
 
 __version__ = "0.1.0"
 

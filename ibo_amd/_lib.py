@@ -58,6 +58,7 @@ _sig("ibo_device_count", c_int, POINTER(c_int))
 _sig("ibo_device_name", c_int, c_int, c_char_p, c_size_t)
 _sig("ibo_selftest_mfma", c_int, c_int, _DP)
 _sig("ibo_set_option", c_int, c_char_p, c_int)
+_sig("ibo_trim", c_int, c_int)
 _sig("ibo_dev_alloc", c_int, c_int, c_size_t, POINTER(c_void_p))
 _sig("ibo_dev_free", c_int, c_int, c_void_p)
 _sig("ibo_memcpy_h2d", c_int, c_int, c_void_p, c_void_p, c_size_t)
@@ -101,7 +102,7 @@ _sig("acqmaxGP", _DP, c_int, _DP, _DP, _DP, _DP, _DP, c_int, c_int, c_int, _DP, 
 _sig("direct", _DP, OBJECTIVE, c_int, _DP, _DP, c_int, c_int, c_int)
 
 EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device_name", "ibo_selftest_mfma",
-            "ibo_set_option", "ibo_dev_alloc", "ibo_dev_free", "ibo_memcpy_h2d", "ibo_memcpy_d2h",
+            "ibo_set_option", "ibo_trim", "ibo_dev_alloc", "ibo_dev_free", "ibo_memcpy_h2d", "ibo_memcpy_d2h",
             "ibo_device_synchronize", "ibo_gp_create", "ibo_gp_destroy", "ibo_gp_fit", "ibo_gp_fit_with_matrix",
             "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
             "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_spd_solve", "ibo_spd_inverse", "ibo_posterior_batch",
@@ -131,6 +132,11 @@ def device_count():
     n = c_int(0)
     check(lib.ibo_device_count(ctypes.byref(n)))
     return n.value
+
+
+def trim(device=None):
+    """give back the device workspace ibo_nlml_grid keeps between calls"""
+    check(lib.ibo_trim(default_device() if device is None else int(device)))
 
 
 def default_device():

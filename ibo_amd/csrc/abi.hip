@@ -755,6 +755,20 @@ extern "C" int ibo_direct_max(ibo_gp_t *g, int D, const double *lb, const double
 }
 
 // ------------------------------------------------------------------------ marginal-likelihood grid
+struct NlmlWorkspace {
+    DevBuf<double> dX, dY, dout, dL, d64;
+    DevBuf<int> dinfo;
+};
+static NlmlWorkspace g_nlml_ws[16];
+
+extern "C" int ibo_trim(int device)
+{
+    IBO_TRY(use_device(device));
+    NlmlWorkspace &ws = g_nlml_ws[device & 15];
+    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dinfo.release();
+    return IBO_OK;
+}
+
 extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *X, const double *Y,
                              int n_theta, const double *thetas, int nhyper, const double *sf2s, double noise,
                              double *nlml_host)
@@ -776,8 +790,11 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         B = g_nlml_batch > 0 ? g_nlml_batch : (int)fit;
         if (B > n_theta) B = n_theta;
     }
-    DevBuf<double> dX, dY, dout, dL, d64;
-    DevBuf<int> dinfo;
+    // the workspace is kept between calls (hyper-parameter learning calls this in a loop and allocating and
+    // freeing gigabytes costs more than the factorisations); ibo_trim() gives it back
+    NlmlWorkspace &ws = g_nlml_ws[device & 15];
+    DevBuf<double> &dX = ws.dX, &dY = ws.dY, &dout = ws.dout, &dL = ws.dL, &d64 = ws.d64;
+    DevBuf<int> &dinfo = ws.dinfo;
     hipStream_t s = nullptr;
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N));
     IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
@@ -806,7 +823,6 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     const double half_log_2pi_n = 0.5 * N * log(2.0 * M_PI);
     for (int t = 0; t < n_theta; t++)
         nlml_host[t] = info[t] ? NAN : 0.5 * out[2 * t] + out[2 * t + 1] + half_log_2pi_n;
-    dX.release(); dY.release(); dout.release(); dinfo.release(); dL.release(); d64.release();
     return IBO_OK;
 }
 

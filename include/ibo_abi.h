@@ -244,6 +244,8 @@ int ibo_nlml_grid(int device, int ktype, int N, int D,
                   int n_theta, const double *thetas_host, int nhyper,
                   const double *sf2_host /* n_theta or NULL (=1) */, double noise,
                   double *nlml_host);
+/* ibo_nlml_grid keeps its device workspace (the batch of factor matrices) between calls; this releases it. */
+int ibo_trim(int device);
 
 /*
  * NLML and its gradient w.r.t. each LOG hyper-parameter for one theta: marginalLikelihood(...,
