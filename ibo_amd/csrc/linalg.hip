@@ -189,19 +189,19 @@ __device__ __forceinline__ void gemm_tile_64(const double *__restrict__ A, int l
 // every load in flight at once -- one global-memory latency instead of four.  acc += A * B^T.
 // As, Bs: 64 * T64_LD doubles each.
 #define T64_LD 68
-__device__ __forceinline__ void tile64_fetch(const double *__restrict__ A, int lda, double2 (&v)[8])
+typedef double d2_t __attribute__((ext_vector_type(2)));   // (HIP's double2 struct arrays end up in scratch here)
+__device__ __forceinline__ void tile64_fetch(const double *__restrict__ A, int lda, d2_t (&v)[8])
 {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = *(const double2 *)(A + (size_t)(8 * u + (t >> 5)) * lda + (t & 31) * 2);
+    for (int u = 0; u < 8; u++) v[u] = *(const d2_t *)(A + (size_t)(8 * u + (t >> 5)) * lda + (t & 31) * 2);
 }
-template <bool NEG = false>
-__device__ __forceinline__ void tile64_stash(double *As, const double2 (&v)[8])
+template <bool NEG = false, int LD = T64_LD>
+__device__ __forceinline__ void tile64_stash(double *As, const d2_t (&v)[8])
 {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < 8; u++)
-        *(double2 *)(As + (8 * u + (t >> 5)) * T64_LD + (t & 31) * 2) = NEG ? make_double2(-v[u].x, -v[u].y) : v[u];
+    for (int u = 0; u < 8; u++) *(d2_t *)(As + (8 * u + (t >> 5)) * LD + (t & 31) * 2) = NEG ? -v[u] : v[u];
 }
 __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs, d4_t (&acc)[2][2])
 {
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, 
     L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
     int ib = jb + 1 + blockIdx.x;
     double *Ab = L + (size_t)ib * 64 * Npad + jb * 64;
-    double2 va[8], vb[8];
+    d2_t va[8], vb[8];
     tile64_fetch(Ab, Npad, va);
     tile64_fetch(diag64 + (size_t)jb * 4096, 64, vb);
     tile64_stash(As, va);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     double *C = L + (size_t)i * 64 * Npad + k * 64;
     const double *Ai = L + (size_t)i * 64 * Npad, *Ak = L + (size_t)k * 64 * Npad;
-    double2 va[8], vb[8];
+    d2_t va[8], vb[8];
     tile64_fetch(Ai + j0 * 64, Npad, va);
     tile64_fetch(Ak + j0 * 64, Npad, vb);
     // the accumulators start as the tile itself (fetched alongside the first operands) and the A strip is
@@ -569,11 +569,48 @@ __global__ __launch_bounds__(256) void trinv_place_diag_kernel(const double *__r
     for (int e = threadIdx.x; e < 4096; e += 256) Wb[(size_t)(e >> 6) * Npad + (e & 63)] = Db[e];
 }
 
-__global__ __launch_bounds__(256) void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W,
-                                                      double *__restrict__ T, int Npad, int s, int nb)
+// acc += sum over 64-blocks kb in [kb0, kb1) of A[:, kb] * B[kb, :]  (A, B row-major 64-row strips; the
+// 64x64 tiles of stage kb+1 are in flight while stage kb is on the MFMAs).  Bs is 64 x TNN_LD: with a row
+// stride of 80 doubles the four k-rows of a B fragment fall on disjoint bank halves.
+#define TNN_LD 80
+__device__ __forceinline__ void tile64_gemm_nn(const double *__restrict__ A, int lda, const double *__restrict__ B,
+                                               int ldb, int kb0, int kb1, d4_t (&acc)[2][2], double *As, double *Bs)
 {
-    __shared__ double As[64 * AS_LD];
-    __shared__ double Bs[16 * BS_LD];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
+    if (kb0 >= kb1) return;
+    d2_t va[8], vb[8];
+    tile64_fetch(A + (size_t)kb0 * 64, lda, va);
+    tile64_fetch(B + (size_t)kb0 * 64 * ldb, ldb, vb);
+    for (int kb = kb0; kb < kb1; kb++) {
+        tile64_stash(As, va);
+        tile64_stash<false, TNN_LD>(Bs, vb);
+        __syncthreads();
+        if (kb + 1 < kb1) {
+            tile64_fetch(A + (size_t)(kb + 1) * 64, lda, va);
+            tile64_fetch(B + (size_t)(kb + 1) * 64 * ldb, ldb, vb);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 16; k4++) {
+            double a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++) a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * T64_LD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+            for (int n = 0; n < 2; n++) b[n] = Bs[(k4 * 4 + (lane >> 4)) * TNN_LD + wc * 32 + n * 16 + (lane & 15)];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[m][n] = mfma_f64(a[m], b[n], acc[m][n]);
+        }
+        if (kb + 1 < kb1) __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W, double *__restrict__ T, int Npad,
+                    int s, int nb)
+{
+    __shared__ double As[64 * T64_LD];
+    __shared__ double Bs[64 * TNN_LD];
     TILE_IDS;
     int o = blockIdx.y * 2 * s;
     int r = min(s, nb - o - s);
@@ -582,7 +619,7 @@ __global__ __launch_bounds__(256) void trinv_T_kernel(const double *__restrict__
     const double *A = L + (size_t)(o + s + ti) * 64 * Npad + (size_t)o * 64;
     const double *B = W + (size_t)o * 64 * Npad + (size_t)(o + tj) * 64;
     d4_t acc[2][2] = {};
-    gemm_tile_64<false>(A, Npad, B, Npad, tj * 64, s * 64, acc, As, Bs);
+    tile64_gemm_nn(A, Npad, B, Npad, tj, s, acc, As, Bs);           // W11 is lower triangular: k-blocks >= tj
     double *C = T + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + tj) * 64;
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -592,11 +629,11 @@ __global__ __launch_bounds__(256) void trinv_T_kernel(const double *__restrict__
             for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
 }
 
-__global__ __launch_bounds__(256) void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T,
-                                                      int Npad, int s, int nb)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T, int Npad, int s, int nb)
 {
-    __shared__ double As[64 * AS_LD];
-    __shared__ double Bs[16 * BS_LD];
+    __shared__ double As[64 * T64_LD];
+    __shared__ double Bs[64 * TNN_LD];
     TILE_IDS;
     int o = blockIdx.y * 2 * s;
     int r = min(s, nb - o - s);
@@ -605,7 +642,7 @@ __global__ __launch_bounds__(256) void trinv_W_kernel(double *__restrict__ W, co
     const double *A = W + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + s) * 64;
     const double *B = T + (size_t)(o + s) * 64 * Npad + (size_t)(o + tj) * 64;
     d4_t acc[2][2] = {};
-    gemm_tile_64<false>(A, Npad, B, Npad, 0, (ti + 1) * 64, acc, As, Bs);
+    tile64_gemm_nn(A, Npad, B, Npad, 0, ti + 1, acc, As, Bs);       // W22 is lower triangular: k-blocks <= ti
     double *C = W + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + tj) * 64;
 #pragma unroll
     for (int m = 0; m < 2; m++)
