@@ -4,11 +4,22 @@ profiles/<tag>_sweep_pmc.json (per-launch means for the sweep kernel, with the g
 correction of MI355X_MICROARCH.md applied in `hbm_bytes_per_launch`)."""
 import csv, glob, json, os, shutil, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
-st = glob.glob(os.path.join(out, "trace", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """rocprofv3 names its files by pid; gpurun merges every call's files into the same directory here, so take
+    the newest per directory"""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
+st = newest(os.path.join(out, "trace", "*", "*_kernel_stats.csv"))
 if st:
     shutil.copy(st[0], "profiles/%s_bench_kernel_stats.csv" % tag)
 res = {"kernel": "sweep_mfma_kernel", "source": "rocprofv3 --pmc, python3 bench.py --steps 3 --warmup 1", "counters": {}}
-for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
+for f in newest(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "sweep_mfma" in r["Kernel_Name"]:
@@ -25,7 +36,7 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
     res["mfma_util_pct"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
 if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c:
     res["mfma_f64_flops_per_launch"] = c["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
-tr = glob.glob(os.path.join(out, "trace", "*", "*_kernel_trace.csv"))
+tr = newest(os.path.join(out, "trace", "*", "*_kernel_trace.csv"))
 if tr:
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr[0])) if "sweep_mfma" in r["Kernel_Name"]]
     res["kernel_trace_mean_ms"] = sum(d) / len(d) / 1e6
