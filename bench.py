@@ -124,8 +124,19 @@ def main():
     comm = None
     id_path = None
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
+        import threading
+
+        def _stuck():
+            sys.stderr.write("bench.py: RCCL communicator setup did not finish in 300 s (rank %d of %d)\n" % (rank, world))
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(300.0, _stuck)   # a rendezvous that never completes must not hang the node
+        watchdog.daemon = True
+        watchdog.start()
         uid, id_path = exchange_unique_id(world, rank)
         comm = RcclArgmax(world, rank, uid, device=local_rank)
+        comm.barrier()
+        watchdog.cancel()
 
     def barrier():
         _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
