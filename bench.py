@@ -95,6 +95,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON: everything else that writes to file descriptor 1 (RCCL prints a
+    # version / hostname / library-path banner through C stdio, flushed at exit) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -213,7 +219,7 @@ def main():
             out["roofline"]["mfma_util_pct_pmc"] = j.get("mfma_util_pct")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, Y, cand_host)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         comm.close()
