@@ -232,8 +232,12 @@ __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs
 #ifdef IBO_STAMPS      // diagnostic build (tools/chol_diag_bench.hip): where does the diagonal block's time go?
 __device__ unsigned long long g_chol_stamps[32];
 #define CSTAMP(i) do { if (threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_upd_stamps[4][32];      // update kernel: 4 sampled workgroups of batch member 0
+#define USTAMP(i) do { if (threadIdx.x == 0 && blockIdx.z == 0 && (blockIdx.x & 1023) == 8 && (blockIdx.x >> 10) < 4) \
+        g_upd_stamps[blockIdx.x >> 10][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CSTAMP(i)
+#define USTAMP(i)
 #endif
 __device__ __forceinline__ double lane_bcast(double x, int l)          // value of lane l, wave-uniform
 {
@@ -482,16 +486,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[m][n][r] = C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)];
+    USTAMP(0);
     for (int j = j0; j < j1; j++) {
         tile64_stash<true>(As, va);
         tile64_stash(Bs, vb);
+        USTAMP(1 + 4 * (j - j0));
         __syncthreads();
+        USTAMP(2 + 4 * (j - j0));
         if (j + 1 < j1) {
             tile64_fetch(Ai + (j + 1) * 64, Npad, va);
             tile64_fetch(Ak + (j + 1) * 64, Npad, vb);
         }
         tile64_mma_nt(As, Bs, acc);
+        USTAMP(3 + 4 * (j - j0));
         if (j + 1 < j1) __syncthreads();
+        USTAMP(4 + 4 * (j - j0));
     }
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -499,6 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
+    USTAMP(20);
 }
 
 static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,

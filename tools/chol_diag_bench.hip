@@ -32,6 +32,31 @@ int main()
         }
         printf("  inverses %llu  doubling %llu  store %llu\n", st[21] - prev, st[22] - st[21], st[23] - st[22]);
     }
+    {   // update kernel stamps: first K = 256 update of a batch of 16 matrices with 66 block rows
+        const int Np = 66 * 64, B = 16;
+        double *dL; hipMalloc(&dL, sizeof(double) * (size_t)Np * Np * B);
+        hipMemset(dL, 0, sizeof(double) * (size_t)Np * Np * B);
+        hipStream_t st = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(e0, 0);
+            launch_update(dL, Np, 0, 4, 4, 66, B, (size_t)Np * Np, st);
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double tiles = 62.0 * 63 / 2 * B;
+            printf("update K=256, %d matrices of %d: %.3f ms  -> %.1f TFLOP/s\n", B, Np, ms, tiles * 2.0 * 64 * 64 * 256 / ms / 1e9);
+        }
+        unsigned long long us[4][32];
+        hipMemcpyFromSymbol(us, HIP_SYMBOL(g_upd_stamps), sizeof(us));
+        for (int w = 0; w < 4; w++) {
+            printf("  wg %d:", w);
+            for (int j = 0; j < 4; j++)
+                printf("  [stash %llu bar %llu mma %llu bar %llu]", us[w][1 + 4 * j] - (j ? us[w][4 * j] : us[w][0]),
+                       us[w][2 + 4 * j] - us[w][1 + 4 * j], us[w][3 + 4 * j] - us[w][2 + 4 * j], us[w][4 + 4 * j] - us[w][3 + 4 * j]);
+            printf("  store %llu\n", us[w][20] - us[w][16]);
+        }
+        hipFree(dL);
+    }
     std::vector<double> Lh(n * n);
     hipMemcpy(Lh.data(), dA, sizeof(double) * n * n, hipMemcpyDeviceToHost);
     double err = 0;
