@@ -100,6 +100,7 @@ _sig("ibo_comm_barrier", c_int, c_void_p)
 _sig("acqmaxGP", _DP, c_int, _DP, _DP, _DP, _DP, _DP, c_int, c_int, c_int, _DP, c_int, _DP, _DP, c_double, _DP, _DP,
      c_double, c_double, c_int, c_int, c_int)
 _sig("direct", _DP, OBJECTIVE, c_int, _DP, _DP, c_int, c_int, c_int)
+_sig("logCDFs", c_double, c_int, POINTER(c_int), _DP)
 
 EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device_name", "ibo_selftest_mfma",
             "ibo_set_option", "ibo_trim", "ibo_dev_alloc", "ibo_dev_free", "ibo_memcpy_h2d", "ibo_memcpy_d2h",
@@ -108,7 +109,7 @@ EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device
             "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_spd_solve", "ibo_spd_inverse", "ibo_posterior_batch",
             "ibo_acq_sweep", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_host", "ibo_nlml_grid", "ibo_nlml_grad",
             "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_argmax", "ibo_comm_allreduce_sum", "ibo_comm_barrier",
-            "acqmaxGP", "direct"]
+            "acqmaxGP", "direct", "logCDFs"]
 
 
 def check(rc):

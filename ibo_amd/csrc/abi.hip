@@ -947,6 +947,19 @@ extern "C" const double *direct(objective_t objective, int ndim, double *lb, dou
     return res;
 }
 
+// libego's preference log-likelihood helper (cpp/helpers.cpp:30-56), host arithmetic: pairs are taken with
+// stride 2 from the index array, a term is skipped when Phi(.)/sqrt 2 is exactly zero
+extern "C" double logCDFs(int nprefinds, int *prefinds, double *x)
+{
+    const double Z = sqrt(2.0);
+    double lcdf = 0.0;
+    for (int i = 0; i + 1 < nprefinds; i += 2) {
+        const double q = 0.5 * (1.0 + erf((x[prefinds[i]] - x[prefinds[i + 1]]) / Z));
+        if (q / Z != 0.0) lcdf += log(q / Z);
+    }
+    return lcdf;
+}
+
 // host-callback DIRECT with the sample counter and the compat switch exposed
 extern "C" int ibo_direct_host(objective_t objective, int ndim, const double *lb, const double *ub, int maxiter,
                                int maxtime, int maxsample, int compat, double *fmin, double *xmin, int64_t *nsamples)

@@ -7,6 +7,7 @@
  *  (A) LEGACY symbols -- byte-for-byte the signatures the reference's Python
  *      binds with ctypes today, so the .so is a drop-in for cpp/libs/libego:
  *        acqmaxGP   replaces  cpp/optimizeGP.cpp:262-283
+ *        logCDFs    replaces  cpp/helpers.cpp:30-56
  *                   bound at  ego/acquisition/__init__.py:343-364
  *        direct     replaces  cpp/direct.cpp:329 (cpp/direct.h:76)
  *                   bound at  ego/utils/optimize.py:320-333
@@ -296,6 +297,13 @@ const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR, double *X
  * kept so ego.utils.optimize.cdirect keeps working against this library). */
 const double *direct(objective_t objective, int ndim, double *lb, double *ub,
                      int maxiter, int maxtime, int maxsample);
+
+/* cpp/helpers.cpp:30-56: sum of log(Phi((x[p[i]] - x[p[i+1]]) / sqrt 2) / sqrt 2) over i = 0, 2, 4, ... < n
+ * (terms whose argument of log is exactly 0 are skipped).  Host-side only.  The reference's only caller
+ * (ego/gaussianprocess/__init__.py:362-371, off by default) passes flattened (v, u, degree) triples with
+ * n = 3 P and so also reads one int past the end for odd P; this entry point keeps the pair-stride loop
+ * but never reads p[n]. */
+double logCDFs(int nprefinds, int *prefinds, double *x);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ from conftest import ROOT, load_golden
 def declared_symbols():
     txt = open(os.path.join(ROOT, "include", "ibo_abi.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = set(re.findall(r"\b(ibo_[A-Za-z0-9_]+|acqmaxGP|direct)\s*\(", txt))
+    names = set(re.findall(r"\b(ibo_[A-Za-z0-9_]+|acqmaxGP|direct|logCDFs)\s*\(", txt))
     return sorted(n for n in names if n not in ("ibo_gp", "ibo_comm"))
 
 
@@ -126,6 +126,30 @@ def test_legacy_direct_symbol_against_compiled_reference(oracle):
         assert np.array_equal(res, np.r_[ref[0], ref[1]])
     o = oracle.cdirect(f, b.tolist(), maxiter=25, maxsample=100000)
     assert cnt[0] == o[2] and np.array_equal(res, np.r_[o[0], o[1]])
+
+
+def test_legacy_logCDFs_symbol_against_compiled_reference(oracle):
+    """`logCDFs` (cpp/helpers.cpp:30-56): pair-stride sum of log(Phi(dx / sqrt 2) / sqrt 2), zero terms skipped"""
+    import math
+    from ibo_amd import _lib
+    rs = np.random.RandomState(8)
+    x = np.ascontiguousarray(rs.randn(12) * 3)
+    x[3] = -60.0                                        # Phi underflows to exactly 0: that pair is skipped
+    p = np.ascontiguousarray(np.r_[rs.randint(0, 12, size=38), 3, 0].astype(np.int32))   # last pair: x[3] - x[0]
+    ip = p.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    got = _lib.lib.logCDFs(len(p), ip, _lib.dp(x))
+    want = 0.0
+    for i in range(0, len(p), 2):
+        q = 0.5 * (1 + math.erf((x[p[i]] - x[p[i + 1]]) / math.sqrt(2)))
+        if q / math.sqrt(2) != 0.0:
+            want += math.log(q / math.sqrt(2))
+    assert got == pytest.approx(want, rel=1e-14)
+    assert _lib.lib.logCDFs(0, ip, _lib.dp(x)) == 0.0
+    if oracle.RefLib.available():
+        ref = oracle.RefLib().lib
+        ref.logCDFs.restype = ctypes.c_double
+        ref.logCDFs.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+        assert ref.logCDFs(len(p), ip, _lib.dp(x)) == got
 
 
 def test_kernel_scalars_and_specs(oracle):
