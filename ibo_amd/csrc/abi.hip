@@ -41,6 +41,7 @@ static int fail(int code, const char *fmt, ...)
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
 extern int g_sweep_variant;     // sweep.hip
+static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
@@ -134,6 +135,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "sweep_variant")) { g_sweep_variant = value; return IBO_OK; }
     if (key && !strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
+    if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
@@ -325,8 +327,15 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     }
     HIP_TRY(hipEventRecord(g->fit0, s));
     KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, N, s));
-    KERNEL_TRY(launch_pad_copy(A_host ? g->A.p : g->R.p, N, N, g->L.p, Np, 1.0, s));
-    KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s));
+    if (Np / 64 <= 32 && g_chol_fused) {
+        // small enough for the plain right-looking order: one fused launch per block column, out of place
+        // (T is free until launch_trinv uses it as scratch)
+        KERNEL_TRY(launch_pad_copy(A_host ? g->A.p : g->R.p, N, N, g->T.p, Np, 1.0, s));
+        KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s));
+    } else {
+        KERNEL_TRY(launch_pad_copy(A_host ? g->A.p : g->R.p, N, N, g->L.p, Np, 1.0, s));
+        KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s));
+    }
     KERNEL_TRY(launch_zero_upper(g->L.p, Np, s));
     KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s));
     KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));

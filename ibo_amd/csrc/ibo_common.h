@@ -185,6 +185,8 @@ int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStrea
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
                             int panel, hipStream_t s);
 void set_chol_panel(int p);
+// out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
+int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s);
 // W = L^-1 (row-major, ld = Npad) using diag64 from launch_cholesky and a scratch T (Npad x Npad)
 int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s);
 // zero the strict upper triangle (ld = Npad)

@@ -203,6 +203,7 @@ __device__ __forceinline__ void tile64_stash(double *As, const d2_t (&v)[8])
 #pragma unroll
     for (int u = 0; u < 8; u++) *(d2_t *)(As + (8 * u + (t >> 5)) * LD + (t & 31) * 2) = NEG ? -v[u] : v[u];
 }
+template <int LD = T64_LD>
 __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs, d4_t (&acc)[2][2])
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
@@ -210,9 +211,9 @@ __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs
     for (int k4 = 0; k4 < 16; k4++) {
         double a[2], b[2];
 #pragma unroll
-        for (int m = 0; m < 2; m++) a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * T64_LD + k4 * 4 + (lane >> 4)];
+        for (int m = 0; m < 2; m++) a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
 #pragma unroll
-        for (int n = 0; n < 2; n++) b[n] = Bs[(wc * 32 + n * 16 + (lane & 15)) * T64_LD + k4 * 4 + (lane >> 4)];
+        for (int n = 0; n < 2; n++) b[n] = Bs[(wc * 32 + n * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -228,7 +229,7 @@ __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs
 // ------------------------------------------------------------------------
 // blocked right-looking Cholesky, NB = 64
 // ------------------------------------------------------------------------
-#define SD 66
+#define SD 68
 #ifdef IBO_STAMPS      // diagnostic build (tools/chol_diag_bench.hip): where does the diagonal block's time go?
 __device__ unsigned long long g_chol_stamps[32];
 #define CSTAMP(i) do { if (threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -285,30 +286,35 @@ __device__ __forceinline__ double rcp_newton(double d)
     return fma(y, fma(-d, y, 1.0), y);
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, int Npad, int jb,
-                                                        double *__restrict__ diag64, int *info,
-                                                        size_t lstride, size_t dstride)
+__device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *S, double *V)
 {
-    __shared__ double S[64 * SD];          // the block; ends up holding L (lower)
-    __shared__ double V[64 * SD];          // its inverse
-    __shared__ double T[64 * SD];          // scratch (L21 * V11 products)
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride; info += blockIdx.z;      // batch member
-    double *Lb = L + (size_t)jb * 64 * Npad + jb * 64;
-    CSTAMP(31);
-    {
-        double v[16];                      // all 16 loads in flight before the first LDS write
+    const int t = threadIdx.x;
+    double v[16];                          // all 16 loads in flight before the first LDS write
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = Lb[(size_t)(4 * u + (t >> 6)) * Npad + (t & 63)];
+    for (int u = 0; u < 16; u++) v[u] = Lb[(size_t)(4 * u + (t >> 6)) * Npad + (t & 63)];
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-            S[(4 * u + (t >> 6)) * SD + (t & 63)] = v[u];
-            V[(4 * u + (t >> 6)) * SD + (t & 63)] = 0.0;
-        }
+    for (int u = 0; u < 16; u++) {
+        S[(4 * u + (t >> 6)) * SD + (t & 63)] = v[u];
+        V[(4 * u + (t >> 6)) * SD + (t & 63)] = 0.0;
     }
-    CSTAMP(0);
-    __syncthreads();
-    CSTAMP(1);
+}
+
+__device__ __forceinline__ void diag64_store(double *Lb, int Npad, double *Db, const double *S, const double *V)
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int r = 4 * u + (t >> 6), c = t & 63;
+        Lb[(size_t)r * Npad + c] = (c <= r) ? S[r * SD + c] : 0.0;
+        Db[r * 64 + c] = V[r * SD + c];
+    }
+}
+
+// S: the 64x64 block (row stride SD), V: zeros.  On return S holds the factor (lower triangle; the strict upper
+// part is scratch), V its inverse.  T is scratch.  Called by all 256 threads; ends with a barrier.
+__device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info)
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (int b = 0; b < 4; b++) {
         const int o = 16 * b;
         if (wv == 0) {
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
 #pragma unroll
                 for (int k = j + 1; k < 16; k++) r[k] = fma(-l, lane_bcast(l, k), r[k]);
             }
-            if (bad >= 0 && lane == 0) atomicCAS(info, 0, jb * 64 + o + bad + 1);
+            if (bad >= 0 && lane == 0 && info) atomicCAS(info, 0, pivot0 + o + bad + 1);
             if (o + lane < 64) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) S[rr * SD + o + k] = (k <= lane) ? r[k] : 0.0;
@@ -402,28 +408,119 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
         for (int r = 0; r < 4; r++) V[(32 + 16 * ti + MM16_ROW(r)) * SD + 16 * tj + MM16_COL] = -acc[r];
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(double *L, int Npad, int jb,
+                                                        double *__restrict__ diag64, int *info,
+                                                        size_t lstride, size_t dstride, double *Lout)
+{
+    __shared__ double S[64 * SD];          // the block; ends up holding L (lower)
+    __shared__ double V[64 * SD];          // its inverse
+    __shared__ double T[64 * SD];          // scratch (L21 * V11 products)
+    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride; info += blockIdx.z;      // batch member
+    if (!Lout) Lout = L; else Lout += blockIdx.z * lstride;
+    const size_t off = (size_t)jb * 64 * Npad + jb * 64;
+    CSTAMP(31);
+    diag64_load(L + off, Npad, S, V);
+    CSTAMP(0);
+    __syncthreads();
+    CSTAMP(1);
+    diag64_factor_invert(S, V, T, jb * 64, info);
     CSTAMP(22);
-    double *Db = diag64 + (size_t)jb * 4096;
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const int r = 4 * u + (t >> 6), c = t & 63;
-        Lb[(size_t)r * Npad + c] = (c <= r) ? S[r * SD + c] : 0.0;
-        Db[r * 64 + c] = V[r * SD + c];
-    }
+    diag64_store(Lout + off, Npad, diag64 + (size_t)jb * 4096, S, V);
     CSTAMP(23);
 }
 
+// OUT OF PLACE: the matrix being reduced (A) is only read in its panel column and updated in its trailing
+// tiles (each by exactly one workgroup); the factor goes to a second matrix (Lout).  Overwriting the panel in
+// place would race with the workgroups that still have to read it.
+// One launch per block column for the plain right-looking order (one matrix, the fit path): every workgroup
+// of the trailing update first repeats the 64x64 factorisation of the diagonal block (the chain, ~15 us, the
+// same on 120 workgroups as on one), then forms the two row blocks of L it needs (A_i V^T, A_k V^T: what
+// chol_trsm_kernel does) and updates its tile.  Workgroup 0 stores the diagonal block and its inverse, the
+// workgroups of the first trailing column store their row block of L.  Two launches and their gaps per
+// column are gone; every product is rounded to fp64 at the same points as in the three-kernel sequence, so
+// the result is bit-identical to it.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npad, int jb,
+                      double *__restrict__ diag64, int *info)
+{
+    __shared__ double S[64 * SD];
+    __shared__ double V[64 * SD];
+    __shared__ double T[64 * SD];
+    TILE_IDS;
+    const int nb = Npad / 64;
+    int k = jb + 1, rem = blockIdx.x;
+    while (rem >= nb - k) { rem -= nb - k; k++; }
+    const int i = k + rem;
+    const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
+    const double *Ai = L + (size_t)i * 64 * Npad + jb * 64, *Ak = L + (size_t)k * 64 * Npad + jb * 64;
+    double *Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
+    double *C = L + (size_t)i * 64 * Npad + k * 64;
+    // everything this workgroup will need from memory is requested before the chain starts
+    d2_t va[8], vb[8];
+    tile64_fetch(Ai, Npad, va);
+    tile64_fetch(Ak, Npad, vb);
+    d4_t c[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) c[m][n][r] = C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)];
+    diag64_load(L + doff, Npad, S, V);
+    __syncthreads();
+    diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
+    if (blockIdx.x == 0) diag64_store(Lout + doff, Npad, diag64 + (size_t)jb * 4096, S, V);
+    __syncthreads();                                   // S is about to be reused
+    // X_i = A_i V^T, X_k = A_k V^T  (V[c][k] row-major is the "B^T" operand as it stands)
+    tile64_stash<false, SD>(S, va);
+    tile64_stash<false, SD>(T, vb);
+    __syncthreads();
+    d4_t xi[2][2] = {}, xk[2][2] = {};
+    tile64_mma_nt<SD>(S, V, xi);
+    tile64_mma_nt<SD>(T, V, xk);
+    __syncthreads();
+    if (k == jb + 1) {                                 // first trailing column: this row block of L is final
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Xi[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = xi[m][n][r];
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                S[TILE_ROW(m, r) * SD + TILE_COL(n)] = -xi[m][n][r];
+                T[TILE_ROW(m, r) * SD + TILE_COL(n)] = xk[m][n][r];
+            }
+    __syncthreads();
+    tile64_mma_nt<SD>(S, T, c);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = c[m][n][r];
+}
+
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
-__global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, int Npad, int jb,
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double *L, int Npad, int jb,
                                                         const double *__restrict__ diag64,
-                                                        size_t lstride, size_t dstride)
+                                                        size_t lstride, size_t dstride, double *Lout)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
     L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
+    if (!Lout) Lout = L; else Lout += blockIdx.z * lstride;
     int ib = jb + 1 + blockIdx.x;
-    double *Ab = L + (size_t)ib * 64 * Npad + jb * 64;
+    const double *Ab = L + (size_t)ib * 64 * Npad + jb * 64;
+    double *Ob = Lout + (size_t)ib * 64 * Npad + jb * 64;
     d2_t va[8], vb[8];
     tile64_fetch(Ab, Npad, va);
     tile64_fetch(diag64 + (size_t)jb * 4096, 64, vb);
@@ -438,7 +535,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, 
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) Ab[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
+            for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
 }
 
 // update with finished block columns [j0, j1):  A[i][k] -= sum_j L[i][j] L[k][j]^T  for the block columns
@@ -448,13 +545,14 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ L, 
 // workgroup b belongs to XCD b % 8 and that XCD's 64 consecutive workgroups are given one 8x8 super-block
 // of tiles -- 16 operand strips of 64 x 64(j1-j0) serve 64 tiles out of L2 instead of being re-fetched
 // from the Infinity Cache (with the operands also kept out of scratch, K = 256 updates went from 18 to 35 TFLOP/s at N = 4096).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void chol_update_kernel(double *__restrict__ L, int Npad, int j0, int j1,
-                                                          int k0, int k1, int nsb, size_t lstride)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void chol_update_kernel(double *L, int Npad, int j0, int j1,
+                                                          int k0, int k1, int nsb, size_t lstride, const double *P)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
     L += blockIdx.z * lstride;
+    if (!P) P = L; else P += blockIdx.z * lstride;          // where the finished block columns live
     const int nb = Npad / 64;
     int i, k;
     if (nsb > 0) {
@@ -473,7 +571,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         i = k + rem;
     }
     double *C = L + (size_t)i * 64 * Npad + k * 64;
-    const double *Ai = L + (size_t)i * 64 * Npad, *Ak = L + (size_t)k * 64 * Npad;
+    const double *Ai = P + (size_t)i * 64 * Npad, *Ak = P + (size_t)k * 64 * Npad;
     d2_t va[8], vb[8];
     tile64_fetch(Ai + j0 * 64, Npad, va);
     tile64_fetch(Ak + j0 * 64, Npad, vb);
@@ -512,20 +610,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,
-                          hipStream_t s)
+                          hipStream_t s, const double *P = nullptr)
 {
     const int nb = Npad / 64, nsr = (nb - k0 + 7) / 8, nsc = (k1 - k0 + 7) / 8;
     int tiles = 0;
     for (int k = k0; k < k1; k++) tiles += nb - k;
     if ((size_t)tiles * batch <= 512) {
-        hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1, 0, lstride);
+        hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1, 0, lstride, P);
         return;
     }
     int nsb = 0;
     for (int c = 0; c < nsc; c++) nsb += nsr - c;
     const int groups = (nsb + 7) / 8;                // every XCD gets `groups` super-blocks of 64 workgroups
     hipLaunchKernelGGL(chol_update_kernel, dim3(groups * 512, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1,
-                       nsb, lstride);
+                       nsb, lstride, P);
 }
 
 // `batch` matrices, `lstride` doubles apart (diag64: (Npad/64)*4096 apart, info: consecutive ints), are
@@ -548,14 +646,41 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
         const int pend = p0 + P < nb ? p0 + P : nb;
         for (int jb = p0; jb < pend; jb++) {
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, info_dev,
-                               lstride, dstride);
+                               lstride, dstride, (double *)nullptr);
             const int m = nb - jb - 1;
             if (m > 0)
                 hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, lstride,
-                                   dstride);
+                                   dstride, (double *)nullptr);
             if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s);
         }
         if (pend < nb) launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
+    }
+    return (int)hipGetLastError();
+}
+
+// Plain right-looking order with one fused launch per block column (chol_step_kernel): `work` holds the matrix
+// and is destroyed, the factor (lower blocks; the strict upper blocks are not touched) goes to `out`.
+// Bit-identical to launch_cholesky with panel = 1.
+int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s)
+{
+    const int nb = Npad / 64;
+    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    for (int jb = 0; jb < nb; jb++) {
+        const int m = nb - jb - 1;
+        if (m > 0 && m * (m + 1) / 2 <= 256) {
+            // the trailing tiles fit on the chip at once: repeating the diagonal factorisation in each of them
+            // costs nothing and two launches disappear
+            hipLaunchKernelGGL(chol_step_kernel, dim3(m * (m + 1) / 2), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                               info_dev);
+        } else {
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
+                               (size_t)0, (size_t)0, out);
+            if (m > 0) {
+                hipLaunchKernelGGL(chol_trsm_kernel, dim3(m), dim3(256), 0, s, work, Npad, jb, diag64, (size_t)0,
+                                   (size_t)0, out);
+                launch_update(work, Npad, jb, jb + 1, jb + 1, nb, 1, 0, s, out);
+            }
+        }
     }
     return (int)hipGetLastError();
 }

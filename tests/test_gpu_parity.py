@@ -581,6 +581,17 @@ def test_cholesky_panel_orders_agree(ibo):
     Lr = np.linalg.cholesky(GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05).R)
     for L in Ls:
         assert np.abs(L - Lr).max() < 1e-12
+    # the fit path's fused one-launch-per-column factorisation rounds at the same points as the three-kernel
+    # sequence with panel = 1: same bits
+    fused = GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05)
+    _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 0))
+    try:
+        plain = GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05)
+        Lp, Wp = plain.L, plain.posteriors(X[:7] + .01)
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 1))
+    assert np.array_equal(fused.L, Lp) and np.array_equal(Ls[0], Lp)
+    assert np.array_equal(np.array(fused.posteriors(X[:7] + .01)), np.array(Wp))
     thetas = np.exp(np.random.RandomState(3).uniform(np.log(.2), np.log(2), size=(7, 5)))
     vals, _ = nlml_grid(GaussianKernel_ard, thetas, X[:300], Y[:300], noise=.01)
     for b in (1, 2, 7):

@@ -16,7 +16,7 @@ int main()
         hipMemcpy(dA, A.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
         hipMemset(info, 0, 4);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, 0, dA, n, 0, dD, info, (size_t)0, (size_t)0);
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, 0, dA, n, 0, dD, info, (size_t)0, (size_t)0, (double *)nullptr);
         hipEventRecord(e1, 0);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
