@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU box): fit + posterior + EI over random (N, D, kernel, M) against the oracle.
+python3 tools/fuzz_gpu.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as orc
+from ibo_amd.gaussianprocess import GaussianProcess
+from ibo_amd.gaussianprocess import kernel as K
+from ibo_amd.acquisition import sweep
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+special_N = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 511, 512, 513, 1023, 1025, 1471, 2047, 2049]
+worst = 0.0
+t0 = time.time()
+for case in range(ncases):
+    N = int(special_N[case % len(special_N)] if case < 2 * len(special_N) else rs.randint(1, 1500))
+    D = int(rs.randint(1, 17))
+    kind = ["ard", "iso", "m3", "m5"][rs.randint(4)]
+    M = int([1, 3, 16, 17, 64, 65, 1000, 8192, 8193, 20000][rs.randint(10)])
+    noise = float([.1, .01, 1e-3][rs.randint(3)])
+    X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
+    th = np.exp(rs.uniform(np.log(.2), np.log(1.5), size=D))
+    if kind == "ard": hyp = th; ours = K.GaussianKernel_ard(hyp)
+    elif kind == "iso": hyp = th[:1]; ours = K.GaussianKernel_iso(hyp)
+    elif kind == "m3": hyp = np.r_[th[0], 1.0]; ours = K.MaternKernel3(hyp)
+    else: hyp = np.r_[th[0], 1.0]; ours = K.MaternKernel5(hyp)
+    ogp = orc.GP(orc.Kern(kind, hyp), X, Y, noise=noise)
+    try:
+        np.linalg.cholesky(ogp.factor_matrix())
+    except np.linalg.LinAlgError:
+        continue
+    gp = GaussianProcess(ours, X, Y, noise=noise)
+    cand = rs.rand(M, D)
+    Mo = min(M, 300)                                    # the oracle's share (it is O(N^2) per point, scalar)
+    r = sweep(gp, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+    o = orc.sweep_native(ogp, cand[:Mo], orc.ACQ_EI, .01)
+    em = np.max(np.abs(r["mu"][:Mo] - o["mu"]) / np.maximum(np.abs(o["mu"]), 1e-9))
+    es = np.max(np.abs(r["s2"][:Mo] - o["s2"]) / np.maximum(np.abs(o["s2"]), 1e-9))
+    ea = np.max(np.abs(r["acq"][:Mo] - o["acq"]) / np.maximum(np.abs(o["acq"]), 1e-9) * (np.abs(o["acq"]) > 1e-12))
+    ok_idx = int(np.argmax(r["acq"])) == r["best_idx"]
+    worst = max(worst, em, es, ea)
+    flag = "" if (max(em, es, ea) < 1e-6 and ok_idx) else "   <-- FAIL"
+    print("N=%5d D=%2d %-3s M=%6d noise=%g  rel err mu %.1e s2 %.1e ei %.1e argmax %s%s" % (N, D, kind, M, noise, em, es, ea, ok_idx, flag), flush=True)
+print("worst relative error %.2e over %d cases, %.1f s" % (worst, ncases, time.time() - t0))
