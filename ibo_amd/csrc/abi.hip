@@ -89,6 +89,7 @@ struct ibo_gp {
     bool fitted = false;
     int N = 0, D = 0, Npad = 0, DP = 0;
     bool reversed = false;          // legacy invR path stores the observations in reverse order
+    bool L_upper_dirty = false;     // zero_upper is deferred to ibo_gp_get_L
     int dot_form = 1;               // SE k* via a_k + b_c + x~.c~; off when |x~|^2 is so large that the
                                     // cancellation would cost more than 1e-10 (pathological length scales)
     KParams kp;
@@ -326,18 +327,20 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
         HIP_TRY(hipMemcpyAsync(g->A.p, A_host, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(hipEventRecord(g->fit0, s));
-    KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, N, s));
-    if (Np / 64 <= 32 && g_chol_fused) {
+    // R, and in the same pass the identity-padded copy the factorisation works on
+    const bool fused = Np / 64 <= 32 && g_chol_fused;
+    double *work = fused ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
+    KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, N, s,
+                                 A_host ? nullptr : work, Np));
+    if (A_host) KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
+    if (fused) {
         // small enough for the plain right-looking order: one fused launch per block column, out of place
-        // (T is free until launch_trinv uses it as scratch)
-        KERNEL_TRY(launch_pad_copy(A_host ? g->A.p : g->R.p, N, N, g->T.p, Np, 1.0, s));
         KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s));
     } else {
-        KERNEL_TRY(launch_pad_copy(A_host ? g->A.p : g->R.p, N, N, g->L.p, Np, 1.0, s));
         KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s));
     }
-    KERNEL_TRY(launch_zero_upper(g->L.p, Np, s));
-    KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s));
+    g->L_upper_dirty = true;        // the strict upper blocks of L are scratch until someone asks for L
+    KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));
     KERNEL_TRY(launch_alpha(g->W.p, N, Np, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, s));
     HIP_TRY(hipEventRecord(g->fit1, s));
@@ -454,6 +457,12 @@ extern "C" int ibo_gp_get_L(ibo_gp_t *g, double *L_host)
 {
     if (!g || !L_host) return fail(IBO_ERR_ARG, "NULL argument");
     if (!g->fitted || g->reversed) return fail(IBO_ERR_STATE, "L not available");
+    if (g->L_upper_dirty) {
+        IBO_TRY(use_device(g->device));
+        KERNEL_TRY(launch_zero_upper(g->L.p, g->Npad, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        g->L_upper_dirty = false;
+    }
     return copy_square(g, g->L.p, g->Npad, L_host);
 }
 extern "C" int ibo_gp_get_W(ibo_gp_t *g, double *W_host)

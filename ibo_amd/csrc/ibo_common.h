@@ -178,7 +178,7 @@ int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
-                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s);
+                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2 = nullptr, int np2 = 0);
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the
 // inverses of the 64x64 diagonal blocks; info (device int) gets the 1-based failing pivot or 0
 int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s);
@@ -188,7 +188,8 @@ void set_chol_panel(int p);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s);
 // W = L^-1 (row-major, ld = Npad) using diag64 from launch_cholesky and a scratch T (Npad x Npad)
-int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s);
+int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s,
+                 bool zero_fill = true);
 // zero the strict upper triangle (ld = Npad)
 int launch_zero_upper(double *A, int Npad, hipStream_t s);
 // Wout/Wp from S; mode 0: W[i][j] = S[i][j]; mode 1: W[i][j] = S[N-1-j][N-1-i] (i,j < N);

@@ -22,7 +22,8 @@
 // (z is accumulated in the reference's order: sum_d w_d (a_d - b_d)^2.)
 __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
                                                          const double *__restrict__ A2, int ldp, int square,
-                                                         int diag_rule, double noise, double *__restrict__ K, int ldk)
+                                                         int diag_rule, double noise, double *__restrict__ K, int ldk,
+                                                         double *__restrict__ K2, int np2)
 {
     __shared__ double As[16 * 16], Bs[64 * 17], ws[16];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
@@ -49,29 +50,35 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
         }
     }
     const int j = j0 + tx;
-    if (j >= n2) return;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int i = i0 + ty * 4 + r;
-        if (i >= n1) break;
-        double v = cov_from_z_rt(kp.family, z[r], kp.sf2);
-        if (square && i == j) {
-            // diag_rule 0: the reference never calls the kernel on the diagonal and
-            // hard-wires 1+noise (ego/gaussianprocess/__init__.py:138)
-            v = (diag_rule == 0) ? (1.0 + noise) : (v + noise);
+        if (i < n1 && j < n2) {
+            double v = cov_from_z_rt(kp.family, z[r], kp.sf2);
+            if (square && i == j) {
+                // diag_rule 0: the reference never calls the kernel on the diagonal and
+                // hard-wires 1+noise (ego/gaussianprocess/__init__.py:138)
+                v = (diag_rule == 0) ? (1.0 + noise) : (v + noise);
+            }
+            K[(size_t)i * ldk + j] = v;
+            if (K2) K2[(size_t)i * np2 + j] = v;
+        } else if (K2 && i < np2 && j < np2) {
+            K2[(size_t)i * np2 + j] = (i == j) ? 1.0 : 0.0;     // identity pad of the np2 x np2 working copy
         }
-        K[(size_t)i * ldk + j] = v;
     }
 }
 
+// K2 (optional, square case): a second, np2 x np2 copy of K padded with the identity -- the matrix the
+// factorisation works on, written by the same kernel instead of a separate pad-and-copy pass.
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
-                      int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s)
+                      int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2)
 {
     int square = (A2 == nullptr);
     if (square) { A2 = A1; n2 = n1; }
-    dim3 grid((n2 + 63) / 64, (n1 + 15) / 16);
+    const int c = K2 ? np2 : n2, r = K2 ? np2 : n1;
+    dim3 grid((c + 63) / 64, (r + 15) / 16);
     hipLaunchKernelGGL(cov_matrix_kernel, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
-                       diag_rule, noise, K, ldk);
+                       diag_rule, noise, K, ldk, K2, np2);
     return (int)hipGetLastError();
 }
 
@@ -787,10 +794,12 @@ void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T, int Np
             for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = -acc[m][n][q];
 }
 
-int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s)
+int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s, bool zero_fill)
 {
     int nb = Npad / 64;
-    HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * (size_t)Npad * Npad, s));
+    // the doubling only ever reads and writes blocks on or below the diagonal; the zeros above it are for
+    // consumers that take W as a full matrix (the fit path re-writes all of W in pack_w_kernel instead)
+    if (zero_fill) HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * (size_t)Npad * Npad, s));
     hipLaunchKernelGGL(trinv_place_diag_kernel, dim3(nb), dim3(256), 0, s, diag64, W, Npad);
     for (int sz = 1; sz < nb; sz *= 2) {
         int nodes = (nb + 2 * sz - 1) / (2 * sz);

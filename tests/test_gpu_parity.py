@@ -178,9 +178,12 @@ def test_g6_sweeps_vs_reference_vectors(ibo, name):
 
 
 @pytest.mark.parametrize("N,D,kind,M", [(100, 3, "ard", 1000), (513, 5, "m5", 300), (1024, 4, "ard", 2048),
-                                         (700, 16, "ard", 200), (65, 1, "iso", 130), (1, 2, "ard", 70)])
+                                         (700, 16, "ard", 200), (65, 1, "iso", 130), (1, 2, "ard", 70),
+                                         (64, 2, "m3", 64), (129, 8, "iso", 17), (1471, 4, "ard", 1),
+                                         (2049, 7, "iso", 65)])
 def test_sweep_vs_oracle_ragged(ibo, oracle, N, D, kind, M):
-    """seeded inputs at awkward sizes (N not a multiple of 16/64/512, M not of 64, N=1)"""
+    """seeded inputs at awkward sizes (N not a multiple of 16/64/512, M not of 64, N=1, N on either side of a
+    64-block boundary, N=2049: 33 blocks, the two-level Cholesky order of the fit path)"""
     from ibo_amd.gaussianprocess import GaussianProcess, kernel as K
     from ibo_amd.acquisition import sweep
     X, Y = synth(7 + N, N, D)
