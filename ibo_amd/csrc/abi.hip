@@ -41,6 +41,7 @@ static int fail(int code, const char *fmt, ...)
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
 extern int g_sweep_variant;     // sweep.hip
+static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
@@ -85,6 +86,8 @@ struct DevBuf {
 struct ibo_gp {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;      // host-array batches: copies overlap the sweep
+    hipEvent_t pe_in[2] = {nullptr, nullptr}, pe_k[2] = {nullptr, nullptr}, pe_out[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, fit0 = nullptr, fit1 = nullptr;
     bool fitted = false;
     int N = 0, D = 0, Npad = 0, DP = 0;
@@ -137,6 +140,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
+    if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
@@ -196,6 +200,13 @@ extern "C" int ibo_gp_create(int device, ibo_gp_t **out)
     ibo_gp *g = new ibo_gp();
     g->device = device;
     HIP_TRY(hipStreamCreate(&g->stream));
+    HIP_TRY(hipStreamCreateWithFlags(&g->h2d_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g->d2h_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipEventCreateWithFlags(&g->pe_in[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g->pe_k[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g->pe_out[b], hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1));
     HIP_TRY(hipEventCreate(&g->fit0)); HIP_TRY(hipEventCreate(&g->fit1));
     memset(&g->kp, 0, sizeof(g->kp));
@@ -216,6 +227,8 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
     (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
     (void)hipEventDestroy(g->fit0); (void)hipEventDestroy(g->fit1);
+    for (int b = 0; b < 2; b++) { (void)hipEventDestroy(g->pe_in[b]); (void)hipEventDestroy(g->pe_k[b]); (void)hipEventDestroy(g->pe_out[b]); }
+    (void)hipStreamDestroy(g->h2d_stream); (void)hipStreamDestroy(g->d2h_stream);
     (void)hipStreamDestroy(g->stream);
     delete g;
     return IBO_OK;
@@ -680,21 +693,79 @@ extern "C" int ibo_last_sweep_kernel_ms(ibo_gp_t *g, float *ms, const char **ker
 
 // host-in / host-out evaluation of M points: values of one acquisition (or the
 // posterior) -- used by posterior_batch and by DIRECT's batches
+static int ensure_pinned(ibo_gp *g, size_t need)
+{
+    if (need <= g->pin_cap) return IBO_OK;
+    if (g->pin) (void)hipHostFree(g->pin);
+    g->pin = nullptr; g->pin_cap = 0;
+    size_t cap = need < 4096 ? 4096 : need * 2;
+    HIP_TRY(hipHostMalloc((void **)&g->pin, cap * sizeof(double), hipHostMallocDefault));
+    g->pin_cap = cap;
+    return IBO_OK;
+}
+
+// Large host-in / host-out batches (GP.posteriors(X) on 10^5..10^7 NumPy rows): chunks of 2^17 points go through
+// two sets of pinned + device buffers; the upload of chunk c+1 and the download of chunk c-1 run on their own
+// streams while chunk c is in the sweep kernel, so the call costs about the kernel time, not kernel + PCIe +
+// pageable staging.
+static int eval_host_points_pipelined(ibo_gp *g, int64_t M, const double *Q_host, int acq, double parm, int erf_mode,
+                                      double clamp_lo, double *mu_host, double *s2_host, double *acq_host)
+{
+    const int64_t CH = (int64_t)1 << 17;
+    const int D = g->D;
+    const int nout = (mu_host ? 1 : 0) + (s2_host ? 1 : 0) + (acq_host ? 1 : 0);
+    IBO_TRY(g->cand.ensure((size_t)(2 * CH) * D));
+    IBO_TRY(g->outs.ensure((size_t)(2 * CH) * 3));
+    IBO_TRY(ensure_pinned(g, (size_t)(2 * CH) * (D + 3)));
+    double *pin_in[2] = {g->pin, g->pin + CH * D};
+    double *pin_out[2] = {g->pin + 2 * CH * D, g->pin + 2 * CH * D + 3 * CH};
+    double *dev_in[2] = {g->cand.p, g->cand.p + CH * D};
+    double *dev_out[2] = {g->outs.p, g->outs.p + 3 * CH};
+    const int64_t nch = (M + CH - 1) / CH;
+    auto drain = [&](int64_t c) -> int {              // results of chunk c: pinned -> caller's arrays
+        const int b = (int)(c & 1);
+        const int64_t m = (c + 1 < nch) ? CH : M - c * CH;
+        HIP_TRY(hipEventSynchronize(g->pe_out[b]));
+        int k = 0;
+        if (mu_host) memcpy(mu_host + c * CH, pin_out[b] + m * k++, sizeof(double) * m);
+        if (s2_host) memcpy(s2_host + c * CH, pin_out[b] + m * k++, sizeof(double) * m);
+        if (acq_host) memcpy(acq_host + c * CH, pin_out[b] + m * k++, sizeof(double) * m);
+        return IBO_OK;
+    };
+    for (int64_t c = 0; c < nch; c++) {
+        const int b = (int)(c & 1);
+        const int64_t m = (c + 1 < nch) ? CH : M - c * CH;
+        if (c >= 2) IBO_TRY(drain(c - 2));           // frees buffer set b (its download has finished)
+        memcpy(pin_in[b], Q_host + c * CH * D, sizeof(double) * m * D);
+        HIP_TRY(hipMemcpyAsync(dev_in[b], pin_in[b], sizeof(double) * m * D, hipMemcpyHostToDevice, g->h2d_stream));
+        HIP_TRY(hipEventRecord(g->pe_in[b], g->h2d_stream));
+        HIP_TRY(hipStreamWaitEvent(g->stream, g->pe_in[b], 0));
+        int k = 0;
+        double *dmu = mu_host ? dev_out[b] + m * k++ : nullptr;
+        double *ds2 = s2_host ? dev_out[b] + m * k++ : nullptr;
+        double *dacq = acq_host ? dev_out[b] + m * k++ : nullptr;
+        IBO_TRY(run_sweep(g, m, dev_in[b], acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
+                          nullptr, nullptr));
+        HIP_TRY(hipEventRecord(g->pe_k[b], g->stream));
+        HIP_TRY(hipStreamWaitEvent(g->d2h_stream, g->pe_k[b], 0));
+        HIP_TRY(hipMemcpyAsync(pin_out[b], dev_out[b], sizeof(double) * m * nout, hipMemcpyDeviceToHost, g->d2h_stream));
+        HIP_TRY(hipEventRecord(g->pe_out[b], g->d2h_stream));
+    }
+    if (nch >= 2) IBO_TRY(drain(nch - 2));
+    IBO_TRY(drain(nch - 1));
+    return IBO_OK;
+}
+
 static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq, double parm, int erf_mode,
                             double clamp_lo, double *mu_host, double *s2_host, double *acq_host)
 {
+    if (M >= ((int64_t)1 << 18) && g_host_pipeline)
+        return eval_host_points_pipelined(g, M, Q_host, acq, parm, erf_mode, clamp_lo, mu_host, s2_host, acq_host);
     IBO_TRY(g->cand.ensure((size_t)M * g->D));
     IBO_TRY(g->outs.ensure(3 * (size_t)M));
     // pinned staging (input points + up to 3 output arrays): pageable copies cost ~15 us each and
     // DIRECT issues ~100 small batches per maximisation
-    size_t need = (size_t)M * (g->D + 3);
-    if (need > g->pin_cap) {
-        if (g->pin) (void)hipHostFree(g->pin);
-        g->pin = nullptr; g->pin_cap = 0;
-        size_t cap = need < 4096 ? 4096 : need * 2;
-        HIP_TRY(hipHostMalloc((void **)&g->pin, cap * sizeof(double), hipHostMallocDefault));
-        g->pin_cap = cap;
-    }
+    IBO_TRY(ensure_pinned(g, (size_t)M * (g->D + 3)));
     hipStream_t s = g->stream;
     double *pin_in = g->pin, *pin_out = g->pin + (size_t)M * g->D;
     memcpy(pin_in, Q_host, sizeof(double) * M * g->D);

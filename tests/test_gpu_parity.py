@@ -606,6 +606,27 @@ def test_cholesky_panel_orders_agree(ibo):
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[4:5], X[:300], Y[:300], noise=.01)[0], vals[4:5])
 
 
+def test_large_host_batches_are_pipelined_without_changing_results(ibo):
+    """GP.posteriors on a big NumPy array goes through overlapped 2^17-point chunks (upload / sweep / download on
+    three streams): same numbers as the single-shot path, ragged last chunk included"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    X, Y = synth(21, 300, 3)
+    GP = GaussianProcess(GaussianKernel_ard([.3, .4, .5]), X, Y, noise=.05)
+    Q = np.random.RandomState(22).rand((1 << 18) + (1 << 17) + 12345, 3)
+    mu1, s21 = GP._posterior_arrays(Q, True)
+    _lib.check(_lib.lib.ibo_set_option(b"host_pipeline", 0))
+    try:
+        mu0, s20 = GP._posterior_arrays(Q, True)
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"host_pipeline", 1))
+    assert np.array_equal(mu0, mu1) and np.array_equal(s20, s21)
+    mu2 = GP._posterior_arrays(Q[: (1 << 18)], False)          # exactly two full chunks, mean only
+    mu2 = mu2[0] if isinstance(mu2, tuple) else mu2
+    assert np.array_equal(np.asarray(mu2).ravel(), mu0[: (1 << 18)])
+
+
 def test_add_observation_point_augmented_variance(ibo, oracle):
     """PrefGaussianProcess.addObservationPoint (ego/gaussianprocess/__init__.py:214-223,502-519): the mean keeps
     using L = chol(R + C^-1), the variance switches to the factor of the augmented matrix"""
