@@ -200,13 +200,6 @@ extern "C" int ibo_gp_create(int device, ibo_gp_t **out)
     ibo_gp *g = new ibo_gp();
     g->device = device;
     HIP_TRY(hipStreamCreate(&g->stream));
-    HIP_TRY(hipStreamCreateWithFlags(&g->h2d_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&g->d2h_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipEventCreateWithFlags(&g->pe_in[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&g->pe_k[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&g->pe_out[b], hipEventDisableTiming));
-    }
     HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1));
     HIP_TRY(hipEventCreate(&g->fit0)); HIP_TRY(hipEventCreate(&g->fit1));
     memset(&g->kp, 0, sizeof(g->kp));
@@ -227,8 +220,10 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
     (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
     (void)hipEventDestroy(g->fit0); (void)hipEventDestroy(g->fit1);
-    for (int b = 0; b < 2; b++) { (void)hipEventDestroy(g->pe_in[b]); (void)hipEventDestroy(g->pe_k[b]); (void)hipEventDestroy(g->pe_out[b]); }
-    (void)hipStreamDestroy(g->h2d_stream); (void)hipStreamDestroy(g->d2h_stream);
+    if (g->h2d_stream) {
+        for (int b = 0; b < 2; b++) { (void)hipEventDestroy(g->pe_in[b]); (void)hipEventDestroy(g->pe_k[b]); (void)hipEventDestroy(g->pe_out[b]); }
+        (void)hipStreamDestroy(g->h2d_stream); (void)hipStreamDestroy(g->d2h_stream);
+    }
     (void)hipStreamDestroy(g->stream);
     delete g;
     return IBO_OK;
@@ -629,13 +624,15 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     int64_t ntiles = (M + 63) / 64;
     IBO_TRY(g->partv.ensure(ntiles)); IBO_TRY(g->parti.ensure(ntiles));
     IBO_TRY(g->res_v.ensure(1)); IBO_TRY(g->res_i.ensure(1));
-    a.part_val = g->partv.p; a.part_idx = g->parti.p; a.result_val = g->res_v.p; a.result_idx = g->res_i.p;
+    a.part_val = g->partv.p; a.part_idx = g->parti.p;
+    const bool want_best = best_val || best_idx;
+    a.result_val = want_best ? g->res_v.p : nullptr; a.result_idx = want_best ? g->res_i.p : nullptr;
     bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16);
-    // small batches: spread the 128-row panels over the grid too (one tile per 64 candidates alone
+    // small batches: spread the IBO_SPLIT_PANEL-row panels over the grid too (one tile per 64 candidates alone
     // would leave most of the 256 CUs idle); above ~128 tiles the plain kernel fills the chip
     bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256));
     if (split) {
-        IBO_TRY(g->qpart.ensure((size_t)((g->Npad + 127) / 128) * M)); IBO_TRY(g->mupart.ensure(2 * (size_t)M));
+        IBO_TRY(g->qpart.ensure((size_t)((g->Npad + IBO_SPLIT_PANEL - 1) / IBO_SPLIT_PANEL) * M)); IBO_TRY(g->mupart.ensure(2 * (size_t)M));
         a.qpart = g->qpart.p; a.mupart = g->mupart.p;
         KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_mfma_kernel<split>";
@@ -713,6 +710,15 @@ static int eval_host_points_pipelined(ibo_gp *g, int64_t M, const double *Q_host
 {
     const int64_t CH = (int64_t)1 << 17;
     const int D = g->D;
+    if (!g->h2d_stream) {                             // copy streams and their events: created on first use
+        HIP_TRY(hipStreamCreateWithFlags(&g->h2d_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&g->d2h_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipEventCreateWithFlags(&g->pe_in[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&g->pe_k[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&g->pe_out[b], hipEventDisableTiming));
+        }
+    }
     const int nout = (mu_host ? 1 : 0) + (s2_host ? 1 : 0) + (acq_host ? 1 : 0);
     IBO_TRY(g->cand.ensure((size_t)(2 * CH) * D));
     IBO_TRY(g->outs.ensure((size_t)(2 * CH) * 3));

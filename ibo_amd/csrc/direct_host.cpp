@@ -16,6 +16,7 @@
 // looking at fixed[0], which stalls the search when dimension 0 is fixed.
 #include "direct_host.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -35,12 +36,24 @@ struct Pool {                 // rectangles, structure-of-arrays, insertion orde
         lb.insert(lb.end(), l, l + D); ub.insert(ub.end(), u, u + D); ctr.insert(ctr.end(), c, c + D);
         y.push_back(yy); d.push_back(dd);
     }
-    void erase(size_t j)
+    // remove the rectangles listed in `dead` (any order) in one pass; the order of the others is kept
+    void erase_many(const std::vector<size_t> &dead)
     {
-        lb.erase(lb.begin() + j * D, lb.begin() + (j + 1) * D);
-        ub.erase(ub.begin() + j * D, ub.begin() + (j + 1) * D);
-        ctr.erase(ctr.begin() + j * D, ctr.begin() + (j + 1) * D);
-        y.erase(y.begin() + j); d.erase(d.begin() + j);
+        if (dead.empty()) return;
+        std::vector<char> gone(size(), 0);
+        for (size_t j : dead) gone[j] = 1;
+        size_t w = 0;
+        for (size_t j = 0; j < size(); j++) {
+            if (gone[j]) continue;
+            if (w != j) {
+                std::copy(lb.begin() + j * D, lb.begin() + (j + 1) * D, lb.begin() + w * D);
+                std::copy(ub.begin() + j * D, ub.begin() + (j + 1) * D, ub.begin() + w * D);
+                std::copy(ctr.begin() + j * D, ctr.begin() + (j + 1) * D, ctr.begin() + w * D);
+                y[w] = y[j]; d[w] = d[j];
+            }
+            w++;
+        }
+        lb.resize(w * D); ub.resize(w * D); ctr.resize(w * D); y.resize(w); d.resize(w);
     }
 };
 
@@ -183,39 +196,56 @@ Division make_division(const Pool &pool, size_t j)
     return dv;
 }
 
-// potentially-optimal rectangles (cpp/direct.cpp:378-471)
+// potentially-optimal rectangles (cpp/direct.cpp:378-471).  The reference tests every rectangle j against every
+// other one: rejected if a rectangle of the same size d has a smaller y, or one with a larger d has y <= y_j
+// (slope <= 0), or min slope to the larger ones < max slope from the smaller ones (maxI1 seeded with DBL_MIN,
+// so non-positive slopes from below never count); kept otherwise subject to the epsilon test.  All of that
+// only involves, per distinct size, the smallest y of that size (a slope to a fixed size is monotone in y, in
+// floating point too), so the sizes are grouped first: same decisions, same floating-point values,
+// O(R + candidates x sizes) instead of O(R^2).
 void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out)
 {
     const double eps = 10e-10;
     const size_t n = pool.size();
     const double *Y = pool.y.data(), *Dd = pool.d.data();
     out.clear();
-    for (size_t j = 0; j < n; j++) {
-        double maxI1 = DBL_MIN, minI2 = DBL_MAX;
-        const double yj = Y[j], dj = Dd[j];
-        bool reject = false;
-        for (size_t i = 0; i < n; i++) {
-            if (i == j) continue;
-            const double di = Dd[i];
-            if (di < dj) {
-                double v = (yj - Y[i]) / (dj - di);
-                if (v > maxI1) maxI1 = v;
-            } else if (di > dj) {
-                double v = (Y[i] - yj) / (di - dj);
-                if (v < minI2) {
-                    minI2 = v;
-                    if (minI2 <= 0.) { reject = true; break; }
-                }
-            } else if (yj > Y[i]) { reject = true; break; }
-            if (maxI1 != DBL_MIN && minI2 != DBL_MAX && minI2 < maxI1) { reject = true; break; }
-        }
-        if (reject) continue;
-        bool take;
-        if (minI2 == DBL_MAX) take = true;
-        else if (fmin == 0.0) take = (yj <= dj * minI2);
-        else take = (eps <= (fmin - yj) / std::fabs(fmin) + (dj / std::fabs(fmin)) * minI2);
-        if (take) out.push_back(j);
+    // distinct sizes (exact equality, as the reference's <, >, else) with their smallest y
+    std::vector<size_t> order(n);
+    for (size_t j = 0; j < n; j++) order[j] = j;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return Dd[a] < Dd[b] || (Dd[a] == Dd[b] && a < b); });
+    std::vector<double> gd, gy;                    // per group: size, min y
+    std::vector<size_t> gbeg;                      // per group: first position in `order`
+    for (size_t q = 0; q < n; q++) {
+        const size_t j = order[q];
+        if (gd.empty() || Dd[j] != gd.back()) { gd.push_back(Dd[j]); gy.push_back(Y[j]); gbeg.push_back(q); }
+        else if (Y[j] < gy.back()) gy.back() = Y[j];
     }
+    gbeg.push_back(n);
+    const size_t G = gd.size();
+    for (size_t g = 0; g < G; g++) {
+        for (size_t q = gbeg[g]; q < gbeg[g + 1]; q++) {
+            const size_t j = order[q];
+            const double yj = Y[j], dj = Dd[j];
+            if (yj > gy[g]) continue;              // a rectangle of the same size is better
+            double maxI1 = DBL_MIN, minI2 = DBL_MAX;
+            for (size_t h = 0; h < g; h++) {
+                double v = (yj - gy[h]) / (dj - gd[h]);
+                if (v > maxI1) maxI1 = v;
+            }
+            for (size_t h = g + 1; h < G; h++) {
+                double v = (gy[h] - yj) / (gd[h] - dj);
+                if (v < minI2) minI2 = v;
+            }
+            if (minI2 <= 0.) continue;
+            if (maxI1 != DBL_MIN && minI2 != DBL_MAX && minI2 < maxI1) continue;
+            bool take;
+            if (minI2 == DBL_MAX) take = true;
+            else if (fmin == 0.0) take = (yj <= dj * minI2);
+            else take = (eps <= (fmin - yj) / std::fabs(fmin) + (dj / std::fabs(fmin)) * minI2);
+            if (take) out.push_back(j);
+        }
+    }
+    std::sort(out.begin(), out.end());             // the reference collects them in pool order
 }
 
 }  // namespace
@@ -249,7 +279,7 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
         S.apply(dv, pool);
     }
 
-    std::vector<size_t> pot;
+    std::vector<size_t> pot, dead;
     std::vector<Division> divs;
     std::vector<double> pts, vals;
     bool done = false;
@@ -262,6 +292,7 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
             break;
         }
         divs.clear();
+        dead.clear();
         for (size_t q = pot.size(); q-- > 0;) divs.push_back(make_division(pool, pot[q]));   // reverse order
         if (opt.per_rectangle) {
             for (Division &dv : divs) {
@@ -271,7 +302,7 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
                 S.plan_children(dv);
                 if (np && (res.status = S.evaluate(dv.kid_ctr.data(), np, dv.kid_vals.data()))) return res;
                 S.apply(dv, pool);
-                pool.erase(dv.src);
+                dead.push_back(dv.src);
                 if (S.nsamples > (int64_t)(unsigned)opt.maxsample) { done = true; break; }
                 if (time(nullptr) - start > opt.maxtime) { done = true; break; }
             }
@@ -295,11 +326,14 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
             }
             for (Division &dv : divs) {
                 S.apply(dv, pool);
-                pool.erase(dv.src);
+                dead.push_back(dv.src);
                 if (S.nsamples > (int64_t)(unsigned)opt.maxsample) { done = true; break; }
                 if (time(nullptr) - start > opt.maxtime) { done = true; break; }
             }
         }
+        // children were appended behind the old rectangles, so removing the divided ones afterwards, in one
+        // pass, leaves the pool in the order one-by-one removal would
+        pool.erase_many(dead);
         if (time(nullptr) - start > opt.maxtime) break;
         if (S.nsamples > (int64_t)(unsigned)opt.maxsample) break;
     }

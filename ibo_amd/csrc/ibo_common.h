@@ -147,6 +147,8 @@ __device__ __forceinline__ double acq_value_dev(int acq, int erf_mode, double mu
 }
 
 // ---- host-side launch API of the kernels (defined in linalg.hip / sweep.hip)
+#define IBO_SPLIT_PANEL 64      // rows per workgroup of the small-batch (SPLIT) sweep
+
 struct SweepArgs {
     KParams kp;
     int N, Npad, DP;

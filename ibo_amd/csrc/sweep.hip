@@ -479,10 +479,12 @@ static int launch_mfma_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 template <int FAM, bool DOT>
 static int launch_mfma_split(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
-    dim3 grid((unsigned)ntiles, (a.Npad + 127) / 128), block(1024);
-    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, 16, 1, 2, 64, DOT, 128, true>), grid, block, 0, s, a);
-    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, 16, 1, 2, 64, DOT, 128, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, 16, 1, 2, 64, DOT, 128, true>), grid, block, 0, s, a);
+    // IBO_SPLIT_PANEL-row panels: 16 waves = 4 row-blocks x 4 candidate-blocks, one accumulator each
+    static_assert(IBO_SPLIT_PANEL == 64, "the split configuration below tiles a 64-row panel");
+    dim3 grid((unsigned)ntiles, (a.Npad + IBO_SPLIT_PANEL - 1) / IBO_SPLIT_PANEL), block(1024);
+    if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
+    else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -508,7 +510,8 @@ int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
     if (e1) (void)hipEventRecord(e1, s);
     if (rc) return rc;
     if (a.qpart) {
-        hipLaunchKernelGGL(sweep_gemv_finish_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, a, (a.Npad + 127) / 128);
+        hipLaunchKernelGGL(sweep_gemv_finish_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, a,
+                           (a.Npad + IBO_SPLIT_PANEL - 1) / IBO_SPLIT_PANEL);
         rc = (int)hipGetLastError();
         if (rc) return rc;
     }
@@ -536,6 +539,7 @@ int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
 
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
+    if (!a.result_val) return 0;                     // per-point outputs only (DIRECT batches, posteriors): no arg-max wanted
     hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, a.part_val, a.part_idx, ntiles,
                        a.result_val, a.result_idx);
     return (int)hipGetLastError();

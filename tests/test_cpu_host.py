@@ -105,6 +105,32 @@ def test_direct_known_answers(oracle):
     assert ns > 1000 and abs(fm - .04) < 1e-9
 
 
+def test_direct_grouped_selection_matches_the_all_pairs_reference(oracle):
+    """the host DIRECT picks its potentially-optimal rectangles from per-size minima (O(R)) and removes divided
+    rectangles in one pass; the oracle (and the compiled reference) test all pairs and erase one by one: same
+    minimum, same point, same number of samples on assorted objectives, including plateaus and ties"""
+    from ibo_amd.utils.optimize import cdirect
+    rs = np.random.RandomState(17)
+    cases = []
+    for D in (1, 2, 3, 5, 8):
+        c = rs.rand(D); w = rs.uniform(.5, 3, D); ph = rs.rand(D) * 6
+        cases.append((lambda x, c=c, w=w, ph=ph: float(np.sum(w * (x - c) ** 2) + .3 * np.sum(np.sin(9 * x + ph))), D))
+    cases.append((lambda x: float(np.round(np.sum((x - .4) ** 2), 1)), 3))          # plateaus: many equal values
+    cases.append((lambda x: 0.0, 2))                                                 # everything ties
+    cases.append((lambda x: float(-np.prod(np.cos(5 * x))), 4))
+    for f, D in cases:
+        b = [[0., 1.]] * D
+        for maxiter in (7, 35):
+            fm, xm, ns = cdirect(f, b, maxiter=maxiter, maxsample=20000, return_samples=True)
+            o = oracle.cdirect(f, b, maxiter=maxiter, maxsample=20000)
+            assert ns == o[2] and fm == o[0] and np.array_equal(xm, o[1]), (D, maxiter)
+    if oracle.RefLib.available():
+        f, D = cases[3]
+        fm, xm, ns = cdirect(f, [[0., 1.]] * D, maxiter=30, maxsample=20000, return_samples=True)
+        ref = oracle.RefLib().direct(f, [[0., 1.]] * D, maxiter=30, maxsample=20000)
+        assert ns == ref[2] and fm == ref[0] and np.array_equal(xm, ref[1])
+
+
 def test_legacy_direct_symbol_against_compiled_reference(oracle):
     """`direct` with the reference's exact signature (cpp/direct.h:76), same answers as _ref/libego.so"""
     from ibo_amd import _lib
