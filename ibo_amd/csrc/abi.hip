@@ -855,12 +855,20 @@ struct NlmlWorkspace {
     DevBuf<int> dinfo;
 };
 static NlmlWorkspace g_nlml_ws[16];
+struct GradWorkspace {
+    DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout;
+    DevBuf<int> dinfo;
+};
+static GradWorkspace g_grad_ws[16];
 
 extern "C" int ibo_trim(int device)
 {
     IBO_TRY(use_device(device));
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
     ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dinfo.release();
+    GradWorkspace &gw = g_grad_ws[device & 15];
+    gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
+    gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
     return IBO_OK;
 }
 
@@ -942,8 +950,12 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     const int Np = round_up(N, 64);
     const size_t nn = (size_t)Np * Np;
     const int nblk = ((N + 15) / 16) * ((N + 15) / 16);
-    DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout;
-    DevBuf<int> dinfo;
+    // workspace kept between calls (BFGS calls this dozens of times; five N^2 buffers allocated and freed per
+    // call cost as much as the arithmetic); ibo_trim() releases it
+    GradWorkspace &ws = g_grad_ws[device & 15];
+    DevBuf<double> &dX = ws.dX, &dY = ws.dY, &dL = ws.dL, &dW = ws.dW, &dT = ws.dT, &dKi = ws.dKi, &d64 = ws.d64,
+                   &dal = ws.dal, &da1 = ws.da1, &tmp = ws.tmp, &dpart = ws.dpart, &dout = ws.dout;
+    DevBuf<int> &dinfo = ws.dinfo;
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(Np)); IBO_TRY(dL.ensure(nn)); IBO_TRY(dW.ensure(nn));
     IBO_TRY(dT.ensure(nn)); IBO_TRY(dKi.ensure(nn)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096));
     IBO_TRY(dal.ensure(Np)); IBO_TRY(da1.ensure(Np)); IBO_TRY(tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));
@@ -975,8 +987,6 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
         for (int i = 0; i < N; i++) { quad += Y[i] * al[i]; logdet += log(dg[i]); }
         *nlml_host = 0.5 * quad + logdet + 0.5 * N * log(2.0 * M_PI);
     }
-    dX.release(); dY.release(); dL.release(); dW.release(); dT.release(); dKi.release(); d64.release(); dal.release();
-    da1.release(); tmp.release(); dpart.release(); dout.release(); dinfo.release();
     return rc;
 }
 

@@ -75,11 +75,26 @@ def marginalLikelihood(kernel, X, Y, nhyper, computeGradient=True, useCholesky=T
     return v.value, g
 
 
+# fmin_bfgs asks for f(x) and then f'(x) at the same x (also inside its line search); both come out of one
+# factorisation, so the pair is computed once and the last one is remembered
+_last = {"key": None, "value": None, "grad": None}
+
+
+def _value_and_grad(loghyper, kernel, X, Y):
+    loghyper = np.asarray(loghyper, dtype=float)
+    key = (loghyper.tobytes(), kernel, id(X), id(Y), len(Y), float(np.sum(Y)), float(np.sum(X[0])))
+    if _last["key"] != key:
+        k = kernel(np.exp(loghyper))
+        _last["key"] = None
+        _last["value"], _last["grad"] = marginalLikelihood(k, X, Y, len(loghyper), computeGradient=True)
+        _last["key"] = key
+    return _last["value"], _last["grad"]
+
+
 def nlml(loghyper, kernel, X, Y, *args):
     """NLML as a function of LOG hyper-parameters (trainhyper.py:99-115); 100 when not PD."""
-    k = kernel(np.exp(loghyper))
     try:
-        ml = marginalLikelihood(k, X, Y, len(loghyper), computeGradient=False)
+        ml = _value_and_grad(loghyper, kernel, X, Y)[0]
     except LinAlgError as e:
         print(e)
         ml = 100
@@ -96,5 +111,4 @@ def nlmlMulti(loghyper, kernel, X, Y, *args):
 
 
 def dnlml(loghyper, kernel, X, Y):
-    k = kernel(np.exp(loghyper))
-    return marginalLikelihood(k, X, Y, len(loghyper), computeGradient=True)[1]
+    return _value_and_grad(loghyper, kernel, X, Y)[1]

@@ -245,7 +245,8 @@ int ibo_nlml_grid(int device, int ktype, int N, int D,
                   int n_theta, const double *thetas_host, int nhyper,
                   const double *sf2_host /* n_theta or NULL (=1) */, double noise,
                   double *nlml_host);
-/* ibo_nlml_grid keeps its device workspace (the batch of factor matrices) between calls; this releases it. */
+/* ibo_nlml_grid and ibo_nlml_grad keep their device workspaces (the batch of factor matrices; the N x N
+ * buffers of the gradient) between calls; this releases them. */
 int ibo_trim(int device);
 
 /*
