@@ -13,6 +13,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <mutex>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -66,6 +67,52 @@ static int use_device(int device)
     return IBO_OK;
 }
 
+// Device allocations are recycled: a Bayesian-optimisation loop builds a new model (a new handle, five N x N
+// buffers) every round, and hipMalloc/hipFree of tens of megabytes cost more than the fit itself.  Freed
+// blocks go to a per-device free list (up to IBO_POOL_LIMIT bytes; ibo_trim() empties it) and are handed out
+// again to requests of up to half their size less.
+#define IBO_POOL_LIMIT ((size_t)16 << 30)
+struct PoolBlock { void *p; size_t bytes; };
+static std::vector<PoolBlock> g_pool[16];
+static size_t g_pool_bytes[16];
+static std::mutex g_pool_mu;
+
+static void *pool_get(size_t bytes, size_t *got)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    std::vector<PoolBlock> &v = g_pool[dev & 15];
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); i++)
+        if (v[i].bytes >= bytes && v[i].bytes <= 2 * bytes + 4096 && (best == v.size() || v[i].bytes < v[best].bytes)) best = i;
+    if (best == v.size()) return nullptr;
+    void *p = v[best].p;
+    *got = v[best].bytes;
+    g_pool_bytes[dev & 15] -= v[best].bytes;
+    v.erase(v.begin() + best);
+    return p;
+}
+
+static void pool_put(void *p, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceSynchronize();                    // what hipFree would have waited for: nothing in flight uses p
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool_bytes[dev & 15] + bytes > IBO_POOL_LIMIT) { (void)hipFree(p); return; }
+    g_pool[dev & 15].push_back({p, bytes});
+    g_pool_bytes[dev & 15] += bytes;
+}
+
+static void pool_trim(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (PoolBlock &b : g_pool[dev & 15]) (void)hipFree(b.p);
+    g_pool[dev & 15].clear();
+    g_pool_bytes[dev & 15] = 0;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -73,14 +120,25 @@ struct DevBuf {
     int ensure(size_t n)
     {
         if (n <= cap) return IBO_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
-        if (e != hipSuccess) return fail(IBO_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
-        cap = n;
+        release();
+        size_t got = 0;
+        void *q = pool_get(n * sizeof(T), &got);
+        if (!q) {
+            got = n * sizeof(T);
+            hipError_t e = hipMalloc(&q, got);
+            if (e != hipSuccess) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                pool_trim(dev);                       // give the cached blocks back and try once more
+                e = hipMalloc(&q, got);
+            }
+            if (e != hipSuccess) return fail(IBO_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", got, hipGetErrorString(e));
+        }
+        p = (T *)q;
+        cap = got / sizeof(T);
         return IBO_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) pool_put(p, cap * sizeof(T)); p = nullptr; cap = 0; }
 };
 
 struct ibo_gp {
@@ -695,7 +753,8 @@ static int ensure_pinned(ibo_gp *g, size_t need)
     if (need <= g->pin_cap) return IBO_OK;
     if (g->pin) (void)hipHostFree(g->pin);
     g->pin = nullptr; g->pin_cap = 0;
-    size_t cap = need < 4096 ? 4096 : need * 2;
+    // head-room for the small, growing batches of DIRECT; exact for large requests (pinning costs ~1 ms/MB)
+    size_t cap = need < 4096 ? 4096 : (need < ((size_t)1 << 20) ? need * 2 : need);
     HIP_TRY(hipHostMalloc((void **)&g->pin, cap * sizeof(double), hipHostMallocDefault));
     g->pin_cap = cap;
     return IBO_OK;
@@ -869,6 +928,7 @@ extern "C" int ibo_trim(int device)
     GradWorkspace &gw = g_grad_ws[device & 15];
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
     gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
+    pool_trim(device);
     return IBO_OK;
 }
 

@@ -245,8 +245,9 @@ int ibo_nlml_grid(int device, int ktype, int N, int D,
                   int n_theta, const double *thetas_host, int nhyper,
                   const double *sf2_host /* n_theta or NULL (=1) */, double noise,
                   double *nlml_host);
-/* ibo_nlml_grid and ibo_nlml_grad keep their device workspaces (the batch of factor matrices; the N x N
- * buffers of the gradient) between calls; this releases them. */
+/* Device memory is recycled: ibo_nlml_grid and ibo_nlml_grad keep their workspaces (the batch of factor
+ * matrices; the N x N buffers of the gradient) between calls, and the buffers of destroyed handles go to a
+ * per-device free list (at most 16 GiB) for the next handle.  This releases all of it. */
 int ibo_trim(int device);
 
 /*

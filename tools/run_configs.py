@@ -42,8 +42,8 @@ def c2():
     r, ms = tm(lambda: sweep(GP, cand), 5)
     _, dms = tm(lambda: maximizeEI(GP, [[0., 1.]] * 4), 3)
     ch = np.random.RandomState(102).rand(1 << 20, 4)
-    GP.posteriors(ch[:1000])
-    _, pms = tm(lambda: GP._posterior_arrays(ch), 2)      # host in / host out: PCIe-inclusive
+    GP._posterior_arrays(ch)                              # first call pins the staging buffers (one-off, ~40 ms)
+    _, pms = tm(lambda: GP._posterior_arrays(ch), 3)      # host in / host out: PCIe-inclusive, steady state
     return dict(fit_ms=fit, fit_dev_ms=GP.last_fit_ms(), sweep_ms=ms, kernel_ms=r["kernel_ms"], evals_per_s=(1 << 20) / ms * 1e3,
                 maximizeEI_default_ms=dms, best=r["best_idx"], posteriors_host_1M_ms=pms,
                 posteriors_host_evals_per_s=(1 << 20) / pms * 1e3)
