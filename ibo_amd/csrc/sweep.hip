@@ -159,6 +159,40 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
     // produce K* rows [k0, k0+KCH) into stage b (LAST: also accumulate the mean)
     auto gen = [&](int k0, int b, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
+        if constexpr (DP > 8 && FAM != FAM_SE) {
+            // Matern kernels in 9..16 dimensions: the candidate's coordinates come from LDS and one row's 16
+            // scaled observation coordinates fill 32 SGPRs; with the KPW rows unrolled side by side hipcc
+            // spills ~470 registers (SGPRs into VGPR lanes, then VGPRs to scratch) and the kernel runs at 40 %
+            // of the MFMA rate; taking the rows one at a time gives 53 %.  (For the squared exponential the
+            // unrolled form is the better one: 64 % against 55 %.)
+#pragma unroll 1
+            for (int kk = 0; kk < KPW; kk++) {
+                const int k = k0 + kl0 + kk;
+                const double *xr = a.Xs + (size_t)k * DP;
+                double kv;
+                if (DOT) {
+                    double y = a.ak[k] + bc;
+#pragma unroll
+                    for (int d = 0; d < DP; d++) y = fma(xr[d], lds_c[d * TC + lane], y);
+                    if (FAM == FAM_SE) kv = exp_fast(y);
+                    else kv = cov_from_z_fast<FAM>(fmax(-2.0 * y, 0.0), a.log_sf2, a.kp.sf2);
+                } else {
+                    double z = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DP; d++) {
+                        double t = xr[d] - lds_c[d * TC + lane];
+                        z = fma(t, t, z);
+                    }
+                    kv = cov_from_z_fast<FAM>(z, a.log_sf2, a.kp.sf2);
+                }
+                if (LAST) {
+                    muY = fma(a.alphaY[k], kv, muY);
+                    mu1 = fma(a.alpha1[k], kv, mu1);
+                }
+                lds_k[b][wr_off + kk * 16] = kv;
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < KPW; kk++) {
             const int k = k0 + kl0 + kk;

@@ -1,0 +1,17 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from ibo_amd import DeviceArray
+from ibo_amd.gaussianprocess import GaussianProcess
+from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard, MaternKernel5
+from ibo_amd.acquisition import sweep
+N, M = 1024, 1 << 18
+for D in (2, 4, 5, 8, 9, 12, 16):
+    rs = np.random.RandomState(2); X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + 0.01 * rs.randn(N)
+    for name, k in (("SE", GaussianKernel_ard([.3 * np.sqrt(D / 4.)] * D)), ("M5", MaternKernel5([.5 * np.sqrt(D / 4.), 1.0]))):
+        GP = GaussianProcess(k, X, Y, noise=.1)
+        cand = DeviceArray.from_host(rs.rand(M, D))
+        sweep(GP, cand)
+        r = sweep(GP, cand)
+        F = N * N + 3 * N * D + 4 * N
+        print("D=%2d %s  kernel %.2f ms  %.1f TFLOP/s (%.0f %%)" % (D, name, r["kernel_ms"], F * M / r["kernel_ms"] / 1e9, F * M / r["kernel_ms"] / 1e9 / 78.6 * 100), flush=True)
