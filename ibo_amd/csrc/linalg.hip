@@ -137,61 +137,8 @@ int launch_zero_upper(double *A, int Npad, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------
-// 64x64 output tile GEMM on fp64 MFMA, 256 threads (2x2 waves, 32x32 each).
-//   acc += sum_{k in [kbeg,kend)} A[r][k] * (TRANSB ? B[c][k] : B[k][c])
-// kbeg/kend multiples of 16.  As: 64*17 doubles, Bs: max(64*17, 16*80) doubles.
+// 64x64 output tiles on fp64 MFMA, 256 threads (2x2 waves, 32x32 each)
 // ------------------------------------------------------------------------
-#define AS_LD 17
-#define BS_LD 80
-template <bool TRANSB>
-__device__ __forceinline__ void gemm_tile_64(const double *__restrict__ A, int lda,
-                                             const double *__restrict__ B, int ldb, int kbeg, int kend,
-                                             d4_t (&acc)[2][2], double *As, double *Bs)
-{
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
-    // these tiles are latency-bound (a few chunks of K each): the next chunk's global loads are issued
-    // into registers before the MFMAs of the current one, so only the first latency is exposed
-    const int ra = t >> 2, kqa = (t & 3) * 4;
-    const int kb = t >> 4, cqb = (t & 15) * 4;
-    const double *pa = A + (size_t)ra * lda + kqa;
-    const double *pb = TRANSB ? B + (size_t)ra * ldb + kqa : B + (size_t)kb * ldb + cqb;
-    double2 a0, a1, b0, b1;
-    auto fetch = [&](int k0) {
-        const double2 *p = (const double2 *)(pa + k0);
-        a0 = p[0]; a1 = p[1];
-        const double2 *q = (const double2 *)(TRANSB ? pb + k0 : pb + (size_t)k0 * ldb);
-        b0 = q[0]; b1 = q[1];
-    };
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        {
-            double *q = As + ra * AS_LD + kqa;
-            q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y;
-            double *w = TRANSB ? Bs + ra * AS_LD + kqa : Bs + kb * BS_LD + cqb;
-            w[0] = b0.x; w[1] = b0.y; w[2] = b1.x; w[3] = b1.y;
-        }
-        __syncthreads();
-        if (k0 + 16 < kend) fetch(k0 + 16);
-#pragma unroll
-        for (int k4 = 0; k4 < 4; k4++) {
-            double a[2], b[2];
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-                a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * AS_LD + k4 * 4 + (lane >> 4)];
-#pragma unroll
-            for (int n = 0; n < 2; n++) {
-                if (TRANSB) b[n] = Bs[(wc * 32 + n * 16 + (lane & 15)) * AS_LD + k4 * 4 + (lane >> 4)];
-                else b[n] = Bs[(k4 * 4 + (lane >> 4)) * BS_LD + wc * 32 + n * 16 + (lane & 15)];
-            }
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int n = 0; n < 2; n++) acc[m][n] = mfma_f64(a[m], b[n], acc[m][n]);
-        }
-        __syncthreads();
-    }
-}
-
 // K = 64 in one stage (the factorisation's trsm / syrk tiles): both 64x64 operand tiles are fetched with
 // every load in flight at once -- one global-memory latency instead of four.  acc += A * B^T.
 // As, Bs: 64 * T64_LD doubles each.
@@ -829,17 +776,17 @@ __global__ void transpose_kernel(const double *__restrict__ A, double *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W,
                                                   double *__restrict__ C, int Npad)
 {
-    __shared__ double As[64 * AS_LD];
-    __shared__ double Bs[16 * BS_LD];
+    __shared__ double As[64 * T64_LD];
+    __shared__ double Bs[64 * TNN_LD];
     TILE_IDS;
     int ti = blockIdx.y, tj = blockIdx.x;
     const double *A = Wt + (size_t)ti * 64 * Npad;              // rows i of W^T, all k
     const double *B = W + (size_t)tj * 64;                      // columns j of W
     d4_t acc[2][2] = {};
-    gemm_tile_64<false>(A, Npad, B, Npad, max(ti, tj) * 64, Npad, acc, As, Bs);
+    tile64_gemm_nn(A, Npad, B, Npad, max(ti, tj), Npad / 64, acc, As, Bs);      // W is lower triangular: k >= max(i, j)
     double *Ct = C + (size_t)ti * 64 * Npad + (size_t)tj * 64;
 #pragma unroll
     for (int m = 0; m < 2; m++)
