@@ -492,6 +492,9 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *L, int Npad, int
             for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
 }
 
+// (amdgpu_waves_per_eu(2, 2) on the kernels with a K loop: with (1, 2) hipcc puts the accumulators in AGPRs and
+// copies all 32 of them in and out of VGPRs on EVERY loop iteration -- one wasted VALU instruction per MFMA, on the
+// pipe the MFMAs need; with the 256-register budget it keeps them in VGPRs and the copies disappear.)
 // update with finished block columns [j0, j1):  A[i][k] -= sum_j L[i][j] L[k][j]^T  for the block columns
 // k in [k0, k1) and the block rows i >= k.  One 64x64 tile per workgroup; the K loop runs in 64-wide stages
 // with the next stage's operands (and, first, the tile itself) in flight.
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *L, int Npad, int
 // workgroup b belongs to XCD b % 8 and that XCD's 64 consecutive workgroups are given one 8x8 super-block
 // of tiles -- 16 operand strips of 64 x 64(j1-j0) serve 64 tiles out of L2 instead of being re-fetched
 // from the Infinity Cache (with the operands also kept out of scratch, K = 256 updates went from 18 to 35 TFLOP/s at N = 4096).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void chol_update_kernel(double *L, int Npad, int j0, int j1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chol_update_kernel(double *L, int Npad, int j0, int j1,
                                                           int k0, int k1, int nsb, size_t lstride, const double *P)
 {
     __shared__ double As[64 * T64_LD];
@@ -694,7 +697,7 @@ __device__ __forceinline__ void tile64_gemm_nn(const double *__restrict__ A, int
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W, double *__restrict__ T, int Npad,
                     int s, int nb)
 {
@@ -718,7 +721,7 @@ void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W, 
             for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T, int Npad, int s, int nb)
 {
     __shared__ double As[64 * T64_LD];
@@ -776,7 +779,7 @@ __global__ void transpose_kernel(const double *__restrict__ A, double *__restric
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W,
                                                   double *__restrict__ C, int Npad)
 {
     __shared__ double As[64 * T64_LD];
