@@ -606,6 +606,25 @@ def test_cholesky_panel_orders_agree(ibo):
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[4:5], X[:300], Y[:300], noise=.01)[0], vals[4:5])
 
 
+def test_recycled_device_buffers_do_not_leak_state(ibo, oracle):
+    """buffers of destroyed models are handed to the next one (possibly larger than it asked for, full of the old
+    model's data): results must only depend on the new model; ibo_amd.trim() empties the free list"""
+    import gc
+    import ibo_amd
+    from ibo_amd.gaussianprocess import GaussianProcess, kernel as K
+    probe = np.random.RandomState(77).rand(40, 3)
+    for rnd in range(2):
+        for N in (500, 300, 64, 700, 1, 300):
+            X, Y = synth(60 + N, N, 3)
+            GP = GaussianProcess(K.GaussianKernel_ard([.3, .4, .5]), X, Y, noise=.1)
+            mu, s2 = GP.posteriors(probe)
+            o_mu, o_s2 = oracle.GP(oracle.Kern("ard", [.3, .4, .5]), X, Y, noise=.1).posteriors(probe)
+            close(mu, o_mu, atol=1e-9); close(s2, o_s2)
+            del GP
+            gc.collect()
+        ibo_amd.trim()
+
+
 def test_large_host_batches_are_pipelined_without_changing_results(ibo):
     """GP.posteriors on a big NumPy array goes through overlapped 2^17-point chunks (upload / sweep / download on
     three streams): same numbers as the single-shot path, ragged last chunk included"""
