@@ -606,6 +606,38 @@ def test_cholesky_panel_orders_agree(ibo):
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[4:5], X[:300], Y[:300], noise=.01)[0], vals[4:5])
 
 
+def test_randomised_parity_sweep(ibo, oracle):
+    """a seeded slice of tools/fuzz_gpu.py: random (N, D, kernel family, noise, M) -- fit, posterior mean/variance and
+    libego-flavoured EI of every candidate against the oracle, all within the 1e-6 bar; arg-max = first maximiser"""
+    from ibo_amd.gaussianprocess import GaussianProcess, kernel as K
+    from ibo_amd.acquisition import sweep
+    rs = np.random.RandomState(20261003)
+    worst = 0.0
+    for case in range(24):
+        N = int([1, 63, 64, 65, 129, 511][case] if case < 6 else rs.randint(2, 700))
+        D = int(rs.randint(1, 17))
+        kind = ["ard", "iso", "m3", "m5"][rs.randint(4)]
+        M = int([1, 17, 64, 65, 1000, 8193][rs.randint(6)])
+        noise = float([.1, .01][rs.randint(2)])
+        X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
+        th = np.exp(rs.uniform(np.log(.2), np.log(1.5), size=D))
+        hyp = {"ard": th, "iso": th[:1], "m3": np.r_[th[0], 1.0], "m5": np.r_[th[0], 1.0]}[kind]
+        cls = {"ard": K.GaussianKernel_ard, "iso": K.GaussianKernel_iso, "m3": K.MaternKernel3, "m5": K.MaternKernel5}[kind]
+        ogp = oracle.GP(oracle.Kern(kind, hyp), X, Y, noise=noise)
+        GP = GaussianProcess(cls(hyp), X, Y, noise=noise)
+        cand = rs.rand(M, D)
+        Mo = min(M, 200)
+        r = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+        o = oracle.sweep_native(ogp, cand[:Mo], oracle.ACQ_EI, .01)
+        for key in ("mu", "s2", "acq"):
+            err = np.abs(r[key][:Mo] - o[key]) / np.maximum(np.abs(o[key]), 1e-9)
+            if key == "acq":
+                err = err * (np.abs(o[key]) > ACQ_ATOL)
+            worst = max(worst, float(err.max()))
+        assert r["best_idx"] == int(np.argmax(r["acq"])), (N, D, kind, M)
+    assert worst < RT, worst
+
+
 def test_bayesian_optimisation_loop_end_to_end(ibo):
     """the loop the reference exists for (demo.py:59-98, repeated): fit -> maximizeEI -> evaluate -> addData.
     25 rounds on a smooth 2-D objective with a known maximum must get within 1e-2 of it, and every model refit /
