@@ -190,9 +190,13 @@ __device__ unsigned long long g_chol_stamps[32];
 __device__ unsigned long long g_upd_stamps[4][32];      // update kernel: 4 sampled workgroups of batch member 0
 #define USTAMP(i) do { if (threadIdx.x == 0 && blockIdx.z == 0 && (blockIdx.x & 1023) == 8 && (blockIdx.x >> 10) < 4) \
         g_upd_stamps[blockIdx.x >> 10][i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_step_stamps[2][16];      // step kernel: workgroup 0 and workgroup 7
+#define SSTAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 7)) \
+        g_step_stamps[blockIdx.x ? 1 : 0][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CSTAMP(i)
 #define USTAMP(i)
+#define SSTAMP(i)
 #endif
 __device__ __forceinline__ double lane_bcast(double x, int l)          // value of lane l, wave-uniform
 {
@@ -412,6 +416,7 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
     double *Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
     double *C = L + (size_t)i * 64 * Npad + k * 64;
     // everything this workgroup will need from memory is requested before the chain starts
+    SSTAMP(0);
     d2_t va[8], vb[8];
     tile64_fetch(Ai, Npad, va);
     tile64_fetch(Ak, Npad, vb);
@@ -424,17 +429,23 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
             for (int r = 0; r < 4; r++) c[m][n][r] = C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)];
     diag64_load(L + doff, Npad, S, V);
     __syncthreads();
+    SSTAMP(1);
     diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
+    SSTAMP(2);
     if (blockIdx.x == 0) diag64_store(Lout + doff, Npad, diag64 + (size_t)jb * 4096, S, V);
     __syncthreads();                                   // S is about to be reused
+    SSTAMP(3);
     // X_i = A_i V^T, X_k = A_k V^T  (V[c][k] row-major is the "B^T" operand as it stands)
     tile64_stash<false, SD>(S, va);
     tile64_stash<false, SD>(T, vb);
     __syncthreads();
+    SSTAMP(4);
     d4_t xi[2][2] = {}, xk[2][2] = {};
     tile64_mma_nt<SD>(S, V, xi);
     tile64_mma_nt<SD>(T, V, xk);
+    SSTAMP(5);
     __syncthreads();
+    SSTAMP(6);
     if (k == jb + 1) {                                 // first trailing column: this row block of L is final
 #pragma unroll
         for (int m = 0; m < 2; m++)
@@ -453,13 +464,16 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
                 T[TILE_ROW(m, r) * SD + TILE_COL(n)] = xk[m][n][r];
             }
     __syncthreads();
+    SSTAMP(7);
     tile64_mma_nt<SD>(S, T, c);
+    SSTAMP(8);
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = c[m][n][r];
+    SSTAMP(9);
 }
 
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T

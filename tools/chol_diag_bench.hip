@@ -32,6 +32,29 @@ int main()
         }
         printf("  inverses %llu  doubling %llu  store %llu\n", st[21] - prev, st[22] - st[21], st[23] - st[22]);
     }
+    {   // fused step kernel stamps: block column 0 of a 1024 x 1024 matrix (120 workgroups)
+        const int Np = 1024;
+        std::vector<double> M((size_t)Np * Np);
+        for (int i = 0; i < Np; i++)
+            for (int j = 0; j < Np; j++) M[(size_t)i * Np + j] = (i == j ? 1.1 : 0.0) + exp(-0.5 * (i - j) * (double)(i - j) / 900.0);
+        double *dW, *dO, *d64; int *dinfo;
+        hipMalloc(&dW, sizeof(double) * Np * Np); hipMalloc(&dO, sizeof(double) * Np * Np); hipMalloc(&d64, sizeof(double) * 16 * 4096); hipMalloc(&dinfo, 4);
+        for (int rep = 0; rep < 2; rep++) {
+            hipMemcpy(dW, M.data(), sizeof(double) * Np * Np, hipMemcpyHostToDevice);
+            hipMemset(dinfo, 0, 4);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(chol_step_kernel, dim3(15 * 16 / 2), dim3(256), 0, 0, dW, dO, Np, 0, d64, dinfo);
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long ss[2][16];
+            hipMemcpyFromSymbol(ss, HIP_SYMBOL(g_step_stamps), sizeof(ss));
+            for (int w = 0; w < 2; w++)
+                printf("step kernel (%.1f us by events) wg %d: fetch-issue+load %llu  diag chain %llu  store+sync %llu  stash+sync %llu  2 trsm products %llu  sync %llu  X to LDS+sync %llu  update product %llu  store %llu   total %llu cycles\n",
+                       ms * 1e3, w ? 7 : 0, ss[w][1] - ss[w][0], ss[w][2] - ss[w][1], ss[w][3] - ss[w][2], ss[w][4] - ss[w][3], ss[w][5] - ss[w][4],
+                       ss[w][6] - ss[w][5], ss[w][7] - ss[w][6], ss[w][8] - ss[w][7], ss[w][9] - ss[w][8], ss[w][9] - ss[w][0]);
+        }
+    }
     {   // update kernel stamps: first K = 256 update of a batch of 16 matrices with 66 block rows
         const int Np = 66 * 64, B = 16;
         double *dL; hipMalloc(&dL, sizeof(double) * (size_t)Np * Np * B);
