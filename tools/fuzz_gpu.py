@@ -16,7 +16,7 @@ special_N = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 25
 worst = 0.0
 t0 = time.time()
 for case in range(ncases):
-    N = int(special_N[case % len(special_N)] if case < 2 * len(special_N) else rs.randint(1, 1500))
+    N = int(special_N[case % len(special_N)] if case < 2 * len(special_N) else rs.randint(1, int(os.environ.get("FUZZ_NMAX", "1500"))))
     D = int(rs.randint(1, 17))
     kind = ["ard", "iso", "m3", "m5"][rs.randint(4)]
     M = int([1, 3, 16, 17, 64, 65, 1000, 8192, 8193, 20000][rs.randint(10)])
