@@ -2,10 +2,18 @@
 """
 bench.py -- EI evaluations/second of the fused candidate sweep (+ GP-fit ms).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], SURVEY 8d "C2"): N=1024 observations, D=4,
+Both launch forms work.  Called plainly with --gpus N > 1 the script starts N fresh rank
+processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT / IBO_COMM_ID_FILE in their
+environment) BEFORE anything touches the GPU, relays rank 0's JSON line and exits non-zero if
+any rank fails; under torch.distributed.run it reads the launcher's environment.  Either way
+there is one process per GPU and no torch inside them (torch bundles its own HIP runtime; two
+GPU runtimes in one process do not coexist): the RCCL unique id travels through a private file,
+barriers and the max-over-ranks timing are RCCL collectives (ibo_amd/multigpu.py, csrc/comm.hip).
+
+Default workload (BASELINE.json configs[1], SURVEY 8d "C2"): N=1024 observations, D=4,
 squared-exponential ARD kernel theta=0.3, noise 0.1, X = RandomState(2).rand, Y =
 sin(3 sum X)+0.01 randn; EI (xi=.01, libm erf, native clamp) over 2^20 candidates
 per GPU = RandomState(102+rank).rand, already resident in HBM when the timed region
@@ -14,18 +22,29 @@ starts.  A "step" is one full sweep of the rank's candidates, ending with the
 exchange.  Weak scaling: every rank sweeps its own 2^20 candidates (global M =
 N * 2^20), the fitted GP is replicated (each rank fits it itself).
 
-One JSON line on rank 0; `value` = all ranks' candidates * steps / max-over-ranks time.
+--config c3: BASELINE configs[2] as a strong-scaling sweep: N=2048, D=8, Matern-5/2, 4M
+candidates cut into N contiguous shards, one EI sweep + one exchange per step.
+--config c5: BASELINE configs[4]: N=4096, D=16, ARD marginal-likelihood grid, 64 theta-points
+per GPU per step, gathered by one all-reduce (weak scaling; value = theta-points/s).
+
+One JSON line on rank 0; `value` = all ranks' units * steps / max-over-ranks time.
 roofline: the sweep kernel is fp64-MFMA bound; algorithmic flops per evaluation
 F = N^2 + 3ND + 4N, achieved = F * M / mean kernel time measured with HIP
 events on the kernel's own stream inside the timed region.
+`configs` (default config only, after the timed region): the other halves of the metric on
+the same clock -- GP-fit ms at N=1024/2048/4096, the C3 shard sweep and gallery-8, the C4
+preference GP (one GPU only) and the C5 grid, each with its own roofline block from SURVEY
+8(d)'s flop counts.
 cpu_baseline (rank 0, N=1 only): the reference's own compiled C++ (oracle/_ref/libego.so,
 negei through acqmaxGP with every dimension fixed = exactly one evaluation per call) on a
 bounded sample of the same candidates; falls back to the plain-C port if _ref is absent.
 """
 import argparse
-import ctypes
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,6 +55,31 @@ sys.path.insert(0, ROOT)
 
 N_OBS, DIM, M_PER_GPU = 1024, 4, 1 << 20
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 matrix = vector peak (AMD spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+C3_N, C3_D, C3_M_TOTAL, C3_SHARD = 2048, 8, 1 << 22, 1 << 19
+C5_N, C5_D, C5_T = 4096, 16, 64
+
+
+def f_eval(N, D):
+    """algorithmic flops of one posterior + acquisition evaluation"""
+    return N * N + 3 * N * D + 4 * N
+
+
+def f_fit(N, D):
+    """K assembly + Cholesky + W = L^-1 + alpha"""
+    return N * N / 2.0 * (3 * D + 2) + 2.0 * N ** 3 / 3.0 + 2.0 * N * N
+
+
+def f_nlml(N, D):
+    """K assembly + Cholesky + the two reductions, no gradient"""
+    return N * N / 2.0 * (3 * D + 2) + N ** 3 / 3.0 + 2.0 * N * N
+
+
+def roofline_mfma(flops, seconds, **extra):
+    a = flops / seconds / 1e12
+    out = {"bound": "mfma", "achieved": a, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / FP64_PEAK_TFLOPS,
+           "traffic": None}
+    out.update(extra)
+    return out
 
 
 def synth(seed, N, D):
@@ -43,6 +87,15 @@ def synth(seed, N, D):
     X = rs.rand(N, D)
     Y = np.sin(3 * X.sum(1)) + 0.01 * rs.randn(N)
     return X, Y
+
+
+def hartman6(x):
+    """ego/utils/testfunctions.py:280-304 (maximised), the C4 preference oracle"""
+    A = np.array([[10, 3, 17, 3.5, 1.7, 8], [0.05, 10, 17, 0.1, 8, 14], [3, 3.5, 1.7, 10, 17, 8], [17, 8, 0.05, 10, 0.1, 14]])
+    P = np.array([[0.1312, 0.1696, 0.5569, 0.0124, 0.8283, 0.5886], [0.2329, 0.4135, 0.8307, 0.3736, 0.1004, 0.9991],
+                  [0.2348, 0.1451, 0.3522, 0.2883, 0.3047, 0.6650], [0.4047, 0.8828, 0.8732, 0.5743, 0.1091, 0.0381]])
+    C = np.array([1, 1.2, 3, 3.2])
+    return float(np.sum(C * np.exp(-np.sum(A * (x - P) ** 2, axis=1))))
 
 
 def cpu_baseline(X, Y, cand, budget_s=12.0):
@@ -87,14 +140,95 @@ def cpu_baseline(X, Y, cand, budget_s=12.0):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def self_launch(ngpus, argv, timeout_s=3000.0, script=None):
+    """Start one fresh process per GPU and relay rank 0's JSON line.  Runs before this process has
+    imported ibo_amd or made any HIP call: the children are ordinary subprocesses (never an exec of
+    a process that touched the GPU).  Returns the exit status."""
+    import shutil
+    import tempfile
+    rdv = tempfile.mkdtemp(prefix="ibo_bench_")              # 0700, fresh per run: nobody else can plant the id
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    try:
+        for r in range(ngpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, IBO_COMM_ID_FILE=os.path.join(rdv, "rccl_id"),
+                       IBO_BENCH_CHILD="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            out = subprocess.PIPE if r == 0 else sys.stderr      # only rank 0 owns the JSON line
+            procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env, stdout=out))
+        t0 = time.time()
+        status = 0
+        pending = set(range(ngpus))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, rc))
+            if status != 0 or time.time() - t0 > timeout_s:
+                if status == 0:
+                    status = 4
+                    sys.stderr.write("bench.py: ranks still running after %.0f s; stopping them\n" % timeout_s)
+                for r in pending:
+                    procs[r].terminate()                          # exactly the children started above
+                for r in pending:
+                    try:
+                        procs[r].wait(20)
+                    except subprocess.TimeoutExpired:
+                        procs[r].kill()
+                pending.clear()
+                break
+            if pending:
+                time.sleep(0.05)
+        line = procs[0].stdout.read().decode("utf-8", "replace") if procs[0].stdout else ""
+        if status == 0:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            if not line.strip():
+                sys.stderr.write("bench.py: rank 0 printed nothing\n")
+                status = 5
+        else:
+            sys.stderr.write(line)
+        return status
+    finally:
+        shutil.rmtree(rdv, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------ worker
+def pmc_numbers():
+    """HBM bytes per launch cannot be read live; they come from committed rocprofv3 --pmc passes over this
+    same command (tools/profile_bench.sh).  A summary is used only when it was taken from THIS build of the
+    sweep kernel: its `source_sha` must equal the hash of the kernel sources in the tree."""
+    h = hashlib.sha256()
+    for f in ("ibo_amd/csrc/sweep.hip", "ibo_amd/csrc/ibo_common.h"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    sha = h.hexdigest()[:16]
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sweep_pmc.json")), reverse=True):
+        try:
+            j = json.load(open(p))
+        except Exception:
+            continue
+        if j.get("source_sha") == sha:
+            return j, os.path.relpath(p, ROOT), sha
+    return None, None, sha
+
+
+def worker(args):
     # stdout carries exactly one line, the JSON: everything else that writes to file descriptor 1 (RCCL prints a
     # version / hostname / library-path banner through C stdio, flushed at exit) is sent to stderr
     sys.stdout.flush()
@@ -104,10 +238,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     os.environ["IBO_DEVICE"] = str(local_rank)
     if world > 1:
         # one node: RCCL's bootstrap sockets go over loopback (the container hostname may not
@@ -115,21 +247,19 @@ def main():
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    import ibo_amd
+    import ibo_amd                                                                  # noqa: F401
     from ibo_amd import _lib, DeviceArray
-    from ibo_amd.gaussianprocess import GaussianProcess
-    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess import GaussianProcess, PrefGaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard, MaternKernel5
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid
     from ibo_amd.acquisition import sweep
-    from ibo_amd.multigpu import RcclArgmax, exchange_unique_id
+    from ibo_amd.acquisition.gallery import fastUCBGallery
+    from ibo_amd.multigpu import RcclArgmax, exchange_unique_id, sharded_gallery, sharded_nlml_grid, shard_bounds
 
-    # No torch in this process: torch bundles its own HIP/HSA runtime and two GPU runtimes in one
-    # process do not coexist (second one finds no device / heap corruption at exit).  The launcher
-    # (torch.distributed.run) only provides RANK/LOCAL_RANK/WORLD_SIZE/MASTER_PORT; rendezvous is a
-    # file in /tmp keyed by the launcher's pid, barriers and the max-over-ranks are RCCL collectives.
     _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
     comm = None
     id_path = None
-    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
+    if world > 1 or "RANK" in os.environ:          # launched as a rank (also with one rank)
         import threading
 
         def _stuck():
@@ -143,6 +273,8 @@ def main():
         comm = RcclArgmax(world, rank, uid, device=local_rank)
         comm.barrier()
         watchdog.cancel()
+        if comm.nranks() != world:
+            raise SystemExit("RCCL reports %d ranks, expected %d" % (comm.nranks(), world))
 
     def barrier():
         _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
@@ -150,84 +282,270 @@ def main():
             comm.barrier()
         _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
 
-    X, Y = synth(2, N_OBS, DIM)
-    GP = GaussianProcess(GaussianKernel_ard([.3] * DIM), X, Y, noise=.1, device=local_rank)
-    fit_ms = []
-    for _ in range(5):                                  # GP-fit ms: host X,Y -> K, L, L^-1, alpha on device
+    def max_over_ranks(x):
+        return x if comm is None else comm.argmax(x, rank)[0]
+
+    def timed(step, steps, warmup):
+        """W untimed steps, then exactly K steps between two barrier+synchronize pairs; max over ranks"""
+        for _ in range(warmup):
+            step()
+        barrier()
         t0 = time.perf_counter()
-        GP._fit_device()
-        fit_ms.append((time.perf_counter() - t0) * 1e3)
-    fit_dev_ms = GP.last_fit_ms()
+        outs = [step() for _ in range(steps)]
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0), outs
 
-    cand_host = np.random.RandomState(102 + rank).rand(M_PER_GPU, DIM)
-    cand = DeviceArray.from_host(cand_host, local_rank)
-    start = rank * M_PER_GPU
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rccl_nranks": comm.nranks() if comm is not None else None,
+            "launcher": "self (bench.py children)" if os.environ.get("IBO_BENCH_CHILD") else
+                        ("torch.distributed.run" if "RANK" in os.environ else "single process")}
 
-    def step():
+    # ---------------------------------------------------------------- C3: strong-scaling sharded sweep
+    def c3_setup(M_total):
+        X, Y = synth(3, C3_N, C3_D)
+        GP = GaussianProcess(MaternKernel5([.5, 1.0]), X, Y, noise=.1, device=local_rank)
+        a, b = shard_bounds(M_total, world, rank)
+        # every rank draws the same stream and keeps its own rows: the global array is the same for any N
+        rs = np.random.RandomState(103)
+        blk = 1 << 18
+        rows = []
+        for s0 in range(0, M_total, blk):
+            chunk = rs.rand(min(blk, M_total - s0), C3_D)
+            lo, hi = max(a, s0), min(b, s0 + len(chunk))
+            if lo < hi:
+                rows.append(chunk[lo - s0:hi - s0])
+        host = np.concatenate(rows) if rows else np.zeros((0, C3_D))
+        return GP, DeviceArray.from_host(host, local_rank), host, a
+
+    def c3_step(GP, cand, host, start):
+        if comm is None:
+            r = sweep(GP, cand, acq='ei', xi=.01, native=True, index_base=start)
+            return r["best_val"], r["best_idx"], r["kernel_ms"]
         r = sweep(GP, cand, acq='ei', xi=.01, native=True, index_base=start)
-        if comm is not None:
-            x = cand_host[r["best_idx"] - start]
-            v, i, _, _ = comm.argmax(r["best_val"], r["best_idx"], x)
-            return v, i, r["kernel_ms"]
-        return r["best_val"], r["best_idx"], r["kernel_ms"]
+        x = host[r["best_idx"] - start] if r["best_idx"] >= 0 else np.zeros(C3_D)
+        v, i, _, _ = comm.argmax(r["best_val"], r["best_idx"], x)
+        return v, i, r["kernel_ms"]
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kms = []
-    best = None
-    for _ in range(args.steps):
-        v, i, ms = step()
-        kms.append(ms)
-        best = (v, i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if comm is not None:
-        elapsed = comm.argmax(elapsed, rank)[0]     # max over ranks (every rank gets it)
+    # ---------------------------------------------------------------- C5: sharded NLML grid
+    def c5_setup():
+        X, Y = synth(5, C5_N, C5_D)
+        allth = np.exp(np.random.RandomState(105).uniform(np.log(.1), np.log(3), size=(512, C5_D)))
+        T = C5_T * world
+        return X, Y, allth[:T] if T <= 512 else np.tile(allth, (T // 512 + 1, 1))[:T]
+
+    def c5_step(X, Y, thetas):
+        if comm is None:
+            return nlml_grid(GaussianKernel_ard, thetas, X, Y, noise=1e-3, device=local_rank)
+        return sharded_nlml_grid(GaussianKernel_ard, thetas, X, Y, comm, noise=1e-3, device=local_rank)
+
+    out = None
+    if args.config == "c3":
+        GP, cand, host, start = c3_setup(C3_M_TOTAL)
+        elapsed, outs = timed(lambda: c3_step(GP, cand, host, start), args.steps, args.warmup)
+        if rank == 0:
+            kmean = float(np.mean([o[2] for o in outs])) * 1e-3
+            out = dict(base)
+            out.update({
+                "metric": "EI evals/sec (N=2048 obs, D=8, Matern-5/2, 2^22 candidates sharded over the GPUs)",
+                "value": float(C3_M_TOTAL) * args.steps / elapsed, "unit": "EI evals/s",
+                "ms_per_step": elapsed / args.steps * 1e3, "scaling": "strong",
+                "config": {"workload": "C3: N=2048 obs, D=8, MaternKernel5([.5, 1]), noise 0.1, EI xi=0.01 (libm erf), "
+                                       "2^22 candidates in %d contiguous shard(s) resident in HBM, arg-max exchange each step" % world,
+                           "n_obs": C3_N, "dim": C3_D, "candidates_total": C3_M_TOTAL,
+                           "parallelism": "candidate-sharded x%d, replicated GP, 1 RCCL arg-max exchange/step" % world},
+                "best": {"value": outs[-1][0], "index": int(outs[-1][1])},
+                "roofline": roofline_mfma(f_eval(C3_N, C3_D) * float(len(host)), kmean, kernel="sweep_mfma_kernel",
+                                          kernel_ms=kmean * 1e3, flops_per_eval=f_eval(C3_N, C3_D),
+                                          evals_per_launch=len(host)),
+            })
+    elif args.config == "c5":
+        X, Y, thetas = c5_setup()
+        elapsed, outs = timed(lambda: c5_step(X, Y, thetas), args.steps, args.warmup)
+        if rank == 0:
+            per_theta = elapsed / args.steps / C5_T            # each GPU does C5_T points per step
+            out = dict(base)
+            out.update({
+                "metric": "NLML grid theta-points/sec (N=4096 obs, D=16, SE-ARD, 64 theta-points per GPU)",
+                "value": float(C5_T * world) * args.steps / elapsed, "unit": "theta-points/s",
+                "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
+                "config": {"workload": "C5: N=4096 obs, D=16, GaussianKernel_ard theta-grid, noise 1e-3, 64 theta-points per GPU "
+                                       "per step (host X,Y in, NLML values + argmin out), gathered by one all-reduce",
+                           "n_obs": C5_N, "dim": C5_D, "theta_points_per_gpu": C5_T,
+                           "parallelism": "theta-sharded x%d, 1 RCCL all-reduce/step" % world},
+                "best": {"value": float(np.nanmin(outs[-1][0])), "index": int(outs[-1][1])},
+                "roofline": roofline_mfma(f_nlml(C5_N, C5_D), per_theta, kernel="chol_update_kernel (dominant)",
+                                          ms_per_theta=per_theta * 1e3, flops_per_theta=f_nlml(C5_N, C5_D),
+                                          note="whole grid step incl. K assembly, factorisation chain, reductions and the "
+                                               "gather; per-kernel times are in profiles/"),
+            })
+    else:
+        X, Y = synth(2, N_OBS, DIM)
+        GP = GaussianProcess(GaussianKernel_ard([.3] * DIM), X, Y, noise=.1, device=local_rank)
+        fit_ms = []
+        for _ in range(5):                                  # GP-fit ms: host X,Y -> K, L, L^-1, alpha on device
+            t0 = time.perf_counter()
+            GP._fit_device()
+            fit_ms.append((time.perf_counter() - t0) * 1e3)
+        fit_dev_ms = GP.last_fit_ms()
+
+        cand_host = np.random.RandomState(102 + rank).rand(M_PER_GPU, DIM)
+        cand = DeviceArray.from_host(cand_host, local_rank)
+        start = rank * M_PER_GPU
+
+        def step():
+            r = sweep(GP, cand, acq='ei', xi=.01, native=True, index_base=start)
+            if comm is not None:
+                x = cand_host[r["best_idx"] - start]
+                v, i, _, _ = comm.argmax(r["best_val"], r["best_idx"], x)
+                return v, i, r["kernel_ms"]
+            return r["best_val"], r["best_idx"], r["kernel_ms"]
+
+        elapsed, outs = timed(step, args.steps, args.warmup)
+        if rank == 0:
+            total = float(M_PER_GPU) * world * args.steps
+            fe = f_eval(N_OBS, DIM)
+            kmean = float(np.mean([o[2] for o in outs])) * 1e-3
+            out = dict(base)
+            out.update({
+                "metric": "EI evals/sec (N=1024 obs, D=4, SE-ARD, 2^20 candidates/GPU sweep)",
+                "value": total / elapsed, "unit": "EI evals/s", "ms_per_step": elapsed / args.steps * 1e3,
+                "scaling": "weak",
+                "config": {"workload": "C2: N=1024 obs, D=4, GaussianKernel_ard(0.3), noise 0.1, EI xi=0.01 (libm erf), "
+                                       "2^20 candidates per GPU resident in HBM, arg-max to host each step",
+                           "n_obs": N_OBS, "dim": DIM, "candidates_per_gpu": M_PER_GPU,
+                           "parallelism": "candidate-sharded x%d, replicated GP, 1 RCCL arg-max exchange/step" % world},
+                "gp_fit_ms": {"host_to_ready_median": float(np.median(fit_ms)), "device_events": fit_dev_ms,
+                              "N": N_OBS, "D": DIM},
+                "best": {"value": outs[-1][0], "index": int(outs[-1][1])},
+                "roofline": roofline_mfma(fe * float(M_PER_GPU), kmean, kernel="sweep_mfma_kernel", kernel_ms=kmean * 1e3,
+                                          flops_per_eval=fe, evals_per_launch=M_PER_GPU),
+            })
+            j, src, sha = pmc_numbers()
+            out["roofline"]["algorithmic_bytes_per_launch"] = (8 * DIM + 16) * M_PER_GPU
+            out["roofline"]["kernel_source_sha"] = sha
+            if j is not None:
+                out["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; same kernel sources)" % src
+                out["roofline"]["mfma_util_pct_pmc"] = j.get("mfma_util_pct")
+            else:
+                out["roofline"]["traffic_source"] = "no committed PMC summary matches this build of the kernel"
+
+        if not args.no_extras:
+            # ------------------------------------------------ the rest of the metric, on the same clock
+            cfgs = {}
+            # GP-fit ms (rank 0 is enough: the fit is single-GPU and replicated)
+            if rank == 0:
+                fits = {}
+                for (n, d, kern) in ((1024, 4, GaussianKernel_ard([.3] * 4)), (2048, 8, MaternKernel5([.5, 1.0])),
+                                     (4096, 16, GaussianKernel_ard([.3] * 16))):
+                    Xf, Yf = synth(7, n, d)
+                    g = GaussianProcess(kern, Xf, Yf, noise=.1, device=local_rank)
+                    dev, host_ms = [], []
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        g._fit_device()
+                        host_ms.append((time.perf_counter() - t0) * 1e3)
+                        dev.append(g.last_fit_ms())
+                    ms = float(np.median(dev))
+                    fits["N%d_D%d" % (n, d)] = {"device_ms": ms, "host_to_ready_ms": float(np.median(host_ms)),
+                                                "roofline": roofline_mfma(f_fit(n, d), ms * 1e-3, flops=f_fit(n, d),
+                                                                          kernels="cov_matrix + chol_step/chol_* + trinv_* + pack_w + gemv")}
+                    # one more observation through addData (block extension of L and W, not a refit)
+                    xa = np.random.RandomState(8).rand(d)
+                    t0 = time.perf_counter()
+                    g.addData(xa, 0.0)
+                    fits["N%d_D%d" % (n, d)]["addData_1_point_ms"] = (time.perf_counter() - t0) * 1e3
+                    del g
+                cfgs["gp_fit"] = fits
+            # C3: this rank's 2^19-candidate shard (at 8 GPUs this IS BASELINE configs[2])
+            GP3, cand3, host3, start3 = c3_setup(C3_SHARD * world)
+            el3, o3 = timed(lambda: c3_step(GP3, cand3, host3, start3), 5, 1)
+            barrier()
+            t0 = time.perf_counter()
+            if comm is None:
+                gal = fastUCBGallery(GP3, [[0., 1.]] * C3_D, 8, candidates=cand3)
+            else:
+                gal = sharded_gallery(GP3, [[0., 1.]] * C3_D, 8, cand3, start3, comm)
+            gms = max_over_ranks((time.perf_counter() - t0) * 1e3)
+            if rank == 0:
+                k3 = float(np.mean([o[2] for o in o3])) * 1e-3
+                gal = np.array(gal)
+                cfgs["c3_shard_sweep"] = {
+                    "workload": "N=2048, D=8, Matern-5/2, EI over 2^19 candidates per GPU (x%d), 5 steps" % world,
+                    "value": float(C3_SHARD * world) * 5 / el3, "unit": "EI evals/s", "ms_per_step": el3 / 5 * 1e3,
+                    "gp_fit_device_ms": GP3.last_fit_ms(),
+                    "roofline": roofline_mfma(f_eval(C3_N, C3_D) * float(C3_SHARD), k3, kernel="sweep_mfma_kernel",
+                                              kernel_ms=k3 * 1e3, flops_per_eval=f_eval(C3_N, C3_D),
+                                              evals_per_launch=C3_SHARD)}
+                cfgs["c3_gallery8"] = {"workload": "fastUCBGallery(N=8) on the same GP and shard(s): 7 rounds of DIRECT + "
+                                                   "sharded sweep + exchange + hallucinated addData",
+                                       "ms": gms, "min_pairwise_distance": float(min(
+                                           np.linalg.norm(gal[i] - gal[j]) for i in range(8) for j in range(i)))}
+            del GP3, cand3
+            # C5: 64 theta-points per GPU
+            X5, Y5, th5 = c5_setup()
+            c5_step(X5, Y5, th5[:world])                         # workspace + first-call costs
+            el5, o5 = timed(lambda: c5_step(X5, Y5, th5), 2, 0)
+            if rank == 0:
+                per = el5 / 2 / C5_T
+                cfgs["c5_nlml_grid"] = {
+                    "workload": "N=4096, D=16, SE-ARD, 64 theta-points per GPU (x%d), host X,Y in, values + argmin out" % world,
+                    "ms_total": el5 / 2 * 1e3, "ms_per_theta": per * 1e3, "argmin": int(o5[-1][1]),
+                    "n_not_pd": int(np.sum(~np.isfinite(o5[-1][0]))),
+                    "roofline": roofline_mfma(f_nlml(C5_N, C5_D), per, flops_per_theta=f_nlml(C5_N, C5_D),
+                                              kernels="cov_matrix + batched chol_diag/trsm/update + reduce")}
+            _lib.trim(local_rank)
+            # C4: preference GP, one GPU only (the MAP is a sequential Newton iteration)
+            if world == 1:
+                rs = np.random.RandomState(4)
+                pts = rs.rand(1024, 6)
+                prefs = []
+                for i in range(512):
+                    a_, b_ = pts[2 * i], pts[2 * i + 1]
+                    prefs.append((a_, b_, 0) if hartman6(a_) > hartman6(b_) else (b_, a_, 0))
+                t0 = time.perf_counter()
+                PG = PrefGaussianProcess(GaussianKernel_ard([0.53, 0.57, 2.5, 0.34, 0.27, 0.35]), prefs, device=local_rank)
+                pms = (time.perf_counter() - t0) * 1e3
+                cand4 = DeviceArray.from_host(np.random.RandomState(104).rand(1 << 20, 6), local_rank)
+                t0 = time.perf_counter()
+                fastUCBGallery(PG, [[0., 1.]] * 6, 8, candidates=cand4)
+                cfgs["c4_prefgp"] = {"workload": "PrefGaussianProcess, 512 pairs -> 1024 points, D=6; gallery of 8 over 2^20 candidates",
+                                     "addPreferences_ms": pms, "gallery8_ms": (time.perf_counter() - t0) * 1e3}
+                del PG, cand4
+            if rank == 0:
+                out["configs"] = cfgs
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X, Y, cand_host)
 
     if rank == 0:
-        total = float(M_PER_GPU) * world * args.steps
-        f_eval = N_OBS ** 2 + 3 * N_OBS * DIM + 4 * N_OBS
-        kmean = float(np.mean(kms)) * 1e-3
-        achieved = f_eval * M_PER_GPU / kmean / 1e12
-        out = {
-            "metric": "EI evals/sec (N=1024 obs, D=4, SE-ARD, 2^20 candidates/GPU sweep)",
-            "value": total / elapsed, "unit": "EI evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: N=1024 obs, D=4, GaussianKernel_ard(0.3), noise 0.1, EI xi=0.01 (libm erf), "
-                                   "2^20 candidates per GPU resident in HBM, arg-max to host each step",
-                       "n_obs": N_OBS, "dim": DIM, "candidates_per_gpu": M_PER_GPU,
-                       "parallelism": "candidate-sharded x%d, replicated GP, 1 RCCL arg-max exchange/step" % world},
-            "gp_fit_ms": {"host_to_ready_median": float(np.median(fit_ms)), "device_events": fit_dev_ms,
-                          "N": N_OBS, "D": DIM},
-            "best": {"value": best[0], "index": int(best[1])},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "sweep_mfma_kernel", "kernel_ms": kmean * 1e3,
-                         "flops_per_eval": f_eval, "evals_per_launch": M_PER_GPU},
-        }
-        pmc = os.path.join(ROOT, "profiles", "r01_sweep_pmc.json")
-        if os.path.exists(pmc):
-            # HBM bytes per launch cannot be read live; they come from the committed rocprofv3 --pmc
-            # passes over this same command (tools/profile_bench.sh), FETCH_SIZE x2 (gfx950) + WRITE_SIZE
-            j = json.load(open(pmc))
-            out["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
-            out["roofline"]["traffic_source"] = "profiles/r01_sweep_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
-            out["roofline"]["algorithmic_bytes_per_launch"] = (8 * DIM + 16) * M_PER_GPU
-            out["roofline"]["mfma_util_pct_pmc"] = j.get("mfma_util_pct")
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, Y, cand_host)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         comm.close()
-        if rank == 0 and id_path:
+        if rank == 0 and id_path and not os.environ.get("IBO_BENCH_CHILD"):
             try:
                 os.unlink(id_path)
             except OSError:
                 pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `configs` object (fit / C3 / C4 / C5 numbers)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if not launched and (args.gpus > 1 or os.environ.get("IBO_BENCH_FORCE_SPAWN")):
+        # no GPU call has been made in this process (ibo_amd is imported by the workers only)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    worker(args)
 
 
 if __name__ == "__main__":

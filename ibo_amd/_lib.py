@@ -93,6 +93,7 @@ _sig("ibo_nlml_grad", c_int, c_int, c_int, c_int, c_int, _DP, _DP, _DP, c_int, c
 _sig("ibo_comm_get_unique_id", c_int, c_char_p)
 _sig("ibo_comm_init", c_int, c_int, c_int, c_int, c_char_p, POINTER(c_void_p))
 _sig("ibo_comm_destroy", c_int, c_void_p)
+_sig("ibo_comm_count", c_int, c_void_p, POINTER(c_int))
 _sig("ibo_comm_argmax", c_int, c_void_p, c_double, c_int64, _DP, c_int, _DP, POINTER(c_int64), _DP, POINTER(c_int))
 _sig("ibo_comm_allreduce_sum", c_int, c_void_p, _DP, c_int64)
 _sig("ibo_comm_barrier", c_int, c_void_p)
@@ -108,7 +109,7 @@ EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device
             "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
             "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_spd_solve", "ibo_spd_inverse", "ibo_posterior_batch",
             "ibo_acq_sweep", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_host", "ibo_nlml_grid", "ibo_nlml_grad",
-            "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_argmax", "ibo_comm_allreduce_sum", "ibo_comm_barrier",
+            "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_count", "ibo_comm_argmax", "ibo_comm_allreduce_sum", "ibo_comm_barrier",
             "acqmaxGP", "direct", "logCDFs"]
 
 

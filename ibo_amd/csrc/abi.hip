@@ -27,6 +27,13 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// the other translation units (comm.hip) report through the same buffer, so ibo_last_error() always
+// describes the call that failed
+void ibo_internal_set_error(const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+}
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -48,6 +55,8 @@ static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices p
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
 
+static size_t g_pool_limit = (size_t)2 << 30;    // ibo_set_option("pool_limit_mb", n) / env IBO_POOL_LIMIT_MB
+
 static int use_device(int device)
 {
     int n = 0;
@@ -62,6 +71,8 @@ static int use_device(int device)
         const char *s = getenv("IBO_SWEEP_IMPL");
         if (s && !strcmp(s, "gemv")) g_force_path = 1;
         if (s && !strcmp(s, "mfma")) g_force_path = 2;
+        const char *pl = getenv("IBO_POOL_LIMIT_MB");
+        if (pl && atoll(pl) >= 0) g_pool_limit = (size_t)atoll(pl) << 20;
         env_read = true;
     }
     return IBO_OK;
@@ -69,9 +80,8 @@ static int use_device(int device)
 
 // Device allocations are recycled: a Bayesian-optimisation loop builds a new model (a new handle, five N x N
 // buffers) every round, and hipMalloc/hipFree of tens of megabytes cost more than the fit itself.  Freed
-// blocks go to a per-device free list (up to IBO_POOL_LIMIT bytes; ibo_trim() empties it) and are handed out
+// blocks go to a per-device free list (up to g_pool_limit bytes, 2 GiB unless configured; ibo_trim() empties it) and are handed out
 // again to requests of up to half their size less.
-#define IBO_POOL_LIMIT ((size_t)16 << 30)
 struct PoolBlock { void *p; size_t bytes; };
 static std::vector<PoolBlock> g_pool[16];
 static size_t g_pool_bytes[16];
@@ -100,7 +110,7 @@ static void pool_put(void *p, size_t bytes)
     (void)hipGetDevice(&dev);
     (void)hipDeviceSynchronize();                    // what hipFree would have waited for: nothing in flight uses p
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool_bytes[dev & 15] + bytes > IBO_POOL_LIMIT) { (void)hipFree(p); return; }
+    if (g_pool_bytes[dev & 15] + bytes > g_pool_limit) { (void)hipFree(p); return; }
     g_pool[dev & 15].push_back({p, bytes});
     g_pool_bytes[dev & 15] += bytes;
 }
@@ -139,6 +149,12 @@ struct DevBuf {
         return IBO_OK;
     }
     void release() { if (p) pool_put(p, cap * sizeof(T)); p = nullptr; cap = 0; }
+};
+// function-local buffers: handed back on every exit path (the members of handles and of the static
+// workspaces are released explicitly -- a static object must not call into HIP at process exit)
+template <typename T>
+struct ScopedBuf : DevBuf<T> {
+    ~ScopedBuf() { this->release(); }
 };
 
 struct ibo_gp {
@@ -200,6 +216,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
+    if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
 
@@ -257,10 +274,21 @@ extern "C" int ibo_gp_create(int device, ibo_gp_t **out)
     IBO_TRY(use_device(device));
     ibo_gp *g = new ibo_gp();
     g->device = device;
-    HIP_TRY(hipStreamCreate(&g->stream));
-    HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1));
-    HIP_TRY(hipEventCreate(&g->fit0)); HIP_TRY(hipEventCreate(&g->fit1));
     memset(&g->kp, 0, sizeof(g->kp));
+    hipError_t e = hipStreamCreate(&g->stream);
+    if (e == hipSuccess) e = hipEventCreate(&g->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&g->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&g->fit0);
+    if (e == hipSuccess) e = hipEventCreate(&g->fit1);
+    if (e != hipSuccess) {                            // hand back whatever was created
+        if (g->ev0) (void)hipEventDestroy(g->ev0);
+        if (g->ev1) (void)hipEventDestroy(g->ev1);
+        if (g->fit0) (void)hipEventDestroy(g->fit0);
+        if (g->fit1) (void)hipEventDestroy(g->fit1);
+        if (g->stream) (void)hipStreamDestroy(g->stream);
+        delete g;
+        return fail(IBO_ERR_HIP, "creating the handle's stream/events failed: %s", hipGetErrorString(e));
+    }
     *out = g;
     return IBO_OK;
 }
@@ -562,7 +590,7 @@ extern "C" int ibo_cov_matrix(int device, int ktype, int D, const double *hyper,
     KParams kp;
     IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
     int m2 = A2 ? n2 : n1;
-    DevBuf<double> a1, a2, k;
+    ScopedBuf<double> a1, a2, k;
     IBO_TRY(a1.ensure((size_t)n1 * D)); IBO_TRY(k.ensure((size_t)n1 * m2));
     HIP_TRY(hipMemcpy(a1.p, A1, sizeof(double) * n1 * D, hipMemcpyHostToDevice));
     if (A2) {
@@ -571,7 +599,6 @@ extern "C" int ibo_cov_matrix(int device, int ktype, int D, const double *hyper,
     }
     KERNEL_TRY(launch_cov_matrix(kp, n1, a1.p, n2, A2 ? a2.p : nullptr, D, diag_rule, noise, k.p, m2, nullptr));
     HIP_TRY(hipMemcpy(K_host, k.p, sizeof(double) * (size_t)n1 * m2, hipMemcpyDeviceToHost));
-    a1.release(); a2.release(); k.release();
     return IBO_OK;
 }
 
@@ -585,8 +612,8 @@ extern "C" int ibo_spd_solve(int device, int N, const double *A_host, int nrhs, 
     IBO_TRY(use_device(device));
     const int Np = round_up(N, 64);
     const size_t nn = (size_t)Np * Np;
-    DevBuf<double> dA, dL, dW, dT, d64, db, dx, d1, tmp;
-    DevBuf<int> dinfo;
+    ScopedBuf<double> dA, dL, dW, dT, d64, db, dx, d1, tmp;
+    ScopedBuf<int> dinfo;
     IBO_TRY(dA.ensure((size_t)N * N)); IBO_TRY(dL.ensure(nn)); IBO_TRY(dW.ensure(nn)); IBO_TRY(dT.ensure(nn));
     IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096)); IBO_TRY(db.ensure(Np)); IBO_TRY(dx.ensure(Np)); IBO_TRY(d1.ensure(Np));
     IBO_TRY(tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64)); IBO_TRY(dinfo.ensure(1));
@@ -611,8 +638,6 @@ extern "C" int ibo_spd_solve(int device, int N, const double *A_host, int nrhs, 
             HIP_TRY(hipMemcpy(X_host + (size_t)r * N, dx.p, sizeof(double) * N, hipMemcpyDeviceToHost));
         }
     }
-    dA.release(); dL.release(); dW.release(); dT.release(); d64.release(); db.release(); dx.release(); d1.release();
-    tmp.release(); dinfo.release();
     return rc;
 }
 
@@ -624,8 +649,8 @@ extern "C" int ibo_spd_inverse(int device, int N, const double *A_host, double *
     IBO_TRY(use_device(device));
     const int Np = round_up(N, 64);
     const size_t nn = (size_t)Np * Np;
-    DevBuf<double> dA, dL, dW, dT, d64;
-    DevBuf<int> dinfo;
+    ScopedBuf<double> dA, dL, dW, dT, d64;
+    ScopedBuf<int> dinfo;
     IBO_TRY(dA.ensure(nn)); IBO_TRY(dL.ensure(nn)); IBO_TRY(dW.ensure(nn)); IBO_TRY(dT.ensure(nn));
     IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096)); IBO_TRY(dinfo.ensure(1));
     hipStream_t s = nullptr;
@@ -645,7 +670,6 @@ extern "C" int ibo_spd_inverse(int device, int N, const double *A_host, double *
         HIP_TRY(hipMemcpy2D(Ainv_host, sizeof(double) * N, dA.p, sizeof(double) * Np, sizeof(double) * N, N,
                             hipMemcpyDeviceToHost));
     }
-    dA.release(); dL.release(); dW.release(); dT.release(); d64.release(); dinfo.release();
     return rc;
 }
 

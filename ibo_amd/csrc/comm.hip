@@ -22,6 +22,7 @@ typedef int (*fn_comm_init_rank)(rccl_comm_t *, int, rccl_unique_id_t, int);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int /*dtype*/, int /*op*/, rccl_comm_t, hipStream_t);
 typedef int (*fn_comm_destroy)(rccl_comm_t);
 typedef const char *(*fn_get_error_string)(int);
+typedef int (*fn_comm_count)(rccl_comm_t, int *);
 enum { RCCL_FLOAT64 = 8, RCCL_SUM = 0 };
 
 static struct {
@@ -31,14 +32,16 @@ static struct {
     fn_all_reduce all_reduce = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
     fn_get_error_string err = nullptr;
+    fn_comm_count comm_count = nullptr;
 } R;
 
-static thread_local char c_err[256];
-extern "C" const char *ibo_last_error(void);
+void ibo_internal_set_error(const char *msg);     // abi.hip: the one buffer behind ibo_last_error()
 static int cfail(int code, const char *msg, int rc = 0)
 {
-    snprintf(c_err, sizeof(c_err), "%s (%s)", msg, (R.err && rc) ? R.err(rc) : "-");
-    fprintf(stderr, "[libibo_hip] comm: %s\n", c_err);
+    char c_err[256];
+    snprintf(c_err, sizeof(c_err), "comm: %s (%s)", msg, (R.err && rc) ? R.err(rc) : "-");
+    ibo_internal_set_error(c_err);
+    fprintf(stderr, "[libibo_hip] %s\n", c_err);
     return code;
 }
 
@@ -53,6 +56,7 @@ static int load_rccl()
     R.all_reduce = (fn_all_reduce)dlsym(R.h, "ncclAllReduce");
     R.comm_destroy = (fn_comm_destroy)dlsym(R.h, "ncclCommDestroy");
     R.err = (fn_get_error_string)dlsym(R.h, "ncclGetErrorString");
+    R.comm_count = (fn_comm_count)dlsym(R.h, "ncclCommCount");
     if (!R.get_unique_id || !R.comm_init_rank || !R.all_reduce || !R.comm_destroy)
         return cfail(IBO_ERR_COMM, "librccl.so lacks an expected symbol");
     return IBO_OK;
@@ -114,6 +118,17 @@ extern "C" int ibo_comm_destroy(ibo_comm_t *c)
     R.comm_destroy(c->comm);
     (void)hipStreamDestroy(c->stream);
     delete c;
+    return IBO_OK;
+}
+
+// number of ranks RCCL itself reports for the communicator (ncclCommCount): bench.py prints it so a reader
+// can see the collective really spanned N processes
+extern "C" int ibo_comm_count(ibo_comm_t *c, int *nranks)
+{
+    if (!c || !nranks) return IBO_ERR_ARG;
+    if (!R.comm_count) return cfail(IBO_ERR_COMM, "librccl.so lacks ncclCommCount");
+    int e = R.comm_count(c->comm, nranks);
+    if (e) return cfail(IBO_ERR_COMM, "ncclCommCount failed", e);
     return IBO_OK;
 }
 

@@ -8,10 +8,10 @@ into its own slot of a zero buffer, a single all-reduce(sum) gathers the slots
 (RCCL has no MAXLOC), and every rank applies the same deterministic reduction:
 largest value, ties to the lowest global index (numpy.argmax order).
 
-The transport is pluggable: `RcclArgmax` is libibo_hip's RCCL path over xGMI
-(csrc/comm.hip); `TorchArgmax` runs the identical slot protocol over any
-torch.distributed backend -- it exists so the protocol is testable on CPU with
-gloo (tests/test_multigpu_gloo.py) and is not used on the GPU path.
+The transport is any object with .world_size, .rank, .argmax(val, idx, payload) and
+.allreduce_sum(buf): `RcclArgmax` is libibo_hip's RCCL path over xGMI (csrc/comm.hip);
+the CPU tests drive the identical slot protocol (fill_slot / reduce_slots) over gloo
+with a transport of their own (tests/gloo_transport.py).
 """
 import ctypes
 
@@ -56,30 +56,6 @@ def fill_slot(world_size, rank, val, idx, payload):
     return buf
 
 
-class TorchArgmax(object):
-    """slot protocol over torch.distributed (CPU/gloo tests)"""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.group = group
-        self.world_size = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-
-    def argmax(self, val, idx, payload=()):
-        import torch
-        payload = np.asarray(payload, dtype=float).reshape(-1)
-        t = torch.from_numpy(fill_slot(self.world_size, self.rank, val, idx, payload))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return reduce_slots(t.numpy(), self.world_size, len(payload))
-
-    def allreduce_sum(self, buf):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64).copy())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t.numpy()
-
-
 class RcclArgmax(object):
     """slot protocol over RCCL/xGMI through libibo_hip (one communicator per process)"""
 
@@ -113,31 +89,65 @@ class RcclArgmax(object):
     def barrier(self):
         _lib.check(_lib.lib.ibo_comm_barrier(self.h))
 
+    def nranks(self):
+        """ranks in the communicator as RCCL itself counts them (ncclCommCount)"""
+        n = ctypes.c_int(0)
+        _lib.check(_lib.lib.ibo_comm_count(self.h, ctypes.byref(n)))
+        return n.value
+
     def close(self):
         if getattr(self, "h", None):
             _lib.lib.ibo_comm_destroy(self.h)
             self.h = None
 
 
+def _rendezvous_path():
+    """where rank 0 leaves the RCCL unique id for the other ranks of a one-node job.
+    IBO_COMM_ID_FILE names the file outright (bench.py's self-launcher creates a fresh private
+    directory per run and passes it down).  Otherwise the file lives in a per-user 0700 directory
+    and its name carries the launcher's pid, MASTER_PORT and torch-elastic's run id + restart
+    count, so a restarted attempt never reads the id of the attempt before it."""
+    import os
+    explicit = os.environ.get("IBO_COMM_ID_FILE")
+    if explicit:
+        return explicit
+    base = os.environ.get("IBO_COMM_DIR") or os.path.join("/tmp", "ibo_rccl_%d" % os.getuid())
+    try:
+        os.mkdir(base, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(base)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("rendezvous directory %s is not a private directory of this user" % base)
+    nonce = "%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    nonce = "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in nonce)
+    return os.path.join(base, "id_%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), nonce))
+
+
 def exchange_unique_id(world_size, rank, timeout_s=600.0):
     """Hand rank 0's RCCL unique id to every rank of a ONE-NODE job without pulling a second
     GPU runtime into the process (torch bundles its own HIP/HSA; two runtimes in one process
-    fail with "no ROCm-capable device" or corrupt the heap at exit).  All ranks of a
-    torch.distributed.run job are children of the same agent, so the agent's pid + MASTER_PORT
-    name a rendezvous file in /tmp; rank 0 writes it atomically, the others poll for it.
-    Multi-node launches must pass the id by their own means (IBO_COMM_ID_FILE overrides the path)."""
+    fail with "no ROCm-capable device" or corrupt the heap at exit).  Rank 0 creates the file
+    exclusively (O_EXCL | O_NOFOLLOW, mode 0600) under a temporary name and renames it into
+    place; the others poll, and accept only a regular file of the right size owned by this user
+    and not older than the launcher.  Multi-node launches pass the id by their own means."""
     import os
     import time
-    path = os.environ.get("IBO_COMM_ID_FILE") or "/tmp/ibo_rccl_id_%d_%s" % (
-        os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    path = _rendezvous_path()
     if rank == 0:
         uid = RcclArgmax.unique_id()
         try:
             os.unlink(path)
         except OSError:
             pass
-        tmp = "%s.%d" % (path, os.getpid())
-        with open(tmp, "wb") as f:
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
         os.rename(tmp, path)
         return uid, path
@@ -145,13 +155,18 @@ def exchange_unique_id(world_size, rank, timeout_s=600.0):
         born = os.stat("/proc/%d" % os.getppid()).st_ctime - 5.0     # ignore files older than the launcher
     except OSError:
         born = 0.0
+    import stat
     t0 = time.time()
     while True:
         try:
-            st = os.stat(path)
-            if st.st_size == _lib.COMM_ID_BYTES and st.st_mtime >= born:
-                with open(path, "rb") as f:
-                    return f.read(), path
+            fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+            try:
+                st = os.fstat(fd)
+                if (stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and st.st_size == _lib.COMM_ID_BYTES
+                        and st.st_mtime >= born):
+                    return os.read(fd, _lib.COMM_ID_BYTES), path
+            finally:
+                os.close(fd)
         except OSError:
             pass
         if time.time() - t0 > timeout_s:

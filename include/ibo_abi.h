@@ -247,7 +247,7 @@ int ibo_nlml_grid(int device, int ktype, int N, int D,
                   double *nlml_host);
 /* Device memory is recycled: ibo_nlml_grid and ibo_nlml_grad keep their workspaces (the batch of factor
  * matrices; the N x N buffers of the gradient) between calls, and the buffers of destroyed handles go to a
- * per-device free list (at most 16 GiB) for the next handle.  This releases all of it. */
+ * per-device free list (at most 2 GiB; ibo_set_option("pool_limit_mb", n) or env IBO_POOL_LIMIT_MB) for the next handle.  This releases all of it. */
 int ibo_trim(int device);
 
 /*
@@ -267,6 +267,8 @@ int ibo_comm_get_unique_id(unsigned char id[IBO_COMM_ID_BYTES]);
 int ibo_comm_init(int device, int world_size, int rank,
                   const unsigned char id[IBO_COMM_ID_BYTES], ibo_comm_t **out);
 int ibo_comm_destroy(ibo_comm_t *comm);
+/* ranks in the communicator as RCCL reports them (ncclCommCount) */
+int ibo_comm_count(ibo_comm_t *comm, int *nranks);
 /*
  * One all-reduce(sum) over a world_size x (3+npayload) slot buffer (value,
  * index, valid flag, payload) in which each rank fills only its own slot (RCCL has no MAXLOC), followed by the same

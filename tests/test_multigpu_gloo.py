@@ -6,10 +6,13 @@ import os
 import socket
 import sys
 
+import multiprocessing as mp          # torch is imported only inside the spawned workers (tests/gloo_transport.py)
+
 import numpy as np
-import torch.multiprocessing as mp
 
 from conftest import ROOT
+
+TESTS = os.path.join(ROOT, "tests")
 
 
 def _free_port():
@@ -18,12 +21,11 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ibo_amd.multigpu import TorchArgmax, shard_bounds
-    comm = TorchArgmax()
+    sys.path[:0] = [ROOT, TESTS]
+    from gloo_transport import GlooArgmax, init_gloo
+    dist = init_gloo(rank, world, port)
+    from ibo_amd.multigpu import shard_bounds
+    comm = GlooArgmax()
     # a synthetic "acquisition" over a sharded candidate array: each rank scans its block
     M, D = 1001, 3
     cand = np.random.RandomState(5).rand(M, D)
@@ -61,6 +63,48 @@ def test_sharded_argmax_two_ranks_gloo():
     assert res[0][2][1] == -1 and res[0][2][3] == -1
 
 
+def _tie_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, TESTS]
+    from gloo_transport import GlooArgmax, init_gloo
+    dist = init_gloo(rank, world, port)
+    from ibo_amd.multigpu import shard_bounds
+    comm = GlooArgmax()
+    M = 30
+    vals = np.zeros(M)
+    vals[[4, 14, 24]] = 1.5                            # one maximiser in EACH of the three shards
+    a, b = shard_bounds(M, world, rank)
+    li = int(np.argmax(vals[a:b]))
+    out = [comm.argmax(vals[a + li], a + li, [float(a + li)])]
+    # global indices beyond 2^31 (and beyond 2^32) travel exactly in the fp64 slot
+    base = (1 << 33) + 12345
+    out.append(comm.argmax(1.0, base + (world - 1 - rank), [float(rank)]))
+    out.append(comm.argmax(float(rank == 1), (1 << 52) + rank, []))
+    q.put((rank, [(v, int(i), list(p), r) for v, i, p, r in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_shard_tie_and_large_indices_gloo():
+    """the same value in all three shards: the lowest GLOBAL index wins on every rank (numpy.argmax
+    order); indices above 2^31 survive the all-reduce(sum) exactly"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tie_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == res[2]
+    assert res[0][0] == (1.5, 4, [4.0], 0)
+    base = (1 << 33) + 12345
+    assert res[0][1] == (1.0, base, [2.0], 2)          # rank 2 holds the lowest index of the tie
+    assert res[0][2] == (1.0, (1 << 52) + 1, [], 1)
+
+
 def _id_worker(rank, world, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_PORT"] = "45678"
@@ -74,7 +118,8 @@ def _id_worker(rank, world, q):
 
 
 def test_unique_id_file_rendezvous():
-    """bench.py's torch-free rendezvous: rank 0 publishes the RCCL id in /tmp, keyed by the launcher pid"""
+    """bench.py's torch-free rendezvous: rank 0 publishes the RCCL id in a private per-user directory,
+    keyed by the launcher pid, the port and torch-elastic's attempt nonce"""
     world = 3
     ctx = mp.get_context("fork")
     q = ctx.Queue()
@@ -87,16 +132,37 @@ def test_unique_id_file_rendezvous():
         assert p.exitcode == 0
     assert all(uid == bytes(range(128)) for _, uid, _ in res)
     assert len(set(path for _, _, path in res)) == 1
+    st = os.stat(res[0][2])
+    assert st.st_mode & 0o077 == 0 and os.stat(os.path.dirname(res[0][2])).st_mode & 0o077 == 0
     os.unlink(res[0][2])
 
 
+def test_rendezvous_name_carries_the_attempt_nonce(monkeypatch, tmp_path):
+    """a restarted torch-elastic attempt must not read the id file of the attempt before it"""
+    from ibo_amd import multigpu
+    monkeypatch.setenv("IBO_COMM_DIR", str(tmp_path / "rdv"))
+    monkeypatch.delenv("IBO_COMM_ID_FILE", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/7")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    a = multigpu._rendezvous_path()
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    b = multigpu._rendezvous_path()
+    assert a != b and os.path.dirname(a) == str(tmp_path / "rdv") and "/" not in os.path.basename(a)
+    os.chmod(str(tmp_path / "rdv"), 0o755)             # somebody else could write here: refuse
+    import pytest
+    with pytest.raises(RuntimeError):
+        multigpu._rendezvous_path()
+    monkeypatch.setenv("IBO_COMM_ID_FILE", "/somewhere/explicit")
+    assert multigpu._rendezvous_path() == "/somewhere/explicit"
+
+
 def _nlml_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ibo_amd.multigpu import TorchArgmax, sharded_nlml_grid
-    comm = TorchArgmax()
+    sys.path[:0] = [ROOT, TESTS]
+    from gloo_transport import GlooArgmax, init_gloo
+    dist = init_gloo(rank, world, port)
+    from ibo_amd.multigpu import sharded_nlml_grid
+    comm = GlooArgmax()
     thetas = np.random.RandomState(9).rand(11, 3) + .1
     f = lambda th: np.where(th[:, 0] > .95, np.nan, np.sum((th - .5) ** 2, axis=1))     # NaN = "not PD" slots
     vals, am = sharded_nlml_grid(None, thetas, None, None, comm, local_eval=f)
