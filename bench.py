@@ -449,7 +449,7 @@ def worker(args):
                         dev.append(g.last_fit_ms())
                     ms = float(np.median(dev))
                     fits["N%d_D%d" % (n, d)] = {"device_ms": ms, "host_to_ready_ms": float(np.median(host_ms)),
-                                                "roofline": roofline_mfma(f_fit(n, d), ms * 1e-3, flops=f_fit(n, d),
+                                                "roofline": roofline_mfma(f_fit(n, d), ms * 1e-3, flops_per_fit=f_fit(n, d),
                                                                           kernels="cov_matrix + chol_step/chol_* + trinv_* + pack_w + gemv")}
                     # one more observation through addData (block extension of L and W, not a refit)
                     xa = np.random.RandomState(8).rand(d)

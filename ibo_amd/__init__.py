@@ -8,6 +8,8 @@ misterwindupbird/IBO, behind the reference's own Python API.
     from ibo_amd.acquisition.gallery import fastUCBGallery
     from ibo_amd.utils.optimize import direct, cdirect
     from ibo_amd.utils.latinhypercube import lhcSample
+    from ibo_amd.utils.testfunctions import Hartman6, Shekel5, Synthetic, learnHyper
+    from ibo_amd.gaussianprocess.prior import RBFNMeanPrior        # .train(X, Y, bounds, k, seed)
 
 `install_as_ego()` registers the same modules under the reference's package
 name so existing `from ego.acquisition import maximizeEI` code runs unchanged.
@@ -27,6 +29,6 @@ def install_as_ego():
     import importlib
     names = ["", ".gaussianprocess", ".gaussianprocess.kernel", ".gaussianprocess.prior",
              ".gaussianprocess.trainhyper", ".acquisition", ".acquisition.gallery", ".utils",
-             ".utils.optimize", ".utils.latinhypercube"]
+             ".utils.optimize", ".utils.latinhypercube", ".utils.testfunctions"]
     for n in names:
         sys.modules["ego" + n] = importlib.import_module("ibo_amd" + n)

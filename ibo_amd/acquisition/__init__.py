@@ -114,6 +114,7 @@ def gpuDirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc=None, xi=-1,
     D = len(lb)
     opt = ctypes.c_double(); optx = np.empty(D); ns = ctypes.c_int64()
     h = model._handle()
+    model._push_prior()
     _lib.check(_lib.lib.ibo_gp_set_kstar_sf2(h, sf2_native))
     try:
         _lib.check(_lib.lib.ibo_direct_max(h, D, _lib.dp(lb), _lib.dp(ub), _ACQ[acqfunc], float(parm),
@@ -192,6 +193,7 @@ def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None,
             parm = xi
     _, _, sf2_py, sf2_native = model.kernel._ibo_spec()
     h = model._handle()
+    model._push_prior()
     outs = {k: _lib.DeviceArray((M,), model._dev.device) for k in outputs}
     ex = None if exclude is None or len(exclude) == 0 else _lib.f64(np.atleast_2d(exclude))
     bv = ctypes.c_double(); bi = ctypes.c_int64()

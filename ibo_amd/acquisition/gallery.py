@@ -14,7 +14,6 @@ and `seed=` makes the default sampling reproducible (the reference is unseeded).
 from copy import deepcopy
 
 import numpy as np
-from numpy.linalg import norm
 
 from ..gaussianprocess import GaussianProcess
 from ..utils.latinhypercube import lhcSample
@@ -22,90 +21,102 @@ from . import EI, maximizeEI, sweep
 from .. import _lib
 
 
+MIN_SEPARATION = .5          # gallery members must be farther apart than this (gallery.py:102,113,125)
+
+
+def _separated(x, members):
+    """True when x is farther than MIN_SEPARATION from every member (vacuously for an empty gallery)"""
+    if len(members) == 0:
+        return True
+    return float(np.min(np.linalg.norm(np.asarray(members, dtype=float) - np.asarray(x, dtype=float), axis=1))) > MIN_SEPARATION
+
+
+def _best_observation_inside(X, Y, bounds):
+    """the best observation seen so far that lies inside the box (first one on ties), or None"""
+    box = np.asarray(bounds, dtype=float)
+    X = np.asarray(X, dtype=float)
+    inside = np.all((X >= box[:, 0]) & (X <= box[:, 1]), axis=1)
+    score = np.where(inside & ~np.isnan(Y), Y, -np.inf)
+    k = int(np.argmax(score))
+    return X[k] if score[k] > -np.inf else None
+
+
+def _start(GP, bounds, useBest):
+    """first gallery member(s) and the plain GP the rounds hallucinate on (gallery.py:49-90): the best
+    in-box observation when there are data; the box centre for an empty model without a prior; otherwise
+    the highest posterior-mean point reached by a local search from each RBF centre of the prior"""
+    plain = dict(prior=GP.prior, device=GP._device)       # default noise: the source model may be a preference GP
+    if len(GP.X) > 0:
+        first = _best_observation_inside(GP.X, GP.Y, bounds) if useBest else None
+        model = GaussianProcess(deepcopy(GP.kernel), np.array(GP.X, dtype=float), np.array(GP.Y, dtype=float), **plain)
+        return ([] if first is None else [first]), model
+    if GP.prior is None:
+        centre = np.array([(lo + hi) / 2. for lo, hi in bounds])
+        return [centre], GaussianProcess(deepcopy(GP.kernel), [centre], [0.0], **plain)
+    from scipy.optimize import fmin_bfgs
+    box = np.asarray(bounds, dtype=float)
+    ends = [np.clip(fmin_bfgs(GP.negmu, m, disp=False), box[:, 0], box[:, 1]) for m in GP.prior.means]
+    heights = [GP.mu(e) for e in ends]
+    k = int(np.argmax(heights))                           # first of equals, as a strict > scan would pick
+    return [ends[k]], GaussianProcess(deepcopy(GP.kernel), ends[k], heights[k], **plain)
+
+
+def _prior_centres(model, bounds, members, floor):
+    """the prior's RBF centres as extra candidates (gallery.py:118-130): clipped to the box, mapped through
+    the prior's affine normalisation, scored with EI(xi=.4) in ONE batched device call; returns
+    (value, point) of the best admissible one that beats `floor`, else None"""
+    pr = model.prior
+    box = np.asarray(bounds, dtype=float)
+    pts = np.clip(np.asarray(pr.means, dtype=float).reshape(len(pr.means), -1), box[:, 0], box[:, 1])
+    pts = pts * np.asarray(pr.width, dtype=float) + np.asarray(pr.lowerb, dtype=float)
+    score = EI(model, xi=.4).values(pts)
+    ok = np.array([_separated(x, members) for x in pts])
+    score = np.where(ok, score, -np.inf)
+    k = int(np.argmax(score))
+    return (float(score[k]), pts[k]) if score[k] > floor else None
+
+
 def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, candidates=None, seed=None,
                    lhc_per_round=None, comm=None, index_base=0):
-    gallery = []
-    if len(GP.X) > 0:
-        if useBest:
-            bestY = -np.inf
-            bestX = None
-            for x, y in zip(GP.X, GP.Y):
-                if y > bestY:
-                    for v, b in zip(x, bounds):
-                        if v < b[0] or v > b[1]:
-                            break
-                    else:
-                        bestY = y
-                        bestX = x
-            if bestX is not None:
-                gallery.append(bestX)
-        # a plain GP on the same data (the original may be a preference GP), default noise
-        hallucGP = GaussianProcess(deepcopy(GP.kernel), deepcopy(GP.X), deepcopy(GP.Y), prior=GP.prior,
-                                   device=GP._device)
-    elif GP.prior is None:
-        x = np.array([(b[0] + b[1]) / 2. for b in bounds])
-        gallery.append(x)
-        hallucGP = GaussianProcess(deepcopy(GP.kernel), [x], [0.0], prior=GP.prior, device=GP._device)
-    else:
-        from scipy.optimize import fmin_bfgs
-        bestmu = -np.inf
-        bestX = None
-        for m in GP.prior.means:
-            argmin = fmin_bfgs(GP.negmu, m, disp=False)
-            for i in range(len(argmin)):
-                argmin[i] = np.clip(argmin[i], bounds[i][0], bounds[i][1])
-            if GP.mu(argmin) > bestmu:
-                bestX = argmin
-                bestmu = GP.mu(argmin)
-        gallery.append(bestX)
-        hallucGP = GaussianProcess(deepcopy(GP.kernel), bestX, bestmu, prior=GP.prior, device=GP._device)
-
+    """N points to show a user (gallery.py:42-136).  Each round proposes (1) the DIRECT maximiser of
+    EI(xi=.3), (2) the best of a sample set under EI(xi=.4, NR erf) -- one fused sweep, distance rule applied
+    in the kernel -- and (3) the prior's centres; the highest admissible proposal joins the gallery and is
+    added to the model with its own posterior mean as a hallucinated observation."""
+    gallery, model = _start(GP, bounds, useBest)
     rnd = 0
     while len(gallery) < N:
-        bestUCB = -np.inf
-        bestX = None
-        opt, optx = maximizeEI(hallucGP, bounds, xi=.3, useCDIRECT=useCDIRECT)
-        if len(gallery) == 0 or min(norm(optx - gx) for gx in gallery) > .5:
-            bestUCB = opt
-            bestX = optx
+        pick_val, pick = -np.inf, None
+        opt, optx = maximizeEI(model, bounds, xi=.3, useCDIRECT=useCDIRECT)
+        if _separated(optx, gallery):
+            pick_val, pick = opt, optx
 
-        # sample set for this round
         if lhc_per_round is not None:
             S = np.asarray(lhc_per_round[rnd], dtype=float)
         elif candidates is not None:
             S = candidates
         else:
             S = np.array(lhcSample(bounds, samples, seed=None if seed is None else seed + rnd))
-        excl = np.array(gallery) if gallery else None
+        shown = np.array(gallery) if gallery else None
         if comm is not None:
             # S is this rank's block of the candidate array (rows index_base ...): sharded sweep + one exchange
             from ..multigpu import sharded_sweep
-            r = sharded_sweep(hallucGP, S, index_base, comm, acq='ei', xi=.4, native=False, exclude=excl,
-                              exclude_radius=.5)
-            if r["best_idx"] >= 0 and r["best_val"] > bestUCB:
-                bestUCB = r["best_val"]
-                bestX = np.array(r["best_x"])
+            r = sharded_sweep(model, S, index_base, comm, acq='ei', xi=.4, native=False, exclude=shown,
+                              exclude_radius=MIN_SEPARATION)
+            if r["best_idx"] >= 0 and r["best_val"] > pick_val:
+                pick_val, pick = r["best_val"], np.array(r["best_x"])
         else:
-            r = sweep(hallucGP, S, acq='ei', xi=.4, native=False, exclude=excl, exclude_radius=.5)
-            if r["best_idx"] >= 0 and r["best_val"] > bestUCB:
-                bestUCB = r["best_val"]
-                if isinstance(S, _lib.DeviceArray):
-                    bestX = S.view_rows(r["best_idx"], r["best_idx"] + 1).to_host()[0]
-                else:
-                    bestX = np.array(S[r["best_idx"]])
+            r = sweep(model, S, acq='ei', xi=.4, native=False, exclude=shown, exclude_radius=MIN_SEPARATION)
+            if r["best_idx"] >= 0 and r["best_val"] > pick_val:
+                k = r["best_idx"]
+                pick_val = r["best_val"]
+                pick = S.view_rows(k, k + 1).to_host()[0] if isinstance(S, _lib.DeviceArray) else np.array(S[k])
 
-        if hallucGP.prior is not None:
-            ut = EI(hallucGP, xi=.4)
-            for x in hallucGP.prior.means:
-                x = np.array([np.clip(x[i], bounds[i][0], bounds[i][1]) for i in range(len(x))])
-                x = x * hallucGP.prior.width + hallucGP.prior.lowerb
-                u = -ut.negf(x)
-                if u > bestUCB:
-                    if len(gallery) == 0 or min(norm(x - gx) for gx in gallery) > .5:
-                        bestUCB = u
-                        bestX = x
+        if model.prior is not None:
+            extra = _prior_centres(model, bounds, gallery, pick_val)
+            if extra is not None:
+                pick_val, pick = extra
 
-        gallery.append(bestX)
-        hallucGP.addData(bestX, hallucGP.mu(bestX))
+        gallery.append(pick)
+        model.addData(pick, model.mu(pick))
         rnd += 1
     return gallery

@@ -78,6 +78,7 @@ class GaussianProcess(object):
         self._device = device
         self._dev = None            # _DeviceGP, created at the first fit
         self._cache = {}
+        self._prior_key, self._prior_pushed = None, False
 
         if (X is None and Y is not None) or (X is not None and Y is None):
             raise ValueError
@@ -126,18 +127,45 @@ class GaussianProcess(object):
         _lib.check(rc)
         if dev is None:
             self._cache = {}
+            self._prior_pushed = False
             self._push_prior()
 
-    def _push_prior(self):
+    def _prior_arrays(self):
+        """flatten the mean prior for the device: (means (k, D), beta, theta, lowerb, width) or None.
+        The device evaluates RBF-network priors (the only kind the reference's native path knows,
+        cpp/optimizeGP.cpp:116-133); anything else is refused loudly rather than silently dropped."""
         p = self.prior
-        h = self._handle()
-        if p is None or getattr(p, "means", None) is None:
-            _lib.check(_lib.lib.ibo_gp_set_prior(h, 0, None, None, 0.0, None, None))
+        if p is None:
+            return None
+        need = ("means", "beta", "theta", "lowerb", "width")
+        if not all(hasattr(p, a) for a in need):
+            raise NotImplementedError("the device path evaluates RBFNMeanPrior-style priors (means, beta, theta, lowerb, "
+                                      "width); %s is not one" % type(p).__name__)
+        if any(getattr(p, a) is None for a in need):
+            raise ValueError("the mean prior has not been trained or filled in (means/beta/lowerb/width missing)")
+        beta = _lib.f64(np.asarray(p.beta, dtype=float).reshape(-1))
+        means = _lib.f64(np.array(p.means, dtype=float).reshape(len(beta), -1))
+        return means, beta, float(p.theta), _lib.f64(p.lowerb), _lib.f64(p.width)
+
+    def _push_prior(self):
+        """bring the device's copy of the prior in line with self.prior.  Called before every device
+        evaluation: the prior may have been assigned, trained or edited in place since the fit, and the
+        arrays are a few hundred bytes (the comparison costs microseconds)."""
+        if self._dev is None:
             return
-        means = _lib.f64(np.array(p.means).reshape(len(p.beta), -1))
-        beta = _lib.f64(p.beta); lo = _lib.f64(p.lowerb); wd = _lib.f64(p.width)
-        _lib.check(_lib.lib.ibo_gp_set_prior(h, len(beta), _lib.dp(means), _lib.dp(beta), float(p.theta),
-                                             _lib.dp(lo), _lib.dp(wd)))
+        arrs = self._prior_arrays()
+        key = None if arrs is None else (arrs[0].tobytes(), arrs[1].tobytes(), arrs[2], arrs[3].tobytes(), arrs[4].tobytes())
+        if key == self._prior_key and self._prior_pushed:
+            return
+        h = self._handle()
+        if arrs is None:
+            _lib.check(_lib.lib.ibo_gp_set_prior(h, 0, None, None, 0.0, None, None))
+        else:
+            means, beta, theta, lo, wd = arrs
+            if means.shape[1] != self.X.shape[1]:
+                raise ValueError("prior centres have %d dimensions, the data %d" % (means.shape[1], self.X.shape[1]))
+            _lib.check(_lib.lib.ibo_gp_set_prior(h, len(beta), _lib.dp(means), _lib.dp(beta), theta, _lib.dp(lo), _lib.dp(wd)))
+        self._prior_key, self._prior_pushed = key, True
 
     def _get_matrix(self, name):
         if name not in self._cache:
@@ -177,6 +205,7 @@ class GaussianProcess(object):
         """host points in, host arrays out, through the device sweep (PCIe-inclusive)"""
         Q = _lib.f64(np.atleast_2d(Q))
         M, D = Q.shape
+        self._push_prior()
         if self._augdev is not None and acq != _lib.ACQ_NONE:
             # augmented variance in force (addObservationPoint): mean and variance come from two
             # factors, so the acquisition is formed from them as the reference's classes do
@@ -222,6 +251,7 @@ class GaussianProcess(object):
     def _posterior_arrays(self, Q, getvar=True):
         Q = _lib.f64(np.atleast_2d(Q))
         M = len(Q)
+        self._push_prior()
         mu = np.empty(M)
         s2 = np.empty(M) if getvar else None
         _lib.check(_lib.lib.ibo_posterior_batch(self._handle(), M, _lib.dp(Q), _lib.CLAMP_PY, _lib.dp(mu),
@@ -345,36 +375,43 @@ class PrefGaussianProcess(GaussianProcess):
             S, g, rho = Sn, gn, rn
         return y
 
+    @staticmethod
+    def _point_key(x):
+        """hashable identity of a point: its fp64 bytes (+0.0 folds -0.0 into 0.0, as == would)"""
+        return (np.asarray(x, dtype=np.float64) + 0.0).tobytes()
+
+    @classmethod
+    def _index_preferences(cls, prefs):
+        """distinct points of all (preferred, unpreferred, degree) triples in order of first appearance
+        (preferred before unpreferred within a triple; the reference's numbering, :395-406, which callers
+        see through GP.X) -> (points (n, D), [(i_preferred, i_unpreferred, degree)], was-ever-preferred mask)"""
+        slot = {}
+        pts = []
+        pairs = []
+        fav = []
+        for better, worse, degree in prefs:
+            ij = []
+            for x in (better, worse):
+                key = cls._point_key(x)
+                k = slot.get(key)
+                if k is None:
+                    k = slot[key] = len(pts)
+                    pts.append(np.asarray(x, dtype=float))
+                    fav.append(False)
+                ij.append(k)
+            fav[ij[0]] = True
+            pairs.append((ij[0], ij[1], degree))
+        return np.array(pts, dtype=float), pairs, fav
+
     def addPreferences(self, prefs, useC=True, showPrefLikelihood=False):
         """add (x_preferred, x_unpreferred, degree) triples and refit from ALL preferences (:347-498)"""
         self.preferences.extend(prefs)
-
-        x2ind = {}
-        prefinds = []
-        vs = set()
-        for v, u, d in self.preferences:
-            v = tuple(np.asarray(v, dtype=float)); u = tuple(np.asarray(u, dtype=float))
-            vs.add(v)
-            if v not in x2ind:
-                x2ind[v] = len(x2ind)
-            if u not in x2ind:
-                x2ind[u] = len(x2ind)
-            prefinds.append((x2ind[v], x2ind[u], d))
-        newX = np.array([x for x, _ in sorted(x2ind.items(), key=lambda t: t[1])], dtype=float)
-
-        lastY = {}
-        for x, y in zip(self.X, self.Y):
-            lastY[tuple(x)] = y
-        if len(self.Y) > 0:
-            ymax, ymin = max(self.Y), min(self.Y)
-        else:
-            ymax, ymin = .5, -.5
-        start = []
-        for x in newX:
-            if tuple(x) in lastY:
-                start.append(lastY[tuple(x)])
-            else:
-                start.append(ymax if tuple(x) in vs else ymin)
+        newX, prefinds, preferred = self._index_preferences(self.preferences)
+        # warm start of the MAP (:408-427): a point keeps the latent value it had; a new point starts at the
+        # top of the current range if it was ever preferred, at the bottom otherwise
+        had = dict((self._point_key(x), y) for x, y in zip(self.X, self.Y))
+        top, bottom = (max(self.Y), min(self.Y)) if len(self.Y) > 0 else (.5, -.5)
+        start = [had.get(self._point_key(x), top if fav else bottom) for x, fav in zip(newX, preferred)]
 
         # K(X,X), Cholesky and L^-1 on the GPU (:432-438)
         self.X = newX

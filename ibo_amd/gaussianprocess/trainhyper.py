@@ -82,7 +82,12 @@ _last = {"key": None, "value": None, "grad": None}
 
 def _value_and_grad(loghyper, kernel, X, Y):
     loghyper = np.asarray(loghyper, dtype=float)
-    key = (loghyper.tobytes(), kernel, id(X), id(Y), len(Y), float(np.sum(Y)), float(np.sum(X[0])))
+    # keyed on the CONTENT of the data (a digest: 0.1 ms at N=4096, D=16 against a 9 ms factorisation), so an
+    # in-place edit of X or Y can never return the pair computed for the old data
+    import hashlib
+    dig = hashlib.blake2b(_lib.f64(np.vstack(X)).tobytes(), digest_size=16)
+    dig.update(_lib.f64(Y).tobytes())
+    key = (loghyper.tobytes(), kernel, dig.digest())
     if _last["key"] != key:
         k = kernel(np.exp(loghyper))
         _last["key"] = None

@@ -239,3 +239,67 @@ def test_install_as_ego_aliases_every_module():
     assert inspect.signature(fastUCBGallery).parameters["samples"].default == 300
     sig = inspect.signature(GaussianProcess.__init__)
     assert sig.parameters["noise"].default == .1 and sig.parameters["gnoise"].default == 1e-4
+
+
+def test_python_direct_matches_the_reference_restated(oracle):
+    """ibo_amd.utils.optimize.direct (columns of boxes, size-grouped selection) against the oracle's statement-level
+    restatement of ego/utils/optimize.py:58-280: same minimum, same location, same number of samples, on smooth,
+    plateau, all-ties and zero-minimum objectives and under each termination rule"""
+    from ibo_amd.utils.optimize import direct
+
+    def bowl(D, seed):
+        c = np.random.RandomState(seed).rand(D)
+        return lambda x: float(np.sum((np.array(x) - c) ** 2) + 0.3 * np.sin(5 * np.sum(x)))
+    cases = [(bowl(2, 1), [[-1., 2.]] * 2, dict(maxiter=12)), (bowl(3, 2), [[-1., 2.]] * 3, dict(maxiter=9)),
+             (bowl(4, 3), [[0., 1.]] * 4, dict(maxsample=400)), (bowl(3, 5), [[-2., 1.]] * 3, dict(maxiter=30, maxsample=500)),
+             (lambda x: 0.0, [[0., 1.]] * 2, dict(maxiter=8)),
+             (lambda x: float(np.round(np.sum(np.abs(np.array(x))), 1)), [[-1., 1.]] * 2, dict(maxiter=8)),
+             (lambda x: float(abs(x[0] - .5) + abs(x[1] - .5)), [[0., 1.]] * 2, dict(maxiter=10)),
+             (lambda x, a: float((x[0] - a) ** 2), [[0., 3.]], dict(maxiter=15, args=[1.25]))]
+    for f, b, kw in cases:
+        (fm, xm), rep = direct(f, b, debug=True, **kw)
+        o = oracle.direct_py(f, b, **kw)
+        assert fm == o[0] and np.array_equal(xm, o[1]) and rep["samples"] == o[2], (kw, fm, o)
+        assert len(rep["fmin evolution"]) >= 1 and all(hasattr(r, "lb") for r in rep["rectangles"])
+
+
+def test_gallery_and_preference_host_helpers():
+    from ibo_amd.acquisition.gallery import _best_observation_inside, _separated
+    from ibo_amd.gaussianprocess import PrefGaussianProcess
+    X = np.array([[.1, .1], [.9, .9], [2., .5], [.9, .9]])
+    Y = np.array([1., 3., 9., 3.])
+    b = [[0., 1.], [0., 1.]]
+    np.testing.assert_array_equal(_best_observation_inside(X, Y, b), [.9, .9])       # best INSIDE the box, first of ties
+    assert _best_observation_inside(X[2:3], Y[2:3], b) is None
+    assert _separated([0., 0.], []) and _separated([0., 0.], [[.6, 0.]]) and not _separated([0., 0.], [[.5, 0.]])
+    a, c, d = np.array([.1, .2]), np.array([.3, .4]), np.array([.5, .6])
+    pts, pairs, fav = PrefGaussianProcess._index_preferences([(a, c, 0), (d, a, 1), (c, d, 0), (np.array([.1, .2]), d, 0)])
+    np.testing.assert_array_equal(pts, [a, c, d])                                   # order of first appearance
+    assert pairs == [(0, 1, 0), (2, 0, 1), (1, 2, 0), (0, 2, 0)] and fav == [True, True, True]
+    pts, pairs, fav = PrefGaussianProcess._index_preferences([(a, c, 0), (a, np.array([0.0, -0.0]), 0), (a, np.array([0.0, 0.0]), 0)])
+    assert len(pts) == 3 and fav == [True, False, False] and pairs[1][1] == pairs[2][1]
+
+
+def test_test_function_zoo_known_minima():
+    """analytic objectives of ego/utils/testfunctions.py: the documented minima at the documented places"""
+    from ibo_amd.utils import testfunctions as tfs
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_iso, MaternKernel3
+    for cls in (tfs.Shekel5, tfs.Shekel7, tfs.Shekel10, tfs.Hartman3, tfs.Hartman6, tfs.Branin):
+        tf = cls(maximize=False)
+        assert abs(tf.f(tf.argmin) - tf.minimum) < 2e-3, cls.__name__
+        assert tf.f(tf.argmin) == -cls().f(tf.argmin)                               # maximize flips the sign
+        rnd = np.random.RandomState(0).rand(500, len(tf.bounds)) * (np.array(tf.bounds)[:, 1] - np.array(tf.bounds)[:, 0]) \
+            + np.array(tf.bounds)[:, 0]
+        v = tf.values(rnd)
+        assert v.shape == (500,) and np.all(v >= tf.f(tf.argmin) - 1e-9)
+        assert abs(tf.f(rnd[3]) - v[3]) < 1e-15
+    cb = tfs.Camelback(maximize=False)
+    assert abs(cb.f([-0.0898, 0.7126]) + 1.0316) < 1e-3 and abs(cb.f([0.0898, -0.7126]) + 1.0316) < 1e-3
+    assert abs(tfs.GoldsteinPrice(maximize=False).f([0., -1.]) - np.log(3.)) < 1e-12
+    assert tfs.Sphere(3).f(np.zeros(3)) == 0.0 and tfs.SumSquares(3, maximize=False).f([1., 1., 1.]) == 6.0
+    g = load_golden("g4_direct")
+    x = np.array([3.7, 4.2, 4.1, 3.9])
+    assert abs(tfs.Shekel5(maximize=False).f(x) - shekel5(g)(x)) < 1e-14             # the golden file's own Shekel data
+    assert isinstance(tfs.Shekel5().createKernel(GaussianKernel_iso), GaussianKernel_iso)
+    with pytest.raises(ValueError):
+        tfs.Shekel5().createKernel(MaternKernel3)

@@ -310,6 +310,47 @@ def test_sweep_full_size_properties(ibo):
         close(m, r["mu"][i], rtol=1e-9, atol=1e-11); close(max(v, 1e-7), max(r["s2"][i], 1e-7), rtol=1e-9)
 
 
+def test_c2_full_size_winner_against_the_oracle(ibo, oracle):
+    """C2 at its stated size: the winning candidate of the 2^20 sweep, the runner-up region and 256 random
+    candidates are re-evaluated by the CPU oracle's reference-shaped posterior (two N^2 matvecs with inv(R),
+    cpp/optimizeGP.cpp:57-215); values within 1e-6, and the oracle agrees that the winner beats them all"""
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.acquisition import sweep
+    from ibo_amd import DeviceArray
+    X, Y = synth(2, 1024, 4)
+    GP = GaussianProcess(GaussianKernel_ard([.3] * 4), X, Y, noise=.1)
+    M = 1 << 20
+    cand = np.random.RandomState(102).rand(M, 4)
+    r = sweep(GP, DeviceArray.from_host(cand), acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+    w = r["best_idx"]
+    top = np.argsort(-r["acq"], kind="stable")[:32]                # the winner and its closest rivals
+    assert top[0] == w
+    idx = np.unique(np.r_[top, np.random.RandomState(7).choice(M, 256, replace=False)])
+    ogp = oracle.GP(oracle.Kern("ard", [.3] * 4), X, Y, noise=.1)
+    o = oracle.sweep_native(ogp, cand[idx], oracle.ACQ_EI, .01)
+    close(r["mu"][idx], o["mu"], atol=1e-10); close(r["s2"][idx], o["s2"])
+    close(r["acq"][idx], o["acq"], atol=ACQ_ATOL)
+    assert idx[o["best_idx"]] == w                                  # the oracle picks the same winner
+    close(r["best_val"], o["best_val"], atol=ACQ_ATOL)
+
+
+def test_sweep_index_base_beyond_32_bits(ibo):
+    """global indices of a shard far into a huge candidate set: index_base > 2^31 (and > 2^32) is carried in
+    64 bits through the kernel's partials, the final reduction and the ABI"""
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.acquisition import sweep
+    X, Y = synth(61, 96, 3)
+    GP = GaussianProcess(GaussianKernel_ard([.3] * 3), X, Y, noise=.1)
+    for M in (9, 700, 20000):                                        # GEMV, panel-split and tile kernels
+        cand = np.random.RandomState(62).rand(M, 3)
+        r0 = sweep(GP, cand)
+        for base in ((1 << 31) + 5, (1 << 33) + 123456789, (1 << 52)):
+            r = sweep(GP, cand, index_base=base)
+            assert r["best_idx"] == base + r0["best_idx"] and r["best_val"] == r0["best_val"]
+
+
 def test_g7_preference_gp(ibo, oracle):
     from ibo_amd.gaussianprocess import PrefGaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
@@ -390,9 +431,40 @@ def test_g2_g8_marginal_likelihood(ibo):
     g_o = lambda lh: orc.marginal_likelihood(orc.Kern("svard", np.exp(lh)), X, Y, 4, True, 1e-3)[1]
     ref = optimize.fmin_bfgs(f_o, x0, g_o, disp=False)
     close(f_o(ours), f_o(ref), rtol=1e-6)
-    # not-PD -> 100 through the nlml() wrapper (trainhyper.py:111-114)
+    # the optima the reference's own test prints (ego/unittest_GP.py:216-219): [6.9714, 0.95405, -0.9769, 0.36469].
+    # The first log length scale sits on a plateau (the data hardly vary along that axis): today's SciPy line
+    # search stops at 8.9 on the CPU oracle too, where the reference's 2010 SciPy stopped at 6.97 -- the NLML
+    # differs by 2e-6 between the two -- so that component is only required to be "large"; the other three are
+    # pinned to the printed 2 decimals.
+    assert ours[0] > 5.0
+    np.testing.assert_allclose(ours[1:], [0.95405, -0.9769, 0.36469], atol=5e-3)
+    # ... and the isotropic case (:250-252): [-0.0893, 0.29]
+    ours_iso = optimize.fmin_bfgs(nlml, np.log([1.5, 1.1]), dnlml, args=(K.SVGaussianKernel_iso, X, Y), disp=False)
+    np.testing.assert_allclose(ours_iso, [-0.0893, 0.29], atol=5e-3)
+    # not-PD -> 100 through the nlml() wrapper (trainhyper.py:111-114).  A coincident pair plus a negative
+    # "noise" makes K indefinite beyond any rounding doubt (2x2 minor [[.5, 1], [1, .5]])
     Xd = np.vstack([X, X[:1]])
-    assert nlml(np.log([2., 2., .1]), lambda h: K.GaussianKernel_ard(h), Xd, np.r_[Y, 1.0]) in (100,) or True
+    Yd = np.r_[Y, 1.0]
+    from ibo_amd.gaussianprocess import trainhyper
+    with pytest.raises(np.linalg.LinAlgError):
+        marginalLikelihood(K.GaussianKernel_ard([2., 2., .1]), Xd, Yd, 3, True, noise=-0.5)
+    with pytest.raises(np.linalg.LinAlgError):
+        marginalLikelihood(K.GaussianKernel_ard([2., 2., .1]), Xd, Yd, 3, False, noise=-0.5)
+    real = trainhyper.marginalLikelihood
+    try:
+        trainhyper.marginalLikelihood = lambda k, X_, Y_, n, computeGradient=True, **kw: real(k, X_, Y_, n, computeGradient, noise=-0.5)
+        assert nlml(np.log([2., 2., .1]), K.GaussianKernel_ard, Xd, Yd) == 100
+    finally:
+        trainhyper.marginalLikelihood = real
+    # the value/gradient memo is keyed on the data's CONTENT: an in-place edit that keeps every sum must not
+    # return the stale pair
+    Xa = np.array(X, dtype=float)
+    lh = np.log([2., 2., .1])
+    v1 = nlml(lh, K.GaussianKernel_ard, Xa, Y)
+    Xa[0, 0], Xa[0, 1] = Xa[0, 1], Xa[0, 0]          # same row sum, same id(), different matrix
+    v2 = nlml(lh, K.GaussianKernel_ard, Xa, Y)
+    close(v2, marginalLikelihood(K.GaussianKernel_ard([2., 2., .1]), Xa, Y, 3, False), rtol=1e-12)
+    assert v1 != v2
 
 
 def test_legacy_acqmaxGP_symbol(ibo, oracle):
@@ -550,6 +622,91 @@ def test_c4_preference_gp_128_pairs(ibo, oracle):
     o_mu, o_s2 = ogp.posteriors(probe)
     close(mu, o_mu, atol=1e-9); close(s2, o_s2)
     assert sum(GP.mu(v) > GP.mu(u) for v, u, _ in prefs) >= 0.9 * P
+
+
+def test_c4_preference_gp_512_pairs_full_size(ibo, oracle):
+    """C4 at its stated size (512 pairs -> 1024 points, D=6): everything downstream of the MAP -- C, L = chol(R +
+    C^-1), posterior mean/variance -- against the oracle fed with the same latent values; the MAP itself must
+    lower S and respect the orderings (the reference's BFGS optimum is not pinned)"""
+    from ibo_amd.gaussianprocess import PrefGaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    P = 512
+    hyp = [0.53, 0.57, 2.5, 0.34, 0.27, 0.35]
+    pts = np.random.RandomState(4).rand(2 * P, 6)
+    prefs = []
+    for i in range(P):
+        a, b = pts[2 * i], pts[2 * i + 1]
+        prefs.append((a, b, 0) if _hartman6(a) > _hartman6(b) else (b, a, 0))
+    GP = PrefGaussianProcess(GaussianKernel_ard(hyp), prefs)
+    assert len(GP.X) == 2 * P and GP.C.shape == (2 * P, 2 * P)
+    ogp = oracle.pref_fit(oracle.Kern("ard", hyp), prefs, noise=.1, Y_map=GP.Y)
+    np.testing.assert_array_equal(GP.X, ogp.X)                       # same point numbering
+    close(GP.R, ogp.R, rtol=1e-12, atol=1e-14)
+    close(GP.C, ogp.C, atol=1e-9); close(GP.L, ogp.L, atol=1e-9)
+    Lr = np.linalg.cholesky(ogp.R)
+    start = np.array([.5 if i in set(v for v, _, _ in ogp.inds) else -.5 for i in range(2 * P)])
+    assert oracle.pref_S(GP.Y, ogp.inds, Lr) < oracle.pref_S(start, ogp.inds, Lr)
+    probe = np.random.RandomState(5).rand(64, 6)
+    mu, s2 = GP.posteriors(probe)
+    o_mu, o_s2 = ogp.posteriors(probe)
+    close(mu, o_mu, atol=1e-9); close(s2, o_s2)
+    assert sum(GP.mu(v) > GP.mu(u) for v, u, _ in prefs[:128]) >= 0.9 * 128
+
+
+def test_rbfn_prior_train_reproduces_the_reference(ibo):
+    """RBFNMeanPrior.train (ego/gaussianprocess/prior.py:76-156) on the data the golden script trained the
+    s512_prior_ard prior with (tests/golden/make_golden.py: 100 latin-hypercube points of Shekel5, k=10,
+    seed=504): same centres (the k-means and its random stream are deterministic) and weights"""
+    from ibo_amd.gaussianprocess.prior import RBFNMeanPrior, GPMeanPrior
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.utils.latinhypercube import lhcSample
+    from ibo_amd.utils.testfunctions import Shekel5
+    g = load_golden("g3_cases")
+    p = "s512_prior_ard/"
+    S5 = Shekel5()
+    pX = lhcSample(S5.bounds, 100, seed=511)
+    pY = [S5.f(x) for x in pX]
+    prior = RBFNMeanPrior()
+    prior.train(pX, pY, bounds=S5.bounds, k=10, seed=504)
+    close(np.array(prior.means), g[p + "pmeans"], rtol=1e-12, atol=1e-14)
+    close(prior.beta, g[p + "pbeta"], rtol=1e-7, atol=1e-9)
+    close(prior.lowerb, g[p + "plowerb"]); close(prior.width, g[p + "pwidth"])
+    close([prior.mu(q) for q in g[p + "probe"]], g[p + "prior_mu"], rtol=1e-7, atol=1e-10)
+    # a prior assigned (or trained) AFTER the fit is honoured by the next evaluation, and taken away again
+    X, Y = g[p + "X"], g[p + "Y"]
+    GP = GaussianProcess(GaussianKernel_ard(g[p + "hyper"]), X, Y, noise=float(g[p + "noise"]))
+    plain = GP.posteriors(g[p + "probe"])[0]
+    GP.prior = our_prior(g, p)
+    close(np.array([GP.posterior(q) for q in g[p + "probe"]]), g[p + "post"], atol=1e-9)
+    GP.prior.beta = np.asarray(GP.prior.beta) * 2.0                  # edited in place
+    assert not np.allclose(GP.posteriors(g[p + "probe"])[0], g[p + "post"][:, 0])
+    GP.prior = None
+    np.testing.assert_array_equal(GP.posteriors(g[p + "probe"])[0], plain)
+    # priors the device cannot represent are refused, never silently dropped
+    class Flat(GPMeanPrior):
+        def mu(self, x):
+            return 1.0
+    GP.prior = Flat()
+    with pytest.raises(NotImplementedError):
+        GP.posterior(g[p + "probe"][0])
+    GP.prior = RBFNMeanPrior()                                        # never trained
+    with pytest.raises(ValueError):
+        GP.posterior(g[p + "probe"][0])
+
+
+def test_synthetic_test_function_and_learn_hyper(ibo):
+    from ibo_amd.utils.testfunctions import Synthetic, Hartman3, learnHyper
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_iso
+    b = [[0., 1.]] * 2
+    tf = Synthetic(GaussianKernel_iso([.3]), b, 30, seed=3, xstar=np.array([.25, .75]), maximize=False)
+    assert len(tf.GP.X) == 31 and np.allclose(tf.xstar, [.25, .75])
+    grid = np.random.RandomState(0).rand(2000, 2)
+    v = tf.values(grid)
+    assert abs(tf.f(grid[5]) - v[5]) < 1e-12
+    assert tf.f(tf.xstar) <= v.min() + 0.5                          # the planted point is (close to) the global minimum
+    th = learnHyper(Hartman3(), GaussianKernel_iso, seed=1)
+    assert th.shape == (1,) and 0.05 < th[0] < 2.0
 
 
 def test_c5_nlml_full_size(ibo, oracle):
