@@ -175,7 +175,7 @@ struct ibo_gp {
     const char *sweep_kernel = "";
     std::vector<double> Yhost;
     double *pin = nullptr; size_t pin_cap = 0;      // pinned host staging for small host-in/host-out batches
-    DevBuf<double> Xp, Xs, ak, Y, R, A, L, W, T, Wp, diag64, alphaY, alpha1, tmp, cand, outs, excl, qpart, mupart, partv, res_v;
+    DevBuf<double> Xp, Xs, ak, XA, Y, R, A, L, W, T, Wp, diag64, alphaY, alpha1, tmp, cand, outs, excl, qpart, mupart, partv, res_v;
     DevBuf<int64_t> parti, res_i;
     DevBuf<int> info;
     // prior
@@ -298,7 +298,7 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     if (!g) return IBO_OK;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    g->Xp.release(); g->Xs.release(); g->ak.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
+    g->Xp.release(); g->Xs.release(); g->ak.release(); g->XA.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
     g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release();
@@ -366,10 +366,14 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
     const int Np = g->Npad, DP = g->DP;
     size_t nn = (size_t)Np * Np;
     IBO_TRY(g->Xp.ensure((size_t)Np * DP)); IBO_TRY(g->Xs.ensure((size_t)Np * DP)); IBO_TRY(g->ak.ensure(Np));
+    IBO_TRY(g->XA.ensure((size_t)((Np + 127) / 128 * 8) * ((D + 5) / 4) * 64));
     IBO_TRY(g->Y.ensure(Np));
     IBO_TRY(g->R.ensure((size_t)N * N)); IBO_TRY(g->L.ensure(nn)); IBO_TRY(g->W.ensure(nn));
     IBO_TRY(g->T.ensure(nn)); IBO_TRY(g->Wp.ensure(nn)); IBO_TRY(g->diag64.ensure((size_t)(Np / 64) * 4096));
-    IBO_TRY(g->alphaY.ensure(Np)); IBO_TRY(g->alpha1.ensure(Np));
+    // sweep2's stages cover rows up to the next multiple of 128: the tail of both alpha vectors stays zero
+    IBO_TRY(g->alphaY.ensure((size_t)Np + 128)); IBO_TRY(g->alpha1.ensure((size_t)Np + 128));
+    HIP_TRY(hipMemsetAsync(g->alphaY.p + Np, 0, 128 * sizeof(double), g->stream));
+    HIP_TRY(hipMemsetAsync(g->alpha1.p + Np, 0, 128 * sizeof(double), g->stream));
     IBO_TRY(g->tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));
     IBO_TRY(g->info.ensure(1));
     std::vector<double> xp((size_t)Np * DP, 0.0), yp(Np, 0.0);
@@ -415,6 +419,7 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     const int Np = g->Npad;
     hipStream_t s = g->stream;
     KERNEL_TRY(launch_scale_x(kp, g->Xp.p, Np, g->DP, g->Xs.p, g->ak.p, s));
+    KERNEL_TRY(launch_pack_xa(g->Xs.p, g->ak.p, N, Np, g->DP, D, g->XA.p, s));
     g->dot_form = dot_form_ok(kp, X, N, D);
     if (A_host) {
         IBO_TRY(g->A.ensure((size_t)N * N));
@@ -473,6 +478,7 @@ static int fit_from_inverse(ibo_gp *g, int ktype, int N, int D, const double *X,
     const int Np = g->Npad;
     hipStream_t s = g->stream;
     KERNEL_TRY(launch_scale_x(kp, g->Xp.p, Np, g->DP, g->Xs.p, g->ak.p, s));
+    KERNEL_TRY(launch_pack_xa(g->Xs.p, g->ak.p, N, Np, g->DP, D, g->XA.p, s));
     g->dot_form = dot_form_ok(kp, X, N, D);
     IBO_TRY(g->A.ensure((size_t)N * N));
     HIP_TRY(hipMemcpyAsync(g->A.p, invR, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
@@ -673,6 +679,21 @@ extern "C" int ibo_spd_inverse(int device, int N, const double *A_host, double *
     return rc;
 }
 
+// 2^(j/2048), j < 2048: the table behind sweep2's exp (one per device, created on first use)
+static double *g_exp_tab[16];
+static int exp_table(int device, const double **out)
+{
+    double *&p = g_exp_tab[device & 15];
+    if (!p) {
+        std::vector<double> h(2048);
+        for (int j = 0; j < 2048; j++) h[j] = exp2((double)j / 2048.0);
+        HIP_TRY(hipMalloc((void **)&p, sizeof(double) * 2048));
+        HIP_TRY(hipMemcpy(p, h.data(), sizeof(double) * 2048, hipMemcpyHostToDevice));
+    }
+    *out = p;
+    return IBO_OK;
+}
+
 // ------------------------------------------------------------------------ sweep
 static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
                      double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,
@@ -686,7 +707,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     SweepArgs a;
     memset(&a, 0, sizeof(a));
     a.kp = g->kp; a.N = g->N; a.Npad = g->Npad; a.DP = g->DP; a.M = M;
-    a.Xs = g->Xs.p; a.ak = g->ak.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = g_dot_override >= 0 ? g_dot_override : g->dot_form;
+    a.Xs = g->Xs.p; a.ak = g->ak.p; a.XA = g->XA.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = g_dot_override >= 0 ? g_dot_override : g->dot_form;
     a.Xp = g->Xp.p; a.W = g->W.p; a.Wp = g->Wp.p; a.alphaY = g->alphaY.p; a.alpha1 = g->alpha1.p;
     a.cand = cand_dev;
     a.prior.nb = g->nb; a.prior.theta = g->ptheta; a.prior.means = g->pmeans.p; a.prior.beta = g->pbeta.p;
@@ -704,7 +725,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     a.index_base = index_base;
     a.out_mu = mu_dev; a.out_s2 = s2_dev; a.out_acq = acq_dev;
     int64_t ntiles = (M + 63) / 64;
-    IBO_TRY(g->partv.ensure(ntiles)); IBO_TRY(g->parti.ensure(ntiles));
+    IBO_TRY(g->partv.ensure(2 * ntiles)); IBO_TRY(g->parti.ensure(2 * ntiles));     // sweep2 has 32-candidate tiles
     IBO_TRY(g->res_v.ensure(1)); IBO_TRY(g->res_i.ensure(1));
     a.part_val = g->partv.p; a.part_idx = g->parti.p;
     const bool want_best = best_val || best_idx;
@@ -723,6 +744,10 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         a.qpart = g->qpart.p; a.mupart = g->mupart.p;
         KERNEL_TRY(launch_sweep_gemv(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_gemv_kernel";
+    } else if (a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad)) {
+        IBO_TRY(exp_table(g->device, &a.exp_tab));
+        KERNEL_TRY(launch_sweep2(a, s, g->ev0, g->ev1));
+        g->sweep_kernel = "sweep2_kernel";
     } else {
 #ifdef IBO_STAMPS
         IBO_TRY(g->mupart.ensure((size_t)ntiles * 16 + 16));

@@ -161,6 +161,7 @@ __device__ __forceinline__ double acq_value_dev(int acq, int erf_mode, double mu
 
 // ---- host-side launch API of the kernels (defined in linalg.hip / sweep.hip)
 #define IBO_SPLIT_PANEL 64      // rows per workgroup of the small-batch (SPLIT) sweep
+#define IBO_S2_TCAND 32         // candidates per workgroup of sweep2_kernel (sweep2.hip)
 
 struct SweepArgs {
     KParams kp;
@@ -169,6 +170,8 @@ struct SweepArgs {
     const double *Xp;        // Npad x DP, zero padded
     const double *Xs;        // Npad x DP, coordinates scaled by sqrt(w_d)  (x~)
     const double *ak;        // Npad: -|x~_k|^2 / 2
+    const double *XA;        // [x~ | a_k | 1] in MFMA A-fragment order (pack_xa_kernel), rows padded to a multiple of 128
+    const double *exp_tab;   // 2^(j/2048), j < 2048 (device; sweep2's exp)
     double log_sf2;          // log of the k* signal variance
     int dot_form;            // y = ak + bc + x~.c~ (D+1 FMAs) instead of the difference form (2D)
     const double *W;         // Npad x Npad row-major lower-triangular, q = |W k*|^2
@@ -190,6 +193,10 @@ struct SweepArgs {
 
 int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+// large batches, dot form: 32-candidate tiles, 1024-row panels, exponent GEMM on the MFMA unit (sweep2.hip)
+int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+bool sweep2_fits(int Npad);      // its LDS budget holds both alpha vectors (N <= ~5000)
+int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, int D, double *XA, hipStream_t s);
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,

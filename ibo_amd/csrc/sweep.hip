@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
     }
 }
 
-int g_sweep_variant = 2;     // <NW,RBW,CBW,KCH>  0: <16,2,4,32>  1: <8,4,4,32>  2: <16,2,4,64> (default)  3: <16,4,2,64>  (ibo_set_option("sweep_variant"))
+int g_sweep_variant = 4;     // 4 (default): sweep2_kernel (sweep2.hip) where the dot form is admissible.  sweep_mfma_kernel <NW,RBW,CBW,KCH>:
+                             // 0: <16,2,4,32>  1: <8,4,4,32>  2: <16,2,4,64> (default of this kernel)  3: <16,4,2,64>  (ibo_set_option("sweep_variant"))
 
 template <int FAM, int NW, int RBW, int CBW, int KCH, bool DOT>
 static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)

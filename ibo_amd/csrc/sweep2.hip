@@ -1,0 +1,414 @@
+// sweep2.hip -- the candidate sweep's main kernel, second design (large batches, dot-form distances).
+//
+// Same mathematics as sweep.hip (GP_Maximizer::posterior + negei/negpi/negucb,
+// cpp/optimizeGP.cpp:57-236; GaussianProcess.posterior, ego/gaussianprocess/__init__.py:169-228):
+//   k*_i = k(x_i, c);  mu = m(c) + aY.k* - m(c) a1.k*;  q = |W k*|^2;  s2 = clamp(1+noise-q);  acq; arg-max.
+//
+// What bounds this kernel is the fp64 MFMA pipe, which executes on the fp64 FMA units: every VALU
+// instruction of any type issued beside it costs ~10 pipe cycles against 64 for an MFMA
+// (tools/mfma_f64_peak).  sweep.hip spends 1.3 of its 1.47 VALU instructions per MFMA on generating k*:
+// D+1 FMAs and a 16-instruction exp per (row, candidate), and every k* row is regenerated for each
+// 512-row panel of W (1.5x at N = 1024, 2.5x at N = 2048).  This kernel removes most of that:
+//
+//   * 32 candidates per workgroup instead of 64: with the same 64 accumulator VGPRs a wave now owns
+//     4 row-blocks x 2 candidate-blocks, so one panel is 16 waves x 4 x 16 = 1024 rows -- no
+//     regeneration up to N = 1024, 1.5x at N = 2048;
+//   * the exponent y = a_k + b_c + x~_k . c~ is itself a small GEMM, [x~ | a_k | 1] (N x (D+2)) times
+//     [c~ | 1 | b_c]^T, so it is done by the MFMA unit: ceil((D+2)/4) MFMAs give a 16-row x
+//     16-candidate tile of y (2 for D <= 6, 5 for D = 16) instead of 4 (D+1) VALU FMAs;
+//   * the MFMA output layout (lane l, element r = row (l>>4)+4r, column l&15) IS the B-fragment layout
+//     of the following V += W K* MFMA for k4-step r, so the four k* values of a lane go to LDS with four
+//     linear 512-byte wave stores and no address arithmetic; per stage every wave produces exactly one
+//     16 x 16 tile (16 waves = 128 rows x 32 candidates per stage);
+//   * W's A-fragments come straight from L2 by buffer_load_dwordx4 with a scalar row/column offset and
+//     ONE lane-offset VGPR (no 64-bit per-lane pointers), one 8-column step ahead, and only for
+//     row-blocks that still have non-zeros in that step (the triangle is skipped for loads and MFMAs).
+//
+// Used for batches > 8192 candidates when the dot form is admissible (ibo_gp.dot_form; otherwise, and
+// for the small-batch SPLIT / GEMV paths, sweep.hip's kernels run).
+#include "ibo_common.h"
+#include <type_traits>
+
+#define S2_NW 16
+#define S2_KCH 128                     // k* rows per LDS stage
+#define S2_PANEL 1024                  // rows of W per pass: 16 waves x 4 row-blocks x 16
+
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t s2_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+}
+
+__device__ __forceinline__ double s2_ld_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
+__device__ __forceinline__ double s2_lo(const v4u_t &v) { return __hiloint2double((int)v.y, (int)v.x); }
+__device__ __forceinline__ double s2_hi(const v4u_t &v) { return __hiloint2double((int)v.w, (int)v.z); }
+
+// exp(y) for the k* generation in 13 VALU instructions (exp_fast in ibo_common.h takes 17, the library ~30): every
+// VALU instruction here is paid in MFMA issue slots.  A 2048-entry table of 2^(j/2048) in LDS (reads are not VALU
+// instructions) shortens the polynomial to degree 3:
+//   t = y 2048/ln2 + 1.5 2^52 puts n = rint(y 2048/ln2) in the low mantissa bits of t; r = y - n ln2/2048
+//   (two-term Cody-Waite, |r| <= 1.7e-4: r^4/24 < 4e-17); j = n mod 2048 indexes the table, n div 2048 goes into
+//   the exponent field by an integer add.  Relative error < 4e-16.  y is clamped at -708 by exactly one v_max_f64
+//   (fmax() on a value the compiler cannot prove quiet costs a second, canonicalising one; an MFMA result is
+//   never a signalling NaN); valid up to y = 709.
+__device__ __forceinline__ double s2_exp(double y, const double *tab)
+{
+    double yc;
+    const double lo = -708.0;
+    asm("v_max_f64 %0, %1, %2" : "=v"(yc) : "v"(y), "s"(lo));
+    const double magic = 6755399441055744.0;               // 1.5 * 2^52
+    const double t = fma(yc, 2954.6394437405970584, magic);            // 2048 / ln 2
+    const double n = t - magic;
+    double r = fma(n, -3.3845077166461124e-04, yc);                    // ln2/2048, upper bits (21 trailing zeros)
+    r = fma(n, -9.317455709329042e-14, r);                              // ... and the remainder
+    const int ti = __double2loint(t);
+    const double T = *(const double *)((const char *)tab + ((ti << 3) & (2047 << 3)));
+    double p = fma(r, 1.0 / 6.0, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = T * p;
+    const int hi = __double2hiint(v) + ((ti & ~2047) << 9);             // (n div 2048) << 20
+    return __hiloint2double(hi, __double2loint(v));
+}
+
+// acquisition epilogue of one candidate; coordinates are read from global memory where needed (prior,
+// exclusion balls) so that no per-lane coordinate array exists (dynamic indexing would put it in scratch)
+__device__ __forceinline__ double s2_finish(const SweepArgs &a, const double *x, double q, double muY, double mu1,
+                                            int64_t li, bool valid, bool &excluded)
+{
+    const int D = a.kp.D;
+    double m = 0.0;
+    if (a.prior.nb > 0) {
+        for (int i = 0; i < a.prior.nb; i++) {
+            double d = 0.0;
+            for (int j = 0; j < D; j++) {
+                double t = (x[j] - a.prior.lowerb[j]) / a.prior.width[j] - a.prior.means[(size_t)i * D + j];
+                d += t * t;
+            }
+            m += a.prior.beta[i] * exp(-a.prior.theta * d);
+        }
+    }
+    const double mu = (a.prior.nb > 0) ? (m + muY - m * mu1) : muY;
+    double s2 = 1.0 + a.noise - q;
+    if (s2 < a.clamp_lo) s2 = a.clamp_lo;
+    else if (s2 > 10.0) s2 = 10.0;
+    const double val = (a.acq == 3) ? mu : acq_value_dev(a.acq, a.erf_mode, mu, sqrt(s2), a.ymax, a.parm);
+    excluded = false;
+    for (int e = 0; e < a.n_excl; e++) {
+        double d2 = 0.0;
+        for (int j = 0; j < D; j++) { double t = x[j] - a.excl[(size_t)e * D + j]; d2 += t * t; }
+        if (!(sqrt(d2) > a.excl_radius)) excluded = true;
+    }
+    if (valid) {
+        if (a.out_mu) a.out_mu[li] = mu;
+        if (a.out_s2) a.out_s2[li] = s2;
+        if (a.out_acq) a.out_acq[li] = val;
+    }
+    return val;
+}
+
+// KA4 = ceil((D + 2) / 4): k4-steps of the exponent GEMM
+template <int FAM, int KA4>
+__global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
+{
+    constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4;
+    static_assert(CBW == 2 && S2_NW * RBW * 16 == S2_PANEL && (S2_KCH / 16) * CBW == S2_NW, "tile geometry");
+    __shared__ double lds_k[2][S2_KCH * TCAND];    // K* stages in B-fragment order: [k4-step][cand-block][lane]
+    __shared__ double lds_c[TCAND * KA];            // augmented, scaled candidates [cand][KA]
+    __shared__ double lds_q[S2_NW][TCAND];
+    __shared__ double lds_m[2][S2_NW][16];
+    __shared__ double lds_tab[2048];                // 2^(j/2048)
+    extern __shared__ __attribute__((aligned(16))) double lds_alpha[];   // alphaY[NA128], alpha1[NA128] (NA128 = rows padded to 128)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tile0 = (int64_t)blockIdx.x * TCAND;
+    const int D = a.kp.D;
+
+    // ---- candidates of this tile: c~ = c sqrt(w), then the two extra columns 1 and b_c
+    const int NA128 = (a.Npad + 127) & ~127;
+    lds_tab[tid] = a.exp_tab[tid];
+    lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
+    for (int e = tid; e < NA128; e += S2_NW * 64) {                 // both vectors are zero beyond N (abi.hip pads them)
+        lds_alpha[e] = a.alphaY[e];
+        lds_alpha[NA128 + e] = a.alpha1[e];
+    }
+    for (int e = tid; e < TCAND * KA; e += S2_NW * 64) {
+        const int c = e / KA, col = e - c * KA;
+        int64_t gi = tile0 + c;
+        if (gi > a.M - 1) gi = a.M - 1;
+        lds_c[e] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid < TCAND) {
+        double n2 = 0.0;
+        for (int d = 0; d < D; d++) { const double v = lds_c[tid * KA + d]; n2 = fma(v, v, n2); }
+        lds_c[tid * KA + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
+    }
+    __syncthreads();
+    // this wave generates the 16 x 16 tile (row-tile rt, candidate block gcb) of every stage
+    const int rt = wave >> 1, gcb = wave & 1;
+    // its B-fragments of the exponent GEMM, c~aug[candidate 16 gcb + (lane&15)][4 s + (lane>>4)], are re-read from
+    // LDS at every generation (KA4 reads, no VALU) rather than held in 2 KA4 registers
+    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * KA + (lane >> 4)];
+
+    const int Npad = a.Npad;
+    const int nk8 = Npad >> 3;
+    const int npanel = (Npad + S2_PANEL - 1) / S2_PANEL;
+    const int rem = Npad % S2_PANEL;
+    const __amdgpu_buffer_rsrc_t rW = s2_rsrc(a.Wp, (size_t)Npad * Npad * sizeof(double));
+    const unsigned lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t rXA = s2_rsrc(a.XA, (size_t)(NA128 / 16) * KA4 * 64 * sizeof(double));
+    const unsigned lane8 = lane * 8;
+    const double *aY_quad = lds_alpha + (lane >> 4), *a1_quad = lds_alpha + NA128 + (lane >> 4);
+    // SIMD balance: a stage's eight partly active row-blocks (2, 4, .., 16 active steps) belong to eight
+    // consecutive waves; waves w and w+4 share a SIMD, so blocks k and 7-k of each group of eight go to waves
+    // that do -- every SIMD then carries the same MFMA count in every stage
+    const int pw = (wave & 8) | ((wave & 4) ? 11 - (wave & 7) : (wave & 7));
+
+    if (lane < 16) { lds_q[wave][lane] = 0.0; lds_q[wave][16 + lane] = 0.0; }
+
+    // the exponent GEMM's A-fragments of the tile this wave generates in stage t (rows 128 t + 16 rt ..)
+    auto load_xa = [&](int k0, double (&xa)[KA4]) {
+        const int tile = (k0 >> 4) + rt;
+#pragma unroll
+        for (int s = 0; s < KA4; s++) xa[s] = s2_ld_f64(rXA, lane8, (unsigned)((tile * KA4 + s) * 512));
+    };
+    // k* rows [k0 + 16 rt, +16) x candidates of block gcb -> stage buffer b
+    auto gen = [&](int k0, int b, const double (&xa)[KA4], double &muY, double &mu1, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int tile = (k0 >> 4) + rt;
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KA4; s++) y = mfma_f64(xa[s], cfrag[4 * s], y);
+        double *dst = &lds_k[b][(4 * rt * CBW + gcb) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double ay = 0.0, a1v = 0.0;
+            if (LAST) { ay = aY_quad[tile * 16 + 4 * r]; a1v = a1_quad[tile * 16 + 4 * r]; }
+            double kv;
+            if (FAM == FAM_SE) kv = s2_exp(y[r], lds_tab);
+            else {                                                  // z = |x~ - c~|^2 = -2y
+                const double z = fmax(-2.0 * y[r], 0.0);
+                const double rr = sqrt_fast((FAM == FAM_M3 ? 3.0 : 5.0) * z);
+                const double poly = FAM == FAM_M3 ? 1.0 + rr : fma(rr, fma(rr, 1.0 / 3.0, 1.0), 1.0);
+                kv = a.kp.sf2 * poly * s2_exp(-rr, lds_tab);
+            }
+            if (LAST) { muY = fma(ay, kv, muY); mu1 = fma(a1v, kv, mu1); }
+            dst[r * CBW * 64] = kv;
+            __builtin_amdgcn_sched_barrier(0);                     // one element at a time: keeps the temporaries few
+        }
+    };
+
+    auto run_panel = [&](int p, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int row0 = (rem == 0) ? p * S2_PANEL : (p == 0 ? 0 : rem + (p - 1) * S2_PANEL);
+        const int row1 = (rem == 0) ? row0 + S2_PANEL : (p == 0 ? rem : row0 + S2_PANEL);
+        const int nstage = (row1 + S2_KCH - 1) / S2_KCH;
+        // Row-blocks of this wave, ascending: g = row0/16 + pw + 16 e, e < ne (a short panel has fewer than RBW);
+        // row-block g has non-zeros in 8-column steps j < 2g + 2.  They sit in the LAST ne slots, so that the slots
+        // still active at any step are always a suffix (RBW-NA .. RBW-1) -- what the four fixed-shape loops below need.
+        const int nrb = (row1 - row0) >> 4;
+        const int ne = nrb > pw ? min(RBW, (nrb - pw + S2_NW - 1) / S2_NW) : 0;
+        int last8[RBW];
+        unsigned wbase[RBW];
+#pragma unroll
+        for (int i = 0; i < RBW; i++) {
+            const int e = i - (RBW - ne);
+            const int g = (row0 >> 4) + pw + S2_NW * (e < 0 ? 0 : e);
+            last8[i] = e >= 0 ? 2 * g + 2 : 0;
+            wbase[i] = (unsigned)g * (unsigned)nk8 * 1024u;        // bytes: fragment (g, j) sits at (g nk8 + j) * 1024
+        }
+        d4_t acc[RBW][CBW];
+#pragma unroll
+        for (int i = 0; i < RBW; i++)
+#pragma unroll
+            for (int cb = 0; cb < CBW; cb++) acc[i][cb] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        double muY = 0.0, mu1 = 0.0;      // partial means: candidate (gcb, lane&15), rows of this wave's tiles (LAST only)
+
+        double xa[KA4];
+        load_xa(0, xa);
+        gen(0, 0, xa, muY, mu1, last_tag);
+        __syncthreads();
+        for (int t = 0; t < nstage; t++) {
+            const int b = t & 1;
+            const int j0 = t * (S2_KCH / 8);
+            // steps of this stage in which row-block i is active: jj < n[i]; n[] ascends with i, all even
+            int n[RBW];
+#pragma unroll
+            for (int i = 0; i < RBW; i++) {
+                const int v = last8[i] - j0;
+                n[i] = __builtin_amdgcn_readfirstlane(v < 0 ? 0 : (v > S2_KCH / 8 ? S2_KCH / 8 : v));
+            }
+            v4u_t A0[RBW], A1[RBW];
+            // step 0's fragments of W and the next stage's fragments of X go out first; the next stage's k* is
+            // generated after the first (all row-blocks active) loop, when the latter have long arrived
+#pragma unroll
+            for (int i = 0; i < RBW; i++)
+                if (n[i] > 0) A0[i] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane16, wbase[i] + (unsigned)j0 * 1024u, 0);
+            const bool more = t + 1 < nstage;
+            constexpr bool XA_EARLY = KA4 <= 4;      // D = 15, 16: five fragment registers more would spill; fetch late
+            if (XA_EARLY && more) load_xa((t + 1) * S2_KCH, xa);
+            const double *kb = &lds_k[b][lane];
+            // Two 8-column steps with the NA largest row-blocks of the wave active (rows RBW-NA .. RBW-1), straight
+            // line: fragments of step jj+1 are fetched while step jj's MFMAs issue, those of step jj+2 during step
+            // jj+1.  The triangle only ever switches row-blocks OFF as jj grows, so the stage is four such loops.
+            auto pair = [&](int jj, auto na_tag) {
+                constexpr int NA = decltype(na_tag)::value;
+                const unsigned so = (unsigned)(j0 + jj) * 1024u;
+#pragma unroll
+                for (int i = RBW - NA; i < RBW; i++) A1[i] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane16, wbase[i] + so + 1024u, 0);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const double b0 = kb[((jj * 2 + h) * CBW + 0) * 64], b1 = kb[((jj * 2 + h) * CBW + 1) * 64];
+#pragma unroll
+                    for (int i = RBW - NA; i < RBW; i++) {
+                        const double av = h ? s2_hi(A0[i]) : s2_lo(A0[i]);
+                        acc[i][0] = mfma_f64(av, b0, acc[i][0]);
+                        acc[i][1] = mfma_f64(av, b1, acc[i][1]);
+                    }
+                }
+#pragma unroll
+                for (int i = RBW - NA; i < RBW; i++) A0[i] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane16, wbase[i] + so + 2048u, 0);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const double b0 = kb[((jj * 2 + 2 + h) * CBW + 0) * 64], b1 = kb[((jj * 2 + 2 + h) * CBW + 1) * 64];
+#pragma unroll
+                    for (int i = RBW - NA; i < RBW; i++) {
+                        const double av = h ? s2_hi(A1[i]) : s2_lo(A1[i]);
+                        acc[i][0] = mfma_f64(av, b0, acc[i][0]);
+                        acc[i][1] = mfma_f64(av, b1, acc[i][1]);
+                    }
+                }
+            };
+            int jj = 0;
+            for (; jj < n[0]; jj += 2) pair(jj, std::integral_constant<int, 4>{});
+            if (!XA_EARLY && more) load_xa((t + 1) * S2_KCH, xa);
+            if (more) gen((t + 1) * S2_KCH, b ^ 1, xa, muY, mu1, last_tag);
+            for (; jj < n[1]; jj += 2) pair(jj, std::integral_constant<int, 3>{});
+            for (; jj < n[2]; jj += 2) pair(jj, std::integral_constant<int, 2>{});
+            for (; jj < n[3]; jj += 2) pair(jj, std::integral_constant<int, 1>{});
+            __syncthreads();
+        }
+        // |V|^2 down the rows of this panel: acc[i][cb][r] is row 16 g_i + (lane>>4) + 4r, candidate 16 cb + (lane&15)
+#pragma unroll
+        for (int cb = 0; cb < CBW; cb++) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < RBW; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s = fma(acc[i][cb][r], acc[i][cb][r], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) lds_q[wave][cb * 16 + lane] += s;
+        }
+        if (LAST) {
+            muY += __shfl_xor(muY, 16); muY += __shfl_xor(muY, 32);
+            mu1 += __shfl_xor(mu1, 16); mu1 += __shfl_xor(mu1, 32);
+            if (lane < 16) { lds_m[0][wave][lane] = muY; lds_m[1][wave][lane] = mu1; }
+        }
+    };
+
+    // the last panel sees every k: it also forms the mean.  A short panel (N not a multiple of 1024) comes first.
+    for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
+    run_panel(npanel - 1, std::true_type{});
+    __syncthreads();
+    if (wave == 0) {
+        const int c = lane & (TCAND - 1);
+        double q = 0.0, my = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < S2_NW; w++) q += lds_q[w][c];
+#pragma unroll
+        for (int w = 0; w < S2_NW / 2; w++) { my += lds_m[0][2 * w + (c >> 4)][c & 15]; m1 += lds_m[1][2 * w + (c >> 4)][c & 15]; }
+        const int64_t li = tile0 + c;
+        const bool valid = lane < TCAND && li < a.M;
+        const int64_t gi = li < a.M ? li : a.M - 1;
+        bool excl;
+        double val = s2_finish(a, a.cand + gi * D, q, my, m1, li, valid, excl);
+        int64_t idx = a.index_base + li;
+        if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(val, o);
+            const int64_t oi = __shfl_xor(idx, o);
+            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+        if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+    }
+}
+
+// XA: the observations as A-fragments of the exponent GEMM.  Row k of the augmented matrix is
+// [x~_k (D), a_k, 1, 0...] (KA = 4 KA4 columns); fragment (tile, s) holds rows 16 tile + (lane&15), column
+// 4 s + (lane>>4) at XA[(tile KA4 + s) 64 + lane].  Rows >= N (padding up to a multiple of 128) are zero.
+__global__ void pack_xa_kernel(const double *__restrict__ Xs, const double *__restrict__ ak, int N, int DP, int D,
+                               int KA4, int ntile, double *__restrict__ XA)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ntile * KA4 * 64) return;
+    const int lane = e & 63, s = (e >> 6) % KA4, tile = (e >> 6) / KA4;
+    const int k = 16 * tile + (lane & 15), col = 4 * s + (lane >> 4);
+    double v = 0.0;
+    if (k < N) v = col < D ? Xs[(size_t)k * DP + col] : (col == D ? ak[k] : (col == D + 1 ? 1.0 : 0.0));
+    XA[e] = v;
+}
+
+int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, int D, double *XA, hipStream_t s)
+{
+    const int KA4 = (D + 2 + 3) / 4;
+    const int ntile = (Npad + 127) / 128 * 8;
+    const int total = ntile * KA4 * 64;
+    hipLaunchKernelGGL(pack_xa_kernel, dim3((total + 255) / 256), dim3(256), 0, s, Xs, ak, N, DP, D, KA4, ntile, XA);
+    return (int)hipGetLastError();
+}
+
+// dynamic LDS: the two alpha vectors (rows padded to 128); static: 64 KiB of k* stages + ~13 KiB
+#define S2_STATIC_LDS (80 * 1024)
+bool sweep2_fits(int Npad)
+{
+    return (size_t)((Npad + 127) & ~127) * 16 + S2_STATIC_LDS <= 160 * 1024;
+}
+
+template <int FAM, int KA4>
+static int launch_s2_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    const int dyn = ((a.Npad + 127) & ~127) * 16;
+    static int granted = 0;                          // per instantiation: largest dynamic size already allowed
+    if (dyn > granted) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep2_kernel<FAM, KA4>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        if (e != hipSuccess) return (int)e;
+        granted = dyn;
+    }
+    hipLaunchKernelGGL((sweep2_kernel<FAM, KA4>), dim3((unsigned)ntiles), dim3(S2_NW * 64), dyn, s, a);
+    return (int)hipGetLastError();
+}
+
+template <int FAM>
+static int launch_s2_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    switch ((a.kp.D + 2 + 3) / 4) {
+    case 1: return launch_s2_one<FAM, 1>(a, ntiles, s);
+    case 2: return launch_s2_one<FAM, 2>(a, ntiles, s);
+    case 3: return launch_s2_one<FAM, 3>(a, ntiles, s);
+    case 4: return launch_s2_one<FAM, 4>(a, ntiles, s);
+    default: return launch_s2_one<FAM, 5>(a, ntiles, s);
+    }
+}
+
+int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
+    int rc;
+    if (e0) (void)hipEventRecord(e0, s);
+    if (a.kp.family == FAM_SE) rc = launch_s2_fam<FAM_SE>(a, ntiles, s);
+    else if (a.kp.family == FAM_M3) rc = launch_s2_fam<FAM_M3>(a, ntiles, s);
+    else rc = launch_s2_fam<FAM_M5>(a, ntiles, s);
+    if (e1) (void)hipEventRecord(e1, s);
+    if (rc) return rc;
+    return launch_argmax_final(a, ntiles, s);
+}

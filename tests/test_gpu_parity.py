@@ -335,6 +335,49 @@ def test_c2_full_size_winner_against_the_oracle(ibo, oracle):
     close(r["best_val"], o["best_val"], atol=ACQ_ATOL)
 
 
+def test_sweep2_kernel_against_oracle_and_the_other_kernels(ibo, oracle):
+    """the large-batch kernel (sweep2.hip: 32-candidate tiles, exponent GEMM on the MFMA unit, table exp) on every
+    kernel family, D = 1..16 (all five widths of the exponent GEMM), one / short-first / several row panels:
+    per-candidate mu, s2, EI against the CPU oracle on a sample and against the independent GEMV kernel on all
+    candidates; same arg-max as the first-generation tile kernel"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.acquisition import sweep
+    cases = [(1024, 4, K.GaussianKernel_ard([.3] * 4), ("ard", [.3] * 4), 9000), (200, 3, K.GaussianKernel_iso([.4]), ("iso", [.4]), 8300),
+             (64, 1, K.GaussianKernel_iso([.4]), ("iso", [.4]), 8300), (1000, 6, K.MaternKernel3([.6, 1.0]), ("m3", [.6, 1.0]), 8300),
+             (2048, 8, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0]), 8300), (1500, 5, K.GaussianKernel_ard([.3] * 5), ("ard", [.3] * 5), 8300),
+             (700, 10, K.GaussianKernel_ard([.5] * 10), ("ard", [.5] * 10), 8300), (600, 13, K.MaternKernel5([1.0, 1.0]), ("m5", [1.0, 1.0]), 8300),
+             (1100, 16, K.GaussianKernel_ard([.9] * 16), ("ard", [.9] * 16), 8300)]
+    try:
+        for N, D, kern, (okind, ohyp), M in cases:
+            X, Y = synth(N + D, N, D)
+            GP = GaussianProcess(kern, X, Y, noise=.1)
+            cand = np.random.RandomState(N).rand(M, D)
+            cand[77] = X[5]                                          # a candidate on top of an observation
+            cand[M - 1] = cand[0]                                    # ragged last tile (M % 32 != 0) with a duplicate
+            _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 4))
+            r = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            assert r["kernel"] == "sweep2_kernel"
+            _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 2))
+            r1 = sweep(GP, cand, acq='ei', xi=.01, native=True)
+            assert r1["kernel"] == "sweep_mfma_kernel" and r1["best_idx"] == r["best_idx"]
+            _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 1))
+            rg = sweep(GP, cand[:600], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 0))
+            assert rg["kernel"] == "sweep_gemv_kernel"
+            close(r["mu"][:600], rg["mu"], rtol=1e-9, atol=1e-10); close(r["s2"][:600], rg["s2"], rtol=1e-9)
+            close(r["acq"][:600], rg["acq"], atol=ACQ_ATOL)
+            ogp = oracle.GP(oracle.Kern(okind, ohyp), X, Y, noise=.1)
+            idx = np.r_[np.arange(0, M, M // 40), 77, M - 1, r["best_idx"]]
+            o = oracle.sweep_native(ogp, cand[idx], oracle.ACQ_EI, .01)
+            close(r["mu"][idx], o["mu"], atol=1e-9); close(r["s2"][idx], o["s2"]); close(r["acq"][idx], o["acq"], atol=ACQ_ATOL)
+            assert r["best_idx"] == int(np.argmax(r["acq"])) and r["s2"][77] < 1 / 1.1
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 4))
+        _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 0))
+
+
 def test_sweep_index_base_beyond_32_bits(ibo):
     """global indices of a shard far into a huge candidate set: index_base > 2^31 (and > 2^32) is carried in
     64 bits through the kernel's partials, the final reduction and the ABI"""
