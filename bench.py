@@ -214,7 +214,7 @@ def pmc_numbers():
     same command (tools/profile_bench.sh).  A summary is used only when it was taken from THIS build of the
     sweep kernel: its `source_sha` must equal the hash of the kernel sources in the tree."""
     h = hashlib.sha256()
-    for f in ("ibo_amd/csrc/sweep.hip", "ibo_amd/csrc/ibo_common.h"):
+    for f in ("ibo_amd/csrc/sweep2.hip", "ibo_amd/csrc/sweep.hip", "ibo_amd/csrc/ibo_common.h"):
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
     sha = h.hexdigest()[:16]
@@ -321,11 +321,11 @@ def worker(args):
     def c3_step(GP, cand, host, start):
         if comm is None:
             r = sweep(GP, cand, acq='ei', xi=.01, native=True, index_base=start)
-            return r["best_val"], r["best_idx"], r["kernel_ms"]
+            return r["best_val"], r["best_idx"], r["kernel_ms"], r["kernel"]
         r = sweep(GP, cand, acq='ei', xi=.01, native=True, index_base=start)
         x = host[r["best_idx"] - start] if r["best_idx"] >= 0 else np.zeros(C3_D)
         v, i, _, _ = comm.argmax(r["best_val"], r["best_idx"], x)
-        return v, i, r["kernel_ms"]
+        return v, i, r["kernel_ms"], r["kernel"]
 
     # ---------------------------------------------------------------- C5: sharded NLML grid
     def c5_setup():
@@ -355,7 +355,7 @@ def worker(args):
                            "n_obs": C3_N, "dim": C3_D, "candidates_total": C3_M_TOTAL,
                            "parallelism": "candidate-sharded x%d, replicated GP, 1 RCCL arg-max exchange/step" % world},
                 "best": {"value": outs[-1][0], "index": int(outs[-1][1])},
-                "roofline": roofline_mfma(f_eval(C3_N, C3_D) * float(len(host)), kmean, kernel="sweep_mfma_kernel",
+                "roofline": roofline_mfma(f_eval(C3_N, C3_D) * float(len(host)), kmean, kernel=outs[-1][3],
                                           kernel_ms=kmean * 1e3, flops_per_eval=f_eval(C3_N, C3_D),
                                           evals_per_launch=len(host)),
             })
@@ -398,8 +398,8 @@ def worker(args):
             if comm is not None:
                 x = cand_host[r["best_idx"] - start]
                 v, i, _, _ = comm.argmax(r["best_val"], r["best_idx"], x)
-                return v, i, r["kernel_ms"]
-            return r["best_val"], r["best_idx"], r["kernel_ms"]
+                return v, i, r["kernel_ms"], r["kernel"]
+            return r["best_val"], r["best_idx"], r["kernel_ms"], r["kernel"]
 
         elapsed, outs = timed(step, args.steps, args.warmup)
         if rank == 0:
@@ -418,7 +418,7 @@ def worker(args):
                 "gp_fit_ms": {"host_to_ready_median": float(np.median(fit_ms)), "device_events": fit_dev_ms,
                               "N": N_OBS, "D": DIM},
                 "best": {"value": outs[-1][0], "index": int(outs[-1][1])},
-                "roofline": roofline_mfma(fe * float(M_PER_GPU), kmean, kernel="sweep_mfma_kernel", kernel_ms=kmean * 1e3,
+                "roofline": roofline_mfma(fe * float(M_PER_GPU), kmean, kernel=outs[-1][3], kernel_ms=kmean * 1e3,
                                           flops_per_eval=fe, evals_per_launch=M_PER_GPU),
             })
             j, src, sha = pmc_numbers()
@@ -475,7 +475,7 @@ def worker(args):
                     "workload": "N=2048, D=8, Matern-5/2, EI over 2^19 candidates per GPU (x%d), 5 steps" % world,
                     "value": float(C3_SHARD * world) * 5 / el3, "unit": "EI evals/s", "ms_per_step": el3 / 5 * 1e3,
                     "gp_fit_device_ms": GP3.last_fit_ms(),
-                    "roofline": roofline_mfma(f_eval(C3_N, C3_D) * float(C3_SHARD), k3, kernel="sweep_mfma_kernel",
+                    "roofline": roofline_mfma(f_eval(C3_N, C3_D) * float(C3_SHARD), k3, kernel=o3[-1][3],
                                               kernel_ms=k3 * 1e3, flops_per_eval=f_eval(C3_N, C3_D),
                                               evals_per_launch=C3_SHARD)}
                 cfgs["c3_gallery8"] = {"workload": "fastUCBGallery(N=8) on the same GP and shard(s): 7 rounds of DIRECT + "

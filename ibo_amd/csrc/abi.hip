@@ -746,6 +746,8 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         g->sweep_kernel = "sweep_gemv_kernel";
     } else if (a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad)) {
         IBO_TRY(exp_table(g->device, &a.exp_tab));
+        IBO_TRY(g->qpart.ensure(3 * (size_t)M));        // (q, aY.k*, a1.k*) per candidate, finished by acq_finish_kernel
+        a.qpart = g->qpart.p;
         KERNEL_TRY(launch_sweep2(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep2_kernel";
     } else {

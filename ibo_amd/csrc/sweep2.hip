@@ -50,32 +50,26 @@ __device__ __forceinline__ double s2_ld_f64(__amdgpu_buffer_rsrc_t r, unsigned v
 __device__ __forceinline__ double s2_lo(const v4u_t &v) { return __hiloint2double((int)v.y, (int)v.x); }
 __device__ __forceinline__ double s2_hi(const v4u_t &v) { return __hiloint2double((int)v.w, (int)v.z); }
 
-// exp(y) for the k* generation in 13 VALU instructions (exp_fast in ibo_common.h takes 17, the library ~30): every
+// exp(y) for the k* generation in 11 VALU instructions (exp_fast in ibo_common.h takes 17, the library ~30): every
 // VALU instruction here is paid in MFMA issue slots.  A 2048-entry table of 2^(j/2048) in LDS (reads are not VALU
 // instructions) shortens the polynomial to degree 3:
-//   t = y 2048/ln2 + 1.5 2^52 puts n = rint(y 2048/ln2) in the low mantissa bits of t; r = y - n ln2/2048
-//   (two-term Cody-Waite, |r| <= 1.7e-4: r^4/24 < 4e-17); j = n mod 2048 indexes the table, n div 2048 goes into
-//   the exponent field by an integer add.  Relative error < 4e-16.  y is clamped at -708 by exactly one v_max_f64
-//   (fmax() on a value the compiler cannot prove quiet costs a second, canonicalising one; an MFMA result is
-//   never a signalling NaN); valid up to y = 709.
+//   t = y 2048/ln2 + 1.5 2^52 puts n = rint(y 2048/ln2) in the low mantissa bits of t; r = y - n ln2/2048, |r| <=
+//   1.7e-4 (r^4/24 < 4e-17); j = n mod 2048 indexes the table and v_ldexp_f64 applies n div 2048, flushing to zero
+//   what underflows.  One FMA forms r: the rounding of ln2/2048 costs |n| 2.7e-20 relative -- 2.4e-15 at y = -30
+//   where k* is already 1e-13, 5.6e-14 at the underflow threshold.  Relative error < 5e-16 for |y| < 10.
+//   Needs |y| < 7e5 (n must fit 32 bits): the kernel's prologue bounds the scaled candidates so that it holds.
 __device__ __forceinline__ double s2_exp(double y, const double *tab)
 {
-    double yc;
-    const double lo = -708.0;
-    asm("v_max_f64 %0, %1, %2" : "=v"(yc) : "v"(y), "s"(lo));
     const double magic = 6755399441055744.0;               // 1.5 * 2^52
-    const double t = fma(yc, 2954.6394437405970584, magic);            // 2048 / ln 2
+    const double t = fma(y, 2954.6394437405970584, magic);              // 2048 / ln 2
     const double n = t - magic;
-    double r = fma(n, -3.3845077166461124e-04, yc);                    // ln2/2048, upper bits (21 trailing zeros)
-    r = fma(n, -9.317455709329042e-14, r);                              // ... and the remainder
+    const double r = fma(n, -3.384507717577858e-04, y);                 // ln2 / 2048
     const int ti = __double2loint(t);
     const double T = *(const double *)((const char *)tab + ((ti << 3) & (2047 << 3)));
     double p = fma(r, 1.0 / 6.0, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double v = T * p;
-    const int hi = __double2hiint(v) + ((ti & ~2047) << 9);             // (n div 2048) << 20
-    return __hiloint2double(hi, __double2loint(v));
+    return __builtin_amdgcn_ldexp(T * p, ti >> 11);
 }
 
 // acquisition epilogue of one candidate; coordinates are read from global memory where needed (prior,
@@ -150,6 +144,14 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     if (tid < TCAND) {
         double n2 = 0.0;
         for (int d = 0; d < D; d++) { const double v = lds_c[tid * KA + d]; n2 = fma(v, v, n2); }
+        // A candidate more than 775 length scales from the origin (hence > 450 from every observation: |x~| <= 316
+        // where the dot form is in use) has k* = 0 exactly; it is pulled in to that radius, where k* is still 0, so
+        // that the exponent stays within what s2_exp's integer arithmetic covers (|y| < 7e5).
+        if (n2 > 6e5) {
+            const double sc = sqrt(6e5 / n2);
+            for (int d = 0; d < D; d++) lds_c[tid * KA + d] *= sc;
+            n2 = 6e5;
+        }
         lds_c[tid * KA + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
     }
     __syncthreads();
@@ -236,38 +238,40 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
         double xa[KA4];
         load_xa(0, xa);
         gen(0, 0, xa, muY, mu1, last_tag);
+        // fragments of the first stage's first step
+        v4u_t A0[RBW], A1[RBW];
+#pragma unroll
+        for (int i = 0; i < RBW; i++) A0[i] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane16, wbase[i], 0);
         __syncthreads();
         for (int t = 0; t < nstage; t++) {
-            const int b = t & 1;
             const int j0 = t * (S2_KCH / 8);
             // steps of this stage in which row-block i is active: jj < n[i]; n[] ascends with i, all even
             int n[RBW];
 #pragma unroll
             for (int i = 0; i < RBW; i++) {
-                const int v = last8[i] - j0;
-                n[i] = __builtin_amdgcn_readfirstlane(v < 0 ? 0 : (v > S2_KCH / 8 ? S2_KCH / 8 : v));
+                int v = last8[i] - j0;
+                v = v < 0 ? 0 : v;
+                n[i] = v > S2_KCH / 8 ? S2_KCH / 8 : v;
             }
-            v4u_t A0[RBW], A1[RBW];
-            // step 0's fragments of W and the next stage's fragments of X go out first; the next stage's k* is
-            // generated after the first (all row-blocks active) loop, when the latter have long arrived
-#pragma unroll
-            for (int i = 0; i < RBW; i++)
-                if (n[i] > 0) A0[i] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane16, wbase[i] + (unsigned)j0 * 1024u, 0);
             const bool more = t + 1 < nstage;
             constexpr bool XA_EARLY = KA4 <= 4;      // D = 15, 16: five fragment registers more would spill; fetch late
+            // the next stage's fragments of X go out first; its k* is generated after the first (all row-blocks
+            // active) range of steps, when they have long arrived
             if (XA_EARLY && more) load_xa((t + 1) * S2_KCH, xa);
-            const double *kb = &lds_k[b][lane];
-            // Two 8-column steps with the NA largest row-blocks of the wave active (rows RBW-NA .. RBW-1), straight
-            // line: fragments of step jj+1 are fetched while step jj's MFMAs issue, those of step jj+2 during step
-            // jj+1.  The triangle only ever switches row-blocks OFF as jj grows, so the stage is four such loops.
-            auto pair = [&](int jj, auto na_tag) {
-                constexpr int NA = decltype(na_tag)::value;
-                const unsigned so = (unsigned)(j0 + jj) * 1024u;
+            const double *kb = &lds_k[t & 1][lane];
+            // Two 8-column steps (jj, jj+1; jj a compile-time constant, so every LDS offset is an immediate) with
+            // the NA largest row-blocks of the wave active (slots RBW-NA .. RBW-1), straight line: fragments of
+            // step jj+1 are fetched while step jj's MFMAs issue, those of step jj+2 -- the next pair's, or the next
+            // stage's first -- during step jj+1.  A fetch past a row-block's last step is harmless (zeros of the
+            // upper triangle, or zeros from the buffer's bounds check) and happens once per range.
+            auto pair = [&](auto jj_tag, auto na_tag) {
+                constexpr int JJ = decltype(jj_tag)::value, NA = decltype(na_tag)::value;
+                const unsigned so = (unsigned)(j0 + JJ) * 1024u;
 #pragma unroll
                 for (int i = RBW - NA; i < RBW; i++) A1[i] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane16, wbase[i] + so + 1024u, 0);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const double b0 = kb[((jj * 2 + h) * CBW + 0) * 64], b1 = kb[((jj * 2 + h) * CBW + 1) * 64];
+                    const double b0 = kb[((JJ * 2 + h) * CBW + 0) * 64], b1 = kb[((JJ * 2 + h) * CBW + 1) * 64];
 #pragma unroll
                     for (int i = RBW - NA; i < RBW; i++) {
                         const double av = h ? s2_hi(A0[i]) : s2_lo(A0[i]);
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
                 for (int i = RBW - NA; i < RBW; i++) A0[i] = __builtin_amdgcn_raw_buffer_load_b128(rW, lane16, wbase[i] + so + 2048u, 0);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const double b0 = kb[((jj * 2 + 2 + h) * CBW + 0) * 64], b1 = kb[((jj * 2 + 2 + h) * CBW + 1) * 64];
+                    const double b0 = kb[((JJ * 2 + 2 + h) * CBW + 0) * 64], b1 = kb[((JJ * 2 + 2 + h) * CBW + 1) * 64];
 #pragma unroll
                     for (int i = RBW - NA; i < RBW; i++) {
                         const double av = h ? s2_hi(A1[i]) : s2_lo(A1[i]);
@@ -288,13 +292,25 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
                     }
                 }
             };
-            int jj = 0;
-            for (; jj < n[0]; jj += 2) pair(jj, std::integral_constant<int, 4>{});
+            // steps [lo, hi) with NA row-blocks active: eight guarded copies of the pair, entered and left by
+            // scalar branches -- no vector instruction is spent on loop control or addresses
+            auto range = [&](int lo, int hi, auto na_tag) {
+                if (lo >= hi) return;
+                if (0 >= lo && 0 < hi) pair(std::integral_constant<int, 0>{}, na_tag);
+                if (2 >= lo && 2 < hi) pair(std::integral_constant<int, 2>{}, na_tag);
+                if (4 >= lo && 4 < hi) pair(std::integral_constant<int, 4>{}, na_tag);
+                if (6 >= lo && 6 < hi) pair(std::integral_constant<int, 6>{}, na_tag);
+                if (8 >= lo && 8 < hi) pair(std::integral_constant<int, 8>{}, na_tag);
+                if (10 >= lo && 10 < hi) pair(std::integral_constant<int, 10>{}, na_tag);
+                if (12 >= lo && 12 < hi) pair(std::integral_constant<int, 12>{}, na_tag);
+                if (14 >= lo && 14 < hi) pair(std::integral_constant<int, 14>{}, na_tag);
+            };
+            range(0, n[0], std::integral_constant<int, 4>{});
             if (!XA_EARLY && more) load_xa((t + 1) * S2_KCH, xa);
-            if (more) gen((t + 1) * S2_KCH, b ^ 1, xa, muY, mu1, last_tag);
-            for (; jj < n[1]; jj += 2) pair(jj, std::integral_constant<int, 3>{});
-            for (; jj < n[2]; jj += 2) pair(jj, std::integral_constant<int, 2>{});
-            for (; jj < n[3]; jj += 2) pair(jj, std::integral_constant<int, 1>{});
+            if (more) gen((t + 1) * S2_KCH, (t + 1) & 1, xa, muY, mu1, last_tag);
+            range(n[0], n[1], std::integral_constant<int, 3>{});
+            range(n[1], n[2], std::integral_constant<int, 2>{});
+            range(n[2], n[3], std::integral_constant<int, 1>{});
             __syncthreads();
         }
         // |V|^2 down the rows of this panel: acc[i][cb][r] is row 16 g_i + (lane>>4) + 4r, candidate 16 cb + (lane&15)
@@ -320,26 +336,45 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
     run_panel(npanel - 1, std::true_type{});
     __syncthreads();
-    if (wave == 0) {
-        const int c = lane & (TCAND - 1);
+    // hand (q, aY.k*, a1.k*) of every candidate to acq_finish_kernel: the acquisition's erf/exp/sqrt chain on one
+    // wave would keep the other fifteen (and the MFMA pipe) waiting at the end of every tile
+    if (tid < TCAND) {
+        const int c = tid;
         double q = 0.0, my = 0.0, m1 = 0.0;
 #pragma unroll
         for (int w = 0; w < S2_NW; w++) q += lds_q[w][c];
 #pragma unroll
         for (int w = 0; w < S2_NW / 2; w++) { my += lds_m[0][2 * w + (c >> 4)][c & 15]; m1 += lds_m[1][2 * w + (c >> 4)][c & 15]; }
         const int64_t li = tile0 + c;
-        const bool valid = lane < TCAND && li < a.M;
-        const int64_t gi = li < a.M ? li : a.M - 1;
-        bool excl;
-        double val = s2_finish(a, a.cand + gi * D, q, my, m1, li, valid, excl);
-        int64_t idx = a.index_base + li;
-        if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(val, o);
-            const int64_t oi = __shfl_xor(idx, o);
-            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
-        }
-        if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+        if (li < a.M) { a.qpart[li] = q; a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1; }
+    }
+}
+
+// second half of the sweep: mean prior, variance clamp, EI / PI / UCB, optional per-candidate outputs, exclusion
+// balls, and a (max value, lowest index) partial per 256 candidates -- all from sweep2_kernel's three numbers per
+// candidate.  Summation order and formulas are those of s2_finish (shared with sweep.hip's epilogue).
+__global__ __launch_bounds__(256) void acq_finish_kernel(SweepArgs a)
+{
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
+    const int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = li < a.M;
+    const int64_t gi = valid ? li : a.M - 1;
+    bool excl;
+    double val = s2_finish(a, a.cand + gi * a.kp.D, a.qpart[gi], a.qpart[a.M + gi], a.qpart[2 * a.M + gi], li, valid, excl);
+    int64_t idx = a.index_base + li;
+    if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(val, o);
+        const int64_t oi = __shfl_xor(idx, o);
+        if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = val; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (sv[w] > val || (sv[w] == val && si[w] < idx)) { val = sv[w]; idx = si[w]; }
+        a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx;
     }
 }
 
@@ -410,5 +445,9 @@ int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e
     else rc = launch_s2_fam<FAM_M5>(a, ntiles, s);
     if (e1) (void)hipEventRecord(e1, s);
     if (rc) return rc;
-    return launch_argmax_final(a, ntiles, s);
+    const int64_t nfin = (a.M + 255) / 256;
+    hipLaunchKernelGGL(acq_finish_kernel, dim3((unsigned)nfin), dim3(256), 0, s, a);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return launch_argmax_final(a, nfin, s);
 }

@@ -18,11 +18,19 @@ def newest(pattern):
 st = newest(os.path.join(out, "trace", "*", "*_kernel_stats.csv"))
 if st:
     shutil.copy(st[0], "profiles/%s_bench_kernel_stats.csv" % tag)
-res = {"kernel": "sweep_mfma_kernel", "source": "rocprofv3 --pmc, python3 bench.py --steps 3 --warmup 1", "counters": {}}
+import hashlib
+def _is_sweep(name):
+    return "sweep2_kernel" in name or "sweep_mfma" in name
+h = hashlib.sha256()
+for f in ("ibo_amd/csrc/sweep2.hip", "ibo_amd/csrc/sweep.hip", "ibo_amd/csrc/ibo_common.h"):     # the same list as bench.py:pmc_numbers
+    h.update(open(f, "rb").read())
+res = {"kernel": None, "source": "rocprofv3 --pmc, python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras", "counters": {},
+       "source_sha": h.hexdigest()[:16]}
 for f in newest(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "sweep_mfma" in r["Kernel_Name"]:
+        if _is_sweep(r["Kernel_Name"]):
+            res["kernel"] = r["Kernel_Name"].split("(")[0]
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             res["vgpr"] = r.get("VGPR_Count"); res["lds"] = r.get("LDS_Block_Size"); res["wg"] = r.get("Workgroup_Size")
     for k, v in acc.items():
@@ -38,7 +46,7 @@ if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c:
     res["mfma_f64_flops_per_launch"] = c["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
 tr = newest(os.path.join(out, "trace", "*", "*_kernel_trace.csv"))
 if tr:
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr[0])) if "sweep_mfma" in r["Kernel_Name"]]
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr[0])) if _is_sweep(r["Kernel_Name"])]
     res["kernel_trace_mean_ms"] = sum(d) / len(d) / 1e6
     res["kernel_trace_launches"] = len(d)
 for l in open(os.path.join(out, "bench_trace.log")):
