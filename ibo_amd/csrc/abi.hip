@@ -166,10 +166,12 @@ struct ibo_gp {
     bool fitted = false;
     int N = 0, D = 0, Npad = 0, DP = 0;
     bool reversed = false;          // legacy invR path stores the observations in reverse order
+    bool plain_fit = false;         // L = chol(R) of the model's own kernel matrix: ibo_gp_extend may append rows
     bool L_upper_dirty = false;     // zero_upper is deferred to ibo_gp_get_L
     int dot_form = 1;               // SE k* via a_k + b_c + x~.c~; off when |x~|^2 is so large that the
                                     // cancellation would cost more than 1e-10 (pathological length scales)
     KParams kp;
+    KParams kp_fit;                 // kp as fitted (kp.sf2 is overridden per sweep by ibo_gp_set_kstar_sf2)
     double noise = 0.0, maxY = 0.0;
     float fit_ms = 0.f, sweep_ms = 0.f;
     const char *sweep_kernel = "";
@@ -368,13 +370,13 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
     IBO_TRY(g->Xp.ensure((size_t)Np * DP)); IBO_TRY(g->Xs.ensure((size_t)Np * DP)); IBO_TRY(g->ak.ensure(Np));
     IBO_TRY(g->XA.ensure((size_t)((Np + 127) / 128 * 8) * ((D + 5) / 4) * 64));
     IBO_TRY(g->Y.ensure(Np));
-    IBO_TRY(g->R.ensure((size_t)N * N)); IBO_TRY(g->L.ensure(nn)); IBO_TRY(g->W.ensure(nn));
+    IBO_TRY(g->R.ensure(nn)); IBO_TRY(g->L.ensure(nn)); IBO_TRY(g->W.ensure(nn));     // R: N x N with row stride Npad (room to extend)
     IBO_TRY(g->T.ensure(nn)); IBO_TRY(g->Wp.ensure(nn)); IBO_TRY(g->diag64.ensure((size_t)(Np / 64) * 4096));
     // sweep2's stages cover rows up to the next multiple of 128: the tail of both alpha vectors stays zero
     IBO_TRY(g->alphaY.ensure((size_t)Np + 128)); IBO_TRY(g->alpha1.ensure((size_t)Np + 128));
     HIP_TRY(hipMemsetAsync(g->alphaY.p + Np, 0, 128 * sizeof(double), g->stream));
     HIP_TRY(hipMemsetAsync(g->alpha1.p + Np, 0, 128 * sizeof(double), g->stream));
-    IBO_TRY(g->tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));
+    IBO_TRY(g->tmp.ensure(3 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));     // launch_alpha's scratch + one vector (ibo_gp_extend)
     IBO_TRY(g->info.ensure(1));
     std::vector<double> xp((size_t)Np * DP, 0.0), yp(Np, 0.0);
     g->Yhost.assign(N, 0.0);
@@ -415,7 +417,7 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
     g->fitted = false;
     IBO_TRY(stage_data(g, N, D, X, Y, false));
-    g->kp = kp; g->noise = noise;
+    g->kp = kp; g->kp_fit = kp; g->noise = noise;
     const int Np = g->Npad;
     hipStream_t s = g->stream;
     KERNEL_TRY(launch_scale_x(kp, g->Xp.p, Np, g->DP, g->Xs.p, g->ak.p, s));
@@ -429,7 +431,7 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     // R, and in the same pass the identity-padded copy the factorisation works on
     const bool fused = Np / 64 <= 32 && g_chol_fused;
     double *work = fused ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
-    KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, N, s,
+    KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, Np, s,
                                  A_host ? nullptr : work, Np));
     if (A_host) KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
     if (fused) {
@@ -446,6 +448,67 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     IBO_TRY(check_info(g, info));
     HIP_TRY(hipEventElapsedTime(&g->fit_ms, g->fit0, g->fit1));
     g->fitted = true;
+    g->plain_fit = (A_host == nullptr);
+    return IBO_OK;
+}
+
+// Append observations to a fitted model without refactoring: the block extension of
+// GaussianProcess.addData (ego/gaussianprocess/__init__.py:301-308), z = L^-1 m, d = chol(r - z^T z), one
+// point at a time.  With W = L^-1 already on the device, z = W k and the new row of W is -(W^T z)/d: two
+// triangular matrix-vector products (the same kernels that form alpha), O(N^2) instead of the O(N^3) refit.
+extern "C" int ibo_gp_extend(ibo_gp_t *g, int n, const double *Xnew, const double *Yall, int *info)
+{
+    if (!g || !Xnew || !Yall || n < 1) return fail(IBO_ERR_ARG, "bad argument");
+    if (!g->fitted || !g->plain_fit || g->reversed) return fail(IBO_ERR_STATE, "model cannot be extended in place");
+    if (g->N + n > g->Npad) return fail(IBO_ERR_STATE, "no room in the current padding (%d + %d > %d)", g->N, n, g->Npad);
+    IBO_TRY(use_device(g->device));
+    hipStream_t s = g->stream;
+    const int Np = g->Npad, DP = g->DP, D = g->D, N0 = g->N;
+    if (info) *info = 0;
+    // stage the new rows of X (padded to DP) behind the old ones; sizes do not change
+    std::vector<double> xp((size_t)n * DP, 0.0);
+    for (int i = 0; i < n; i++)
+        for (int d = 0; d < D; d++) xp[(size_t)i * DP + d] = Xnew[(size_t)i * D + d];
+    HIP_TRY(hipMemcpyAsync(g->Xp.p + (size_t)N0 * DP, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(g->info.p, 0, sizeof(int), s));
+    HIP_TRY(hipEventRecord(g->fit0, s));
+    for (int i = 0; i < n; i++) {
+        const int N = N0 + i;                       // rows present before this point
+        // k = K(X, x_new) (also the new row / column of R), z = W k and u = W^T z, then the new rows of L and W
+        KERNEL_TRY(launch_extend_kvec(g->kp_fit, g->Xp.p, DP, N, Np, g->noise, g->R.p, g->tmp.p + 2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np, s));
+        double *kvec = g->tmp.p + 2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np;
+        KERNEL_TRY(launch_alpha(g->W.p, N, Np, kvec, g->tmp.p, g->T.p, g->T.p + Np, s));      // t2[0..Np) = z, T[0..Np) = W^T z
+        KERNEL_TRY(launch_extend_rows(N, Np, g->noise, g->tmp.p, g->T.p, g->L.p, g->W.p, g->Wp.p, g->info.p, s));
+    }
+    const int N1 = N0 + n;
+    std::vector<double> yp(Np, 0.0);
+    double my = Yall[0];
+    for (int i = 0; i < N1; i++) { yp[i] = Yall[i]; if (Yall[i] > my) my = Yall[i]; }
+    HIP_TRY(hipMemcpyAsync(g->Y.p, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    KERNEL_TRY(launch_scale_x(g->kp_fit, g->Xp.p, Np, DP, g->Xs.p, g->ak.p, s));
+    KERNEL_TRY(launch_pack_xa(g->Xs.p, g->ak.p, N1, Np, DP, D, g->XA.p, s));
+    KERNEL_TRY(launch_alpha(g->W.p, N1, Np, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, s));
+    HIP_TRY(hipEventRecord(g->fit1, s));
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, g->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));               // also: xp / yp go out of scope
+    if (h != 0) {
+        // the rows written so far belong to a matrix that is not positive definite: the handle needs a refit
+        g->fitted = false;
+        if (info) *info = h;
+        return fail(IBO_ERR_NOT_PD, "matrix is not positive definite (pivot %d)", h);
+    }
+    HIP_TRY(hipEventElapsedTime(&g->fit_ms, g->fit0, g->fit1));
+    if (g->dot_form) {                              // |x~|^2 of the new points still admits the dot form?
+        for (int i = 0; i < n && g->dot_form; i++) {
+            double n2 = 0.0;
+            for (int d = 0; d < D; d++) { const double v = Xnew[(size_t)i * D + d] * g->kp_fit.sw[d]; n2 += v * v; }
+            if (n2 > 1e5) g->dot_form = 0;
+        }
+    }
+    g->N = N1; g->maxY = my;
+    g->Yhost.assign(Yall, Yall + N1);
+    g->L_upper_dirty = true;
     return IBO_OK;
 }
 
@@ -551,7 +614,7 @@ extern "C" int ibo_gp_get_R(ibo_gp_t *g, double *R_host)
 {
     if (!g || !R_host) return fail(IBO_ERR_ARG, "NULL argument");
     if (!g->fitted || g->reversed) return fail(IBO_ERR_STATE, "R not available");
-    return copy_square(g, g->R.p, g->N, R_host);
+    return copy_square(g, g->R.p, g->Npad, R_host);
 }
 extern "C" int ibo_gp_get_L(ibo_gp_t *g, double *L_host)
 {

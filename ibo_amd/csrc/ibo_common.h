@@ -226,6 +226,12 @@ int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double
 int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s);
 int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double *X, int ldx, const double *Kinv, int ldk,
                      const double *alpha, double *partial, double *out, hipStream_t s);
+// one-point block extension (ibo_gp_extend): kvec[i] = k(x_i, x_N) for i < N (zero beyond) and row / column N of R
+int launch_extend_kvec(const KParams &kp, const double *Xp, int ldp, int N, int Npad, double noise, double *R, double *kvec,
+                       hipStream_t s);
+// d = sqrt(1 + noise - |z|^2); L[N][:N] = z, L[N][N] = d; W[N][:N] = -u/d, W[N][N] = 1/d; row-block N/16 of Wp repacked
+int launch_extend_rows(int N, int Npad, double noise, const double *z, const double *u, double *L, double *W, double *Wp,
+                       int *info, hipStream_t s);
 int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s);
 int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);

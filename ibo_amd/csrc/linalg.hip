@@ -995,6 +995,76 @@ int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2
 }
 
 // ------------------------------------------------------------------------
+// One-point block extension of a fitted model (ibo_gp_extend; ego/gaussianprocess/__init__.py:301-308)
+// ------------------------------------------------------------------------
+// the new point is row N of Xp.  R's entries come out of the same expression, in the same order, as
+// cov_matrix_kernel's, so an extended R equals a rebuilt one bit for bit.
+__global__ __launch_bounds__(256) void extend_kvec_kernel(KParams kp, const double *__restrict__ Xp, int ldp, int N, int Npad,
+                                                          double noise, double *__restrict__ R, double *__restrict__ kvec)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    double v = 0.0;
+    if (i < N) {
+        double z = 0.0;
+        for (int d = 0; d < kp.D; d++) {
+            const double u = Xp[(size_t)i * ldp + d] - Xp[(size_t)N * ldp + d];
+            z += kp.w[d] * (u * u);
+        }
+        v = cov_from_z_rt(kp.family, z, kp.sf2);
+        R[(size_t)N * Npad + i] = v;
+        R[(size_t)i * Npad + N] = v;
+    } else if (i == N) R[(size_t)N * Npad + N] = 1.0 + noise;
+    kvec[i] = v;
+}
+
+int launch_extend_kvec(const KParams &kp, const double *Xp, int ldp, int N, int Npad, double noise, double *R, double *kvec,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(extend_kvec_kernel, dim3((Npad + 255) / 256), dim3(256), 0, s, kp, Xp, ldp, N, Npad, noise, R, kvec);
+    return (int)hipGetLastError();
+}
+
+// one workgroup: the pivot (fixed-order reduction of |z|^2), then the new rows of L and W and the row-block of
+// W's fragment copy that contains row N
+__global__ __launch_bounds__(1024) void extend_rows_kernel(int N, int Npad, double noise, const double *__restrict__ z,
+                                                           const double *__restrict__ u, double *__restrict__ L,
+                                                           double *__restrict__ W, double *__restrict__ Wp, int *info)
+{
+    __shared__ double red[1024];
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int k = t; k < N; k += 1024) s = fma(z[k], z[k], s);
+    red[t] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const double d2 = (1.0 + noise) - red[0];
+    if (!(d2 > 0.0)) { if (t == 0) atomicCAS(info, 0, N + 1); return; }
+    const double d = sqrt(d2), id = 1.0 / d;
+    for (int k = t; k < N; k += 1024) {
+        L[(size_t)N * Npad + k] = z[k];
+        W[(size_t)N * Npad + k] = -u[k] * id;
+    }
+    if (t == 0) { L[(size_t)N * Npad + N] = d; W[(size_t)N * Npad + N] = id; }
+    // fragment copy of row-block N/16: its earlier rows come from W (written by earlier launches), row N from u
+    const int g = N >> 4, nk8 = Npad >> 3;
+    for (int e = t; e < nk8 * 128; e += 1024) {
+        const int h = e & 1, lane = (e >> 1) & 63, j = e >> 7;
+        const int row = 16 * g + (lane & 15), col = 8 * j + 4 * h + (lane >> 4);
+        double v = 0.0;
+        if (row <= N && col <= row) v = (row == N) ? (col == N ? id : -u[col] * id) : W[(size_t)row * Npad + col];
+        Wp[((size_t)g * nk8 + j) * 128 + e % 128] = v;
+    }
+}
+
+int launch_extend_rows(int N, int Npad, double noise, const double *z, const double *u, double *L, double *W, double *Wp,
+                       int *info, hipStream_t s)
+{
+    hipLaunchKernelGGL(extend_rows_kernel, dim3(1), dim3(1024), 0, s, N, Npad, noise, z, u, L, W, Wp, info);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
 // Marginal likelihood scalars |L^-1 y|^2 and sum log L_ii (ego/gaussianprocess/trainhyper.py:60-68)
 // without a separate triangular solve: append y as row N of the matrix
 // being factored ([[K, y],[y^T, c]]); after the Cholesky that row IS z = L^-1 y, produced by

@@ -129,6 +129,8 @@ class GaussianProcess(object):
             self._cache = {}
             self._prior_pushed = False
             self._push_prior()
+            # what the device factor was built from: only an unchanged plain model may be extended in place
+            self._fit_spec = (ktype, tuple(hyper), sf2, float(self.noise)) if A is None and X is self.X else None
 
     def _prior_arrays(self):
         """flatten the mean prior for the device: (means (k, D), beta, theta, lowerb, width) or None.
@@ -277,8 +279,12 @@ class GaussianProcess(object):
     def negmu(self, x):
         return -self.mu(x)
 
+    EXTEND_MAX = 16          # more points than this in one addData call: a refit is cheaper than point-by-point rows
+
     def addData(self, X, Y, G=None):
-        """append observations and refit (:267-308).  X (N,D) or (D,); Y vector or scalar."""
+        """append observations (:267-308).  X (N,D) or (D,); Y vector or scalar.  A fitted model is extended
+        as the reference does -- z = L^-1 m, d = chol(r - z^T z), here with W = L^-1 on the device (ibo_gp_extend,
+        O(N^2) per point); the first batch, large batches and a model whose row padding is full are (re)fitted."""
         if G is not None:
             raise NotImplementedError("gradient observations are not supported")
         X = np.array(X, dtype=float, ndmin=2)
@@ -286,15 +292,39 @@ class GaussianProcess(object):
         assert len(Y) == len(X), 'wrong number of Y-observations given'
         if len(self.X) == 0 and len(self.gnoise) == 1:
             self.gnoise = np.tile(self.gnoise, X.shape[1])
+        oldX, oldY = self.X, self.Y
         if len(self.X) == 0:
             self.X = np.copy(X)
             self.Y = np.copy(Y)
         else:
             self.X = np.r_[self.X, X]
             self.Y = np.r_[self.Y, Y]
-        # the reference extends L block-wise; refitting from R gives the same R and a
-        # factor that is identical for batch and sequential construction
-        self._fit_device()
+        try:
+            if not self._extend_device(len(oldX), X):
+                self._fit_device()
+        except Exception:
+            # as the reference: a failed factorisation leaves the model as it was.  The device rows may have been
+            # half written, so the old data are factored again before the error is passed on
+            self.X, self.Y = oldX, oldY
+            if len(oldX):
+                self._fit_device()
+            raise
+
+    def _extend_device(self, n_old, Xnew):
+        """block extension on the device; False when the handle has to be refitted instead"""
+        if n_old == 0 or self._dev is None or len(Xnew) > self.EXTEND_MAX:
+            return False
+        spec = self.kernel._ibo_spec()
+        if getattr(self, "_fit_spec", None) != (spec[0], tuple(spec[1]), spec[2], float(self.noise)):
+            return False                             # kernel or noise changed since the fit
+        info = ctypes.c_int(0)
+        Xc = _lib.f64(Xnew); Yc = _lib.f64(self.Y)
+        rc = _lib.lib.ibo_gp_extend(self._handle(), len(Xnew), _lib.dp(Xc), _lib.dp(Yc), ctypes.byref(info))
+        if rc == _lib.ERR_STATE:
+            return False
+        _lib.check(rc)
+        self._cache = {}
+        return True
 
     def getYfromX(self, qx):
         for x, y in zip(self.X, self.Y):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IBO_ABI_VERSION 1
+#define IBO_ABI_VERSION 2   /* 2: + ibo_gp_extend, ibo_comm_count */
 
 /* status codes */
 #define IBO_OK              0
@@ -125,6 +125,17 @@ int ibo_gp_fit_with_matrix(ibo_gp_t *gp, int ktype, int N, int D,
                            const double *X_host, const double *Y_host,
                            const double *hyper_host, int nhyper, double sf2, double noise,
                            const double *A_host, int *info);
+
+/*
+ * Append n observations (Xnew_host: n x D) to a fitted model WITHOUT refactoring: the block extension of
+ * GaussianProcess.addData (ego/gaussianprocess/__init__.py:301-308: z = solve(L, m), d = chol(r - z^T z)),
+ * one point at a time, O(N^2) per point.  Y_all_host holds all N + n targets.  R, L, W and both alpha vectors
+ * are updated in place on the device.  Returns IBO_ERR_STATE -- and changes nothing -- when the handle cannot
+ * be extended (never fitted, fitted from a caller-supplied matrix or from an inverse, or N + n exceeds the
+ * row padding, a multiple of 64): the caller then calls ibo_gp_fit with all the data.  IBO_ERR_NOT_PD as
+ * ibo_gp_fit (the handle then needs a refit).
+ */
+int ibo_gp_extend(ibo_gp_t *gp, int n, const double *Xnew_host, const double *Y_all_host, int *info);
 
 /* replace Y (and the alpha vectors) without refactoring: the preference GP's
  * C-matrix loop re-reads mu with L fixed (ego/gaussianprocess/__init__.py:476) */

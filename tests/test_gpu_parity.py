@@ -139,9 +139,61 @@ def test_batch_vs_sequential_identity(ibo):
     for i in range(18, 25):
         GP4.addData(X[i], Y[i])
     assert np.all(GP1.R == GP2.R) and np.all(GP1.R == GP4.R)
+    # the factor of a model grown point by point (block extension, as the reference grows it) differs from the
+    # batch factor in the last bits; the reference's own test asks for 5-7 decimal places (assertAlmostEqual)
     for x in lhcSample(b, 25, seed=2):
-        assert GP1.posterior(x) == GP2.posterior(x) == GP4.posterior(x)
+        close(GP2.posterior(x), GP1.posterior(x), rtol=1e-11, atol=1e-13)
+        close(GP4.posterior(x), GP1.posterior(x), rtol=1e-11, atol=1e-13)
     assert len(GP2.X) == 25
+
+
+def test_add_data_block_extension_equals_refit(ibo, oracle):
+    """GaussianProcess.addData on a fitted model extends L (and W = L^-1, the alpha vectors, every packed copy)
+    on the device as ego/gaussianprocess/__init__.py:301-308 does; everything must agree with a refit from
+    scratch at 1e-12 and with the oracle's (refitted) posterior at 1e-6 -- also across a 64-row padding boundary
+    (where the extension hands over to a refit), for a batch, after a kernel change, and when it must fail"""
+    from ibo_amd import _lib, NotPositiveDefinite
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.acquisition import sweep, maximizeEI
+    for N0, D, kern, okern, adds in ((300, 4, K.GaussianKernel_ard([.3] * 4), ("ard", [.3] * 4), (1, 1, 3, 1, 16, 17)),
+                                     (60, 3, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0]), (1, 1, 1, 1, 1, 1, 2)),     # crosses 64
+                                     (1000, 8, K.MaternKernel3([.7, 1.0]), ("m3", [.7, 1.0]), (1, 5, 1))):
+        tot = N0 + sum(adds)
+        X, Y = synth(90 + D, tot, D)
+        GP = GaussianProcess(kern, X[:N0], Y[:N0], noise=.1)
+        n = N0
+        for a in adds:
+            GP.addData(X[n:n + a] if a > 1 else X[n], Y[n:n + a] if a > 1 else Y[n])
+            n += a
+            ref = GaussianProcess(kern, X[:n], Y[:n], noise=.1)
+            np.testing.assert_array_equal(GP.R, ref.R)
+            close(GP.L, ref.L, rtol=1e-12, atol=1e-13)
+            Wa = np.empty((n, n)); Wb = np.empty((n, n))
+            _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(Wa))); _lib.check(_lib.lib.ibo_gp_get_W(ref._handle(), _lib.dp(Wb)))
+            close(Wa, Wb, rtol=1e-10, atol=1e-11)
+            probe = np.random.RandomState(n).rand(40, D)
+            close(GP.posteriors(probe), ref.posteriors(probe), rtol=1e-11, atol=1e-12)
+        # the large-batch kernel reads the packed copies (fragment-order W, augmented X, alpha): all extended
+        cand = np.random.RandomState(7).rand(8300, D)
+        ra = sweep(GP, cand, outputs=("mu", "s2", "acq")); rb = sweep(ref, cand, outputs=("mu", "s2", "acq"))
+        close(ra["mu"], rb["mu"], rtol=1e-10, atol=1e-11); close(ra["s2"], rb["s2"], rtol=1e-10); assert ra["best_idx"] == rb["best_idx"]
+        close(maximizeEI(GP, [[0., 1.]] * D, maxiter=8)[0], maximizeEI(ref, [[0., 1.]] * D, maxiter=8)[0], rtol=1e-9)
+        ogp = oracle.GP(oracle.Kern(*okern), X[:n], Y[:n], noise=.1)
+        close(GP.posteriors(probe), ogp.posteriors(probe), atol=1e-9)
+    # a changed kernel is noticed (refit with the new one), not extended with the old factor
+    X, Y = synth(3, 41, 2)
+    GP = GaussianProcess(K.GaussianKernel_iso([.3]), X[:40], Y[:40], noise=.1)
+    GP.kernel = K.GaussianKernel_iso([.5])
+    GP.addData(X[40], Y[40])
+    close(GP.posteriors(X[:5] + .01), GaussianProcess(K.GaussianKernel_iso([.5]), X, Y, noise=.1).posteriors(X[:5] + .01), rtol=1e-12)
+    # a duplicate point without noise has no factor: numpy's LinAlgError, and the model stays as it was
+    GP = GaussianProcess(K.GaussianKernel_iso([.3]), X[:20], Y[:20], noise=0.0)
+    before = GP.posteriors(X[20:25])
+    with pytest.raises(NotPositiveDefinite):
+        GP.addData(X[3], Y[3])
+    assert len(GP.X) == 20
+    close(GP.posteriors(X[20:25]), before, rtol=1e-12)
 
 
 @pytest.mark.parametrize("name", ["c1_n32_d2_ard", "c2r_n256_d4_ard", "c2r_n256_d4_iso", "c3r_n192_d8_m5",

@@ -18,4 +18,4 @@ for N, D in ((32, 2), (1024, 4), (2048, 8)):
     t0 = time.perf_counter()
     for _ in range(20): GP.addData(rs.rand(D), 0.1)
     ta = (time.perf_counter() - t0) / 20 * 1e3
-    print("N=%4d D=%d  posterior(x) %.0f us   EI.negf(x) %.0f us   addData (refit) %.2f ms" % (N, D, tp, te, ta))
+    print("N=%4d D=%d  posterior(x) %.0f us   EI.negf(x) %.0f us   addData (1 point) %.2f ms" % (N, D, tp, te, ta))
