@@ -168,7 +168,7 @@ def maximizeEI(model, bounds, useCDIRECT=True, xi=0.01, maxiter=50, maxtime=30, 
 
 
 def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None, native=True, ymax=None,
-          exclude=None, exclude_radius=0.5, index_base=0, outputs=(), NA=None):
+          exclude=None, exclude_radius=0.5, index_base=0, outputs=(), NA=None, incremental=False):
     """Evaluate an acquisition over a whole candidate array and return its arg-max.
 
     candidates   (M, D) ndarray (uploaded) or a _lib.DeviceArray already in HBM
@@ -176,6 +176,9 @@ def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None,
     native=False Python-class semantics: NR erf, clamp [1e-7, 10]
     exclude      points whose exclude_radius-ball is left out of the arg-max (gallery rule)
     outputs      any of 'mu', 's2', 'acq': per-candidate arrays to return (host ndarrays)
+    incremental  keep the per-candidate state of THIS DeviceArray on the model's handle and, when the model has only
+                 grown through addData since the last such call, fold the new rows in instead of sweeping again
+                 (fastUCBGallery's rounds); the array's contents must not change between calls
     Returns dict(best_val, best_idx, kernel_ms, [mu], [s2], [acq]); first maximiser wins ties.
     """
     if isinstance(candidates, _lib.DeviceArray):
@@ -200,7 +203,8 @@ def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None,
     if native:
         _lib.check(_lib.lib.ibo_gp_set_kstar_sf2(h, sf2_native))
     try:
-        _lib.check(_lib.lib.ibo_acq_sweep(
+        entry = _lib.lib.ibo_acq_sweep_incremental if incremental else _lib.lib.ibo_acq_sweep
+        _lib.check(entry(
             h, M, cand.ptr, code, float(parm), _lib.ERF_LIBM if native else _lib.ERF_NR,
             _lib.CLAMP_NATIVE if native else _lib.CLAMP_PY, float('nan') if ymax is None else float(ymax),
             0 if ex is None else len(ex), None if ex is None else _lib.dp(ex), float(exclude_radius),

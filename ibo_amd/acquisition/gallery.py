@@ -41,11 +41,13 @@ def _best_observation_inside(X, Y, bounds):
     return X[k] if score[k] > -np.inf else None
 
 
-def _start(GP, bounds, useBest):
+def _start(GP, bounds, useBest, rounds=0):
     """first gallery member(s) and the plain GP the rounds hallucinate on (gallery.py:49-90): the best
     in-box observation when there are data; the box centre for an empty model without a prior; otherwise
     the highest posterior-mean point reached by a local search from each RBF centre of the prior"""
-    plain = dict(prior=GP.prior, device=GP._device)       # default noise: the source model may be a preference GP
+    # default noise: the source model may be a preference GP; room for the rounds' hallucinated rows, so that every one
+    # of them is an in-place extension of the factor (and of the kept sweep state) rather than a refit
+    plain = dict(prior=GP.prior, device=GP._device, reserve_rows=rounds)
     if len(GP.X) > 0:
         first = _best_observation_inside(GP.X, GP.Y, bounds) if useBest else None
         model = GaussianProcess(deepcopy(GP.kernel), np.array(GP.X, dtype=float), np.array(GP.Y, dtype=float), **plain)
@@ -82,7 +84,13 @@ def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, ca
     EI(xi=.3), (2) the best of a sample set under EI(xi=.4, NR erf) -- one fused sweep, distance rule applied
     in the kernel -- and (3) the prior's centres; the highest admissible proposal joins the gallery and is
     added to the model with its own posterior mean as a hallucinated observation."""
-    gallery, model = _start(GP, bounds, useBest)
+    gallery, model = _start(GP, bounds, useBest, rounds=N)
+    # a fixed candidate array is swept every round while the model grows by one hallucinated point: it goes to
+    # HBM once, and from the second round on the device folds the model's new row into the per-candidate state it
+    # kept (sweep(incremental=True)) instead of repeating the O(N^2)-per-candidate sweep
+    fixed = candidates is not None and lhc_per_round is None
+    if fixed and not isinstance(candidates, _lib.DeviceArray):
+        candidates = _lib.DeviceArray.from_host(np.atleast_2d(np.asarray(candidates, dtype=float)), model._dev.device)
     rnd = 0
     while len(gallery) < N:
         pick_val, pick = -np.inf, None
@@ -101,11 +109,12 @@ def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, ca
             # S is this rank's block of the candidate array (rows index_base ...): sharded sweep + one exchange
             from ..multigpu import sharded_sweep
             r = sharded_sweep(model, S, index_base, comm, acq='ei', xi=.4, native=False, exclude=shown,
-                              exclude_radius=MIN_SEPARATION)
+                              exclude_radius=MIN_SEPARATION, incremental=fixed)
             if r["best_idx"] >= 0 and r["best_val"] > pick_val:
                 pick_val, pick = r["best_val"], np.array(r["best_x"])
         else:
-            r = sweep(model, S, acq='ei', xi=.4, native=False, exclude=shown, exclude_radius=MIN_SEPARATION)
+            r = sweep(model, S, acq='ei', xi=.4, native=False, exclude=shown, exclude_radius=MIN_SEPARATION,
+                      incremental=fixed)
             if r["best_idx"] >= 0 and r["best_val"] > pick_val:
                 k = r["best_idx"]
                 pick_val = r["best_val"]

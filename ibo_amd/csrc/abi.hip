@@ -179,6 +179,11 @@ struct ibo_gp {
     double *pin = nullptr; size_t pin_cap = 0;      // pinned host staging for small host-in/host-out batches
     DevBuf<double> Xp, Xs, ak, XA, Y, R, A, L, W, T, Wp, diag64, alphaY, alpha1, tmp, cand, outs, excl, qpart, mupart, partv, res_v;
     DevBuf<int64_t> parti, res_i;
+    // kept sweep state (ibo_acq_sweep_incremental): (q, aY.k*, a1.k*) per candidate of ONE device candidate array
+    DevBuf<double> state;
+    const double *st_cand = nullptr; int64_t st_M = 0; int st_N = 0; double st_sf2 = 0.0; unsigned st_epoch = 0;
+    unsigned fit_epoch = 0;         // bumped by every full fit: a kept state never survives one
+    int reserve = 0;                // rows of head-room the next fit leaves for ibo_gp_extend (ibo_gp_reserve)
     DevBuf<int> info;
     // prior
     int nb = 0; double ptheta = 0.0;
@@ -303,7 +308,7 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->Xp.release(); g->Xs.release(); g->ak.release(); g->XA.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
     g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
-    g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release();
+    g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release();
     if (g->pin) (void)hipHostFree(g->pin);
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
     (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
@@ -363,7 +368,7 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
 {
     if (N < 1) return fail(IBO_ERR_ARG, "N=%d", N);
     if (!X || !Y) return fail(IBO_ERR_ARG, "X/Y is NULL");
-    g->N = N; g->D = D; g->Npad = round_up(N, 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
+    g->N = N; g->D = D; g->Npad = round_up(N + (reverse ? 0 : g->reserve), 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
     g->reversed = reverse;
     const int Np = g->Npad, DP = g->DP;
     size_t nn = (size_t)Np * Np;
@@ -449,6 +454,7 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     HIP_TRY(hipEventElapsedTime(&g->fit_ms, g->fit0, g->fit1));
     g->fitted = true;
     g->plain_fit = (A_host == nullptr);
+    g->fit_epoch++;
     return IBO_OK;
 }
 
@@ -512,6 +518,13 @@ extern "C" int ibo_gp_extend(ibo_gp_t *g, int n, const double *Xnew, const doubl
     return IBO_OK;
 }
 
+extern "C" int ibo_gp_reserve(ibo_gp_t *g, int rows)
+{
+    if (!g || rows < 0) return fail(IBO_ERR_ARG, "bad argument");
+    g->reserve = rows;
+    return IBO_OK;
+}
+
 extern "C" int ibo_gp_fit(ibo_gp_t *g, int ktype, int N, int D, const double *X, const double *Y,
                           const double *hyper, int nhyper, double sf2, double noise, int *info)
 {
@@ -554,6 +567,8 @@ static int fit_from_inverse(ibo_gp *g, int ktype, int N, int D, const double *X,
     IBO_TRY(check_info(g, nullptr));
     HIP_TRY(hipEventElapsedTime(&g->fit_ms, g->fit0, g->fit1));
     g->fitted = true;
+    g->plain_fit = false;
+    g->fit_epoch++;
     return IBO_OK;
 }
 
@@ -761,7 +776,7 @@ static int exp_table(int device, const double **out)
 static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
                      double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,
                      int64_t index_base, double *mu_dev, double *s2_dev, double *acq_dev,
-                     double *best_val, int64_t *best_idx)
+                     double *best_val, int64_t *best_idx, bool incremental = false)
 {
     if (!g->fitted) return fail(IBO_ERR_STATE, "sweep before a successful fit");
     if (M < 1 || !cand_dev) return fail(IBO_ERR_ARG, "empty candidate set");
@@ -809,10 +824,27 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         g->sweep_kernel = "sweep_gemv_kernel";
     } else if (a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad)) {
         IBO_TRY(exp_table(g->device, &a.exp_tab));
-        IBO_TRY(g->qpart.ensure(3 * (size_t)M));        // (q, aY.k*, a1.k*) per candidate, finished by acq_finish_kernel
-        a.qpart = g->qpart.p;
-        KERNEL_TRY(launch_sweep2(a, s, g->ev0, g->ev1));
-        g->sweep_kernel = "sweep2_kernel";
+        if (incremental) {
+            // the state of this candidate array is kept on the handle; if the model has only grown by a few rows
+            // (ibo_gp_extend) since it was formed, those rows are folded in -- O(N) per candidate, not O(N^2)
+            const bool usable = g->st_cand == cand_dev && g->st_M == M && g->st_epoch == g->fit_epoch && g->st_sf2 == g->kp.sf2 &&
+                                g->st_N >= 1 && g->st_N <= g->N && g->N - g->st_N <= 8 && g->state.cap >= 3 * (size_t)M;
+            IBO_TRY(g->state.ensure(3 * (size_t)M));
+            a.qpart = g->state.p;
+            if (usable) {
+                KERNEL_TRY(launch_sweep2_refresh(a, g->st_N, g->N - 1, s, g->ev0, g->ev1));
+                g->sweep_kernel = g->N > g->st_N ? "sweep2_rank1_kernel" : "acq_finish_kernel";
+            } else {
+                KERNEL_TRY(launch_sweep2(a, s, g->ev0, g->ev1));
+                g->sweep_kernel = "sweep2_kernel";
+            }
+            g->st_cand = cand_dev; g->st_M = M; g->st_N = g->N; g->st_sf2 = g->kp.sf2; g->st_epoch = g->fit_epoch;
+        } else {
+            IBO_TRY(g->qpart.ensure(3 * (size_t)M));    // (q, aY.k*, a1.k*) per candidate, finished by acq_finish_kernel
+            a.qpart = g->qpart.p;
+            KERNEL_TRY(launch_sweep2(a, s, g->ev0, g->ev1));
+            g->sweep_kernel = "sweep2_kernel";
+        }
     } else {
 #ifdef IBO_STAMPS
         IBO_TRY(g->mupart.ensure((size_t)ntiles * 16 + 16));
@@ -850,6 +882,17 @@ extern "C" int ibo_acq_sweep(ibo_gp_t *g, int64_t M, const double *cand_dev, int
     IBO_TRY(use_device(g->device));
     return run_sweep(g, M, cand_dev, acq, parm, erf_mode, clamp_lo, ymax, n_excl, excl_host, excl_radius,
                      index_base, mu_dev, s2_dev, acq_dev, best_val, best_idx);
+}
+
+extern "C" int ibo_acq_sweep_incremental(ibo_gp_t *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
+                                         double clamp_lo, double ymax, int n_excl, const double *excl_host,
+                                         double excl_radius, int64_t index_base, double *mu_dev, double *s2_dev,
+                                         double *acq_dev, double *best_val, int64_t *best_idx)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    IBO_TRY(use_device(g->device));
+    return run_sweep(g, M, cand_dev, acq, parm, erf_mode, clamp_lo, ymax, n_excl, excl_host, excl_radius,
+                     index_base, mu_dev, s2_dev, acq_dev, best_val, best_idx, true);
 }
 
 extern "C" int ibo_last_sweep_kernel_ms(ibo_gp_t *g, float *ms, const char **kernel_name)

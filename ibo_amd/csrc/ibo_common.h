@@ -189,12 +189,14 @@ struct SweepArgs {
     double *qpart;                       // gemv path scratch: rowchunks x M
     double *mupart;                      // gemv path scratch: 2 x M
     double *result_val; int64_t *result_idx;   // device, single element each
+    int rank1_row;                             // sweep2_rank1_kernel: the appended row of W being folded into the state
 };
 
 int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 // large batches, dot form: 32-candidate tiles, 1024-row panels, exponent GEMM on the MFMA unit (sweep2.hip)
 int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+int launch_sweep2_refresh(const SweepArgs &a, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool sweep2_fits(int Npad);      // its LDS budget holds both alpha vectors (N <= ~5000)
 int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, int D, double *XA, hipStream_t s);
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);

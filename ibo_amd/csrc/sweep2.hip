@@ -378,6 +378,102 @@ __global__ __launch_bounds__(256) void acq_finish_kernel(SweepArgs a)
     }
 }
 
+// Refresh of a kept sweep state after the model has grown by one row (ibo_gp_extend): with W' = [[W, 0], [w^T, 1/d]]
+// the new candidate-side quantity is q' = q + (w'_last . k*')^2, and the means are re-formed from the current alpha
+// vectors -- three dot products against the regenerated k* per candidate, O(N) instead of the O(N^2) of W K*.
+// Same tile geometry and k* generation as sweep2_kernel (each wave produces the 16 x 16 tile (wave>>1, wave&1) of
+// every 128-row stage) without the MFMA phase, the LDS stages and the barriers.  a.qpart is the state [3][M].
+template <int FAM, int KA4>
+__global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
+{
+    constexpr int TCAND = IBO_S2_TCAND, KA = 4 * KA4;
+    __shared__ double lds_c[TCAND * KA];
+    __shared__ double lds_m[3][S2_NW][16];
+    __shared__ double lds_tab[2048];
+    extern __shared__ __attribute__((aligned(16))) double lds_vec[];     // alphaY, alpha1, new row of W: NA128 each
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tile0 = (int64_t)blockIdx.x * TCAND;
+    const int D = a.kp.D, row = a.rank1_row, Npad = a.Npad;
+    const int NA128 = (Npad + 127) & ~127;
+    lds_tab[tid] = a.exp_tab[tid];
+    lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
+    for (int e = tid; e < NA128; e += S2_NW * 64) {
+        lds_vec[e] = a.alphaY[e];
+        lds_vec[NA128 + e] = a.alpha1[e];
+        lds_vec[2 * NA128 + e] = e <= row ? a.W[(size_t)row * Npad + e] : 0.0;
+    }
+    for (int e = tid; e < TCAND * KA; e += S2_NW * 64) {
+        const int c = e / KA, col = e - c * KA;
+        int64_t gi = tile0 + c;
+        if (gi > a.M - 1) gi = a.M - 1;
+        lds_c[e] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid < TCAND) {                               // as sweep2_kernel: radius guard, then b_c
+        double n2 = 0.0;
+        for (int d = 0; d < D; d++) { const double v = lds_c[tid * KA + d]; n2 = fma(v, v, n2); }
+        if (n2 > 6e5) {
+            const double sc = sqrt(6e5 / n2);
+            for (int d = 0; d < D; d++) lds_c[tid * KA + d] *= sc;
+            n2 = 6e5;
+        }
+        lds_c[tid * KA + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
+    }
+    __syncthreads();
+    const int rt = wave >> 1, gcb = wave & 1;
+    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * KA + (lane >> 4)];
+    const __amdgpu_buffer_rsrc_t rXA = s2_rsrc(a.XA, (size_t)(NA128 / 16) * KA4 * 64 * sizeof(double));
+    const unsigned lane8 = lane * 8;
+    const double *vq = lds_vec + (lane >> 4);
+    const int nstage = (row + 1 + S2_KCH - 1) / S2_KCH;
+    double muY = 0.0, mu1 = 0.0, nu = 0.0;
+    double xa[KA4], xn[KA4];
+#pragma unroll
+    for (int s = 0; s < KA4; s++) xa[s] = s2_ld_f64(rXA, lane8, (unsigned)((rt * KA4 + s) * 512));
+    for (int t = 0; t < nstage; t++) {
+        const int tile = t * (S2_KCH / 16) + rt;
+        if (t + 1 < nstage) {
+#pragma unroll
+            for (int s = 0; s < KA4; s++) xn[s] = s2_ld_f64(rXA, lane8, (unsigned)(((tile + S2_KCH / 16) * KA4 + s) * 512));
+        }
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KA4; s++) y = mfma_f64(xa[s], cfrag[4 * s], y);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int k = tile * 16 + 4 * r;
+            const double ay = vq[k], a1v = vq[NA128 + k], om = vq[2 * NA128 + k];
+            double kv;
+            if (FAM == FAM_SE) kv = s2_exp(y[r], lds_tab);
+            else {
+                const double z = fmax(-2.0 * y[r], 0.0);
+                const double rr = sqrt_fast((FAM == FAM_M3 ? 3.0 : 5.0) * z);
+                const double poly = FAM == FAM_M3 ? 1.0 + rr : fma(rr, fma(rr, 1.0 / 3.0, 1.0), 1.0);
+                kv = a.kp.sf2 * poly * s2_exp(-rr, lds_tab);
+            }
+            muY = fma(ay, kv, muY); mu1 = fma(a1v, kv, mu1); nu = fma(om, kv, nu);
+        }
+#pragma unroll
+        for (int s = 0; s < KA4; s++) xa[s] = xn[s];
+    }
+    muY += __shfl_xor(muY, 16); muY += __shfl_xor(muY, 32);
+    mu1 += __shfl_xor(mu1, 16); mu1 += __shfl_xor(mu1, 32);
+    nu += __shfl_xor(nu, 16); nu += __shfl_xor(nu, 32);
+    if (lane < 16) { lds_m[0][wave][lane] = muY; lds_m[1][wave][lane] = mu1; lds_m[2][wave][lane] = nu; }
+    __syncthreads();
+    if (tid < TCAND) {
+        const int c = tid;
+        double my = 0.0, m1 = 0.0, v = 0.0;
+#pragma unroll
+        for (int w = 0; w < S2_NW / 2; w++) {
+            my += lds_m[0][2 * w + (c >> 4)][c & 15]; m1 += lds_m[1][2 * w + (c >> 4)][c & 15]; v += lds_m[2][2 * w + (c >> 4)][c & 15];
+        }
+        const int64_t li = tile0 + c;
+        if (li < a.M) { a.qpart[li] = fma(v, v, a.qpart[li]); a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1; }
+    }
+}
+
 // XA: the observations as A-fragments of the exponent GEMM.  Row k of the augmented matrix is
 // [x~_k (D), a_k, 1, 0...] (KA = 4 KA4 columns); fragment (tile, s) holds rows 16 tile + (lane&15), column
 // 4 s + (lane>>4) at XA[(tile KA4 + s) 64 + lane].  Rows >= N (padding up to a multiple of 128) are zero.
@@ -406,7 +502,7 @@ int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, 
 #define S2_STATIC_LDS (80 * 1024)
 bool sweep2_fits(int Npad)
 {
-    return (size_t)((Npad + 127) & ~127) * 16 + S2_STATIC_LDS <= 160 * 1024;
+    return (size_t)((Npad + 127) & ~127) * 16 + S2_STATIC_LDS <= 160 * 1024;      // (the refresh kernel's 24 B/row + 27 KiB fit whenever this does)
 }
 
 template <int FAM, int KA4>
@@ -423,6 +519,32 @@ static int launch_s2_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+template <int FAM, int KA4>
+static int launch_s2_rank1_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    const int dyn = ((a.Npad + 127) & ~127) * 24;
+    static int granted = 0;
+    if (dyn > granted) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep2_rank1_kernel<FAM, KA4>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        if (e != hipSuccess) return (int)e;
+        granted = dyn;
+    }
+    hipLaunchKernelGGL((sweep2_rank1_kernel<FAM, KA4>), dim3((unsigned)ntiles), dim3(S2_NW * 64), dyn, s, a);
+    return (int)hipGetLastError();
+}
+
+template <int FAM>
+static int launch_s2_rank1_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    switch ((a.kp.D + 2 + 3) / 4) {
+    case 1: return launch_s2_rank1_one<FAM, 1>(a, ntiles, s);
+    case 2: return launch_s2_rank1_one<FAM, 2>(a, ntiles, s);
+    case 3: return launch_s2_rank1_one<FAM, 3>(a, ntiles, s);
+    case 4: return launch_s2_rank1_one<FAM, 4>(a, ntiles, s);
+    default: return launch_s2_rank1_one<FAM, 5>(a, ntiles, s);
+    }
+}
+
 template <int FAM>
 static int launch_s2_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
@@ -433,6 +555,29 @@ static int launch_s2_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     case 4: return launch_s2_one<FAM, 4>(a, ntiles, s);
     default: return launch_s2_one<FAM, 5>(a, ntiles, s);
     }
+}
+
+// rows [row_first, row_last] were appended to the model since a.qpart (the kept state [3][M]) was last brought up to
+// date: one refresh launch per row, then the acquisition as after a full sweep
+int launch_sweep2_refresh(const SweepArgs &a0, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int64_t ntiles = (a0.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
+    if (e0) (void)hipEventRecord(e0, s);
+    for (int r = row_first; r <= row_last; r++) {
+        SweepArgs a = a0;
+        a.rank1_row = r;
+        int rc;
+        if (a.kp.family == FAM_SE) rc = launch_s2_rank1_fam<FAM_SE>(a, ntiles, s);
+        else if (a.kp.family == FAM_M3) rc = launch_s2_rank1_fam<FAM_M3>(a, ntiles, s);
+        else rc = launch_s2_rank1_fam<FAM_M5>(a, ntiles, s);
+        if (rc) return rc;
+    }
+    if (e1) (void)hipEventRecord(e1, s);
+    const int64_t nfin = (a0.M + 255) / 256;
+    hipLaunchKernelGGL(acq_finish_kernel, dim3((unsigned)nfin), dim3(256), 0, s, a0);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return launch_argmax_final(a0, nfin, s);
 }
 
 int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1)

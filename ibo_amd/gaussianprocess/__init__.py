@@ -70,8 +70,9 @@ class _DeviceGP(object):
 
 class GaussianProcess(object):
 
-    def __init__(self, kernel, X=None, Y=None, prior=None, noise=.1, gnoise=1e-4, G=None, device=None):
+    def __init__(self, kernel, X=None, Y=None, prior=None, noise=.1, gnoise=1e-4, G=None, device=None, reserve_rows=0):
         self.kernel = kernel
+        self._reserve_rows = int(reserve_rows)      # head-room for addData's in-place extension (ibo_gp_reserve)
         self.prior = prior
         self.noise = noise
         self.gnoise = np.array(gnoise, ndmin=1)
@@ -106,6 +107,8 @@ class GaussianProcess(object):
     def _handle(self):
         if self._dev is None:
             self._dev = _DeviceGP(self._device)
+            if self._reserve_rows:
+                _lib.check(_lib.lib.ibo_gp_reserve(self._dev.h, self._reserve_rows))
         return self._dev.h
 
     def _fit_device(self, A=None, dev=None, X=None):

@@ -136,6 +136,10 @@ int ibo_gp_fit_with_matrix(ibo_gp_t *gp, int ktype, int N, int D,
  * ibo_gp_fit (the handle then needs a refit).
  */
 int ibo_gp_extend(ibo_gp_t *gp, int n, const double *Xnew_host, const double *Y_all_host, int *info);
+/* head-room: later fits of this handle pad the matrices to a multiple of 64 that leaves at least `rows` free rows, so
+ * that many observations can be appended by ibo_gp_extend before a refit is due (a gallery of n points on a model
+ * whose size is a multiple of 64 would otherwise refit, and sweep in full, in its very first round) */
+int ibo_gp_reserve(ibo_gp_t *gp, int rows);
 
 /* replace Y (and the alpha vectors) without refactoring: the preference GP's
  * C-matrix loop re-reads mu with L fixed (ego/gaussianprocess/__init__.py:476) */
@@ -217,6 +221,23 @@ int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
                   int64_t index_base,
                   double *mu_dev, double *s2_dev, double *acq_dev,
                   double *best_val, int64_t *best_idx);
+
+/*
+ * ibo_acq_sweep for a caller that sweeps the SAME device candidate array again and again while the model grows by
+ * ibo_gp_extend -- fastUCBGallery's rounds (ego/acquisition/gallery.py:92-134: one hallucinated observation per
+ * round, the same sample set).  The first call is a full sweep and leaves q = |W k*|^2 (and the two mean terms) per
+ * candidate on the handle, 24 bytes each.  A later call with the same array, after at most 8 rows were appended and
+ * nothing else changed, folds the new rows of W into q -- (w_new . k*)^2, O(N) per candidate instead of O(N^2) --
+ * re-forms the means from the current alpha vectors and evaluates the acquisition as usual.  Anything else (other
+ * array or size, a refit, another k* variance, batches small enough for the other kernels) is a full sweep.
+ * The caller must not change the candidate array's contents between calls.
+ */
+int ibo_acq_sweep_incremental(ibo_gp_t *gp, int64_t M, const double *cand_dev,
+                              int acq, double parm, int erf_mode, double clamp_lo, double ymax,
+                              int n_excl, const double *excl_host, double excl_radius,
+                              int64_t index_base,
+                              double *mu_dev, double *s2_dev, double *acq_dev,
+                              double *best_val, int64_t *best_idx);
 
 /* device-side duration (hipEvent, ms) of the dominant kernel of the last
  * ibo_acq_sweep / ibo_posterior_batch on this handle, and its name */

@@ -430,6 +430,51 @@ def test_sweep2_kernel_against_oracle_and_the_other_kernels(ibo, oracle):
         _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 0))
 
 
+def test_incremental_sweep_state_equals_full_sweeps(ibo):
+    """sweep(incremental=True) on a fixed candidate array while the model grows by addData (the gallery's rounds):
+    every round's per-candidate mu / s2 / EI and arg-max equal a full sweep of a freshly fitted model -- values at
+    1e-6 (the bar), here 1e-9; the refresh kernel really runs; a refit, another array or a bigger jump start over"""
+    from ibo_amd import DeviceArray
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.acquisition import sweep
+    from ibo_amd.acquisition.gallery import fastUCBGallery
+    for N0, D, kern in ((500, 4, K.GaussianKernel_ard([.3] * 4)), (1030, 8, K.MaternKernel5([.5, 1.0])), (120, 2, K.MaternKernel3([.4, 1.0]))):
+        X, Y = synth(70 + D, N0 + 12, D)
+        GP = GaussianProcess(kern, X[:N0], Y[:N0], noise=.1)
+        dc = DeviceArray.from_host(np.random.RandomState(71).rand(9001, D))
+        seen = []
+        for rnd in range(7):
+            excl = X[:2] if rnd % 2 else None
+            r = sweep(GP, dc, acq='ei', xi=.4, native=False, exclude=excl, incremental=True, outputs=("mu", "s2", "acq"))
+            seen.append(r["kernel"])
+            ref = GaussianProcess(kern, GP.X, GP.Y, noise=.1)
+            f = sweep(ref, dc, acq='ei', xi=.4, native=False, exclude=excl, outputs=("mu", "s2", "acq"))
+            close(r["mu"], f["mu"], rtol=1e-9, atol=1e-10); close(r["s2"], f["s2"], rtol=1e-9); close(r["acq"], f["acq"], rtol=1e-9, atol=ACQ_ATOL)
+            assert r["best_idx"] == f["best_idx"]
+            n = len(GP.X)
+            if rnd == 3:
+                GP.addData(X[n:n + 2], Y[n:n + 2])              # two rows at once
+            elif rnd == 4:
+                GP._fit_device()                                 # a refit in between: the state must not survive it
+            else:
+                GP.addData(X[n], Y[n])
+        assert seen[0] == "sweep2_kernel" and seen[1] == "sweep2_rank1_kernel" and seen[4] == "sweep2_rank1_kernel"
+        assert seen[5] == "sweep2_kernel" and seen[6] == "sweep2_rank1_kernel"
+        assert sweep(GP, dc, incremental=True)["kernel"] == "sweep2_rank1_kernel"      # the row added in the last round
+        assert sweep(GP, dc, incremental=True)["kernel"] == "acq_finish_kernel"        # nothing new: acquisition only
+        other = DeviceArray.from_host(np.random.RandomState(72).rand(9001, D))
+        assert sweep(GP, other, incremental=True)["kernel"] == "sweep2_kernel"
+    # the gallery is the caller: same picks with and without the kept state
+    X, Y = synth(75, 600, 3)
+    GP = GaussianProcess(K.GaussianKernel_ard([.25, .3, .35]), X, Y, noise=.1)
+    cand = np.random.RandomState(76).rand(20000, 3)
+    b = [[0., 1.]] * 3
+    g_inc = np.array(fastUCBGallery(GP, b, 6, candidates=cand))
+    g_full = np.array(fastUCBGallery(GP, b, 6, lhc_per_round=[cand] * 6))
+    np.testing.assert_array_equal(g_inc, g_full)
+
+
 def test_sweep_index_base_beyond_32_bits(ibo):
     """global indices of a shard far into a huge candidate set: index_base > 2^31 (and > 2^32) is carried in
     64 bits through the kernel's partials, the final reduction and the ABI"""
