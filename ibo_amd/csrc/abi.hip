@@ -221,6 +221,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
+    if (key && !strcmp(key, "chol_update2")) { set_chol_update2(value); return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
@@ -443,7 +444,7 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
         // small enough for the plain right-looking order: one fused launch per block column, out of place
         KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s));
     } else {
-        KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s));
+        KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s, g->T.p));      // T: free until launch_trinv
     }
     g->L_upper_dirty = true;        // the strict upper blocks of L are scratch until someone asks for L
     KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
@@ -1067,7 +1068,7 @@ extern "C" int ibo_direct_max(ibo_gp_t *g, int D, const double *lb, const double
 
 // ------------------------------------------------------------------------ marginal-likelihood grid
 struct NlmlWorkspace {
-    DevBuf<double> dX, dY, dout, dL, d64;
+    DevBuf<double> dX, dY, dout, dL, d64, dP;       // dP: packed panels of the trailing updates (update2.hip)
     DevBuf<int> dinfo;
 };
 static NlmlWorkspace g_nlml_ws[16];
@@ -1081,7 +1082,7 @@ extern "C" int ibo_trim(int device)
 {
     IBO_TRY(use_device(device));
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
-    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dinfo.release();
+    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release();
     GradWorkspace &gw = g_grad_ws[device & 15];
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
     gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
@@ -1119,6 +1120,8 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N));
     IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
     IBO_TRY(dL.ensure(nn * B)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096 * B));
+    const size_t pws = 2 * (size_t)Np * 256;        // per matrix: both packed copies of a 4-block panel
+    IBO_TRY(ws.dP.ensure(pws * B));
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
     // identity pad once: the factorisation leaves the pad rows/columns as it found them
@@ -1129,10 +1132,10 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
             const int t = t0 + k;
             KParams kp;
             IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
-            KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, s));
+            KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, s, nullptr, 0, 1));
             KERNEL_TRY(launch_nlml_aug(dL.p + nn * k, Np, N, dY.p, s));
         }
-        KERNEL_TRY(launch_cholesky_batched(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s));
+        KERNEL_TRY(launch_cholesky_batched(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s, ws.dP.p, pws));
         for (int k = 0; k < nb; k++) KERNEL_TRY(launch_nlml_reduce(dL.p + nn * k, Np, N, dout.p + 2 * (t0 + k), s));
     }
     HIP_TRY(hipStreamSynchronize(s));

@@ -202,13 +202,18 @@ int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, 
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
-                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2 = nullptr, int np2 = 0);
+                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2 = nullptr, int np2 = 0, int lower_only = 0);
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the
 // inverses of the 64x64 diagonal blocks; info (device int) gets the 1-based failing pivot or 0
-int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s);
+// ws (optional): workspace of 2 * Npad * 64 * panel doubles per matrix (wstride apart) for the packed-panel trailing
+// update (update2.hip); without it the 64 x 64-tile update kernel runs.  Results are bit-identical either way.
+int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s, double *ws = nullptr);
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
-                            int panel, hipStream_t s);
+                            int panel, hipStream_t s, double *ws = nullptr, size_t wstride = 0);
+int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t lstride, double *ws, size_t wstride,
+                        hipStream_t s);
 void set_chol_panel(int p);
+void set_chol_update2(int v);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s);
 // W = L^-1 (row-major, ld = Npad) using diag64 from launch_cholesky and a scratch T (Npad x Npad)

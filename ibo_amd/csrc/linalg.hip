@@ -23,11 +23,12 @@
 __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
                                                          const double *__restrict__ A2, int ldp, int square,
                                                          int diag_rule, double noise, double *__restrict__ K, int ldk,
-                                                         double *__restrict__ K2, int np2)
+                                                         double *__restrict__ K2, int np2, int lower_only)
 {
     __shared__ double As[16 * 16], Bs[64 * 17], ws[16];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 16, D = kp.D;
+    if (lower_only && j0 > i0 + 15) return;          // a factorisation only reads the lower triangle
 #pragma unroll
     for (int d = 0; d < 16; d++)
         if (t == d) ws[d] = kp.w[d];
@@ -71,14 +72,14 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
 // K2 (optional, square case): a second, np2 x np2 copy of K padded with the identity -- the matrix the
 // factorisation works on, written by the same kernel instead of a separate pad-and-copy pass.
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
-                      int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2)
+                      int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2, int lower_only)
 {
     int square = (A2 == nullptr);
     if (square) { A2 = A1; n2 = n1; }
     const int c = K2 ? np2 : n2, r = K2 ? np2 : n1;
     dim3 grid((c + 63) / 64, (r + 15) / 16);
     hipLaunchKernelGGL(cov_matrix_kernel, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
-                       diag_rule, noise, K, ldk, K2, np2);
+                       diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0);
     return (int)hipGetLastError();
 }
 
@@ -603,9 +604,11 @@ static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, i
 // panel to the rest of the matrix once, with K = 64 P (fewer passes over the trailing matrix: large N, batches).
 static int g_chol_panel = 0;                         // 0 = choose; ibo_set_option("chol_panel", P)
 void set_chol_panel(int p) { g_chol_panel = p; }
+static int g_update2 = 1;                            // ibo_set_option("chol_update2", 0/1): packed-panel trailing update (update2.hip)
+void set_chol_update2(int v) { g_update2 = v; }
 
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
-                            int panel, hipStream_t s)
+                            int panel, hipStream_t s, double *ws, size_t wstride)
 {
     const int nb = Npad / 64;
     const size_t dstride = (size_t)nb * 4096;
@@ -624,7 +627,14 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
                                    dstride, (double *)nullptr);
             if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s);
         }
-        if (pend < nb) launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
+        if (pend < nb) {
+            // the big update (K = 64 P): packed-panel kernel when the caller lent a workspace, bit-identical to the other
+            const int nI2 = (Npad - 64 * pend + 127) / 128;
+            if (ws && g_update2 && (size_t)nI2 * (nI2 + 1) / 2 * batch >= 1024) {      // enough 128 x 128 tiles to fill the chip twice
+                int rc = launch_chol_update2(L, Npad, p0, pend, batch, lstride, ws, wstride, s);
+                if (rc) return rc;
+            } else launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
+        }
     }
     return (int)hipGetLastError();
 }
@@ -656,9 +666,9 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
     return (int)hipGetLastError();
 }
 
-int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s)
+int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s, double *ws)
 {
-    return launch_cholesky_batched(L, Npad, diag64, info_dev, 1, 0, Npad / 64 > 32 ? 4 : 1, s);
+    return launch_cholesky_batched(L, Npad, diag64, info_dev, 1, 0, Npad / 64 > 32 ? 4 : 1, s, ws, 0);
 }
 
 // ------------------------------------------------------------------------
