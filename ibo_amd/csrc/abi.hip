@@ -51,6 +51,7 @@ void ibo_internal_set_error(const char *msg)
 extern int g_sweep_variant;     // sweep.hip
 static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
+static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
@@ -222,6 +223,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_update2")) { set_chol_update2(value); return IBO_OK; }
+    if (key && !strcmp(key, "chol_ride")) { g_chol_ride = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
@@ -441,13 +443,22 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
                                  A_host ? nullptr : work, Np));
     if (A_host) KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
     if (fused) {
-        // small enough for the plain right-looking order: one fused launch per block column, out of place
-        KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s));
+        // small enough for the plain right-looking order: one fused launch per block column, out of place, with
+        // W = L^-1 riding along (E = I in W's buffer turns into (L^-1)^T in Wp's, then is transposed into W)
+        // up to 24 block columns nearly every step's extra tiles find idle CUs; beyond that the middle steps would need a
+        // second launch each and the recursive-doubling inversion (launch_trinv) is the shorter chain
+        const bool ride = g_chol_ride != 0 && Np / 64 <= 24;
+        if (ride) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, g->W.p, Np, 1.0, s));       // identity
+        KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s, ride ? g->W.p : nullptr,
+                                         ride ? g->Wp.p : nullptr));
+        g->L_upper_dirty = true;    // the strict upper blocks of L are scratch until someone asks for L
+        if (ride) KERNEL_TRY(launch_transpose_lower(g->Wp.p, g->W.p, Np, s));
+        else KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     } else {
         KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s, g->T.p));      // T: free until launch_trinv
+        g->L_upper_dirty = true;
+        KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     }
-    g->L_upper_dirty = true;        // the strict upper blocks of L are scratch until someone asks for L
-    KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));
     KERNEL_TRY(launch_alpha(g->W.p, N, Np, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, s));
     HIP_TRY(hipEventRecord(g->fit1, s));

@@ -215,7 +215,10 @@ int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t
 void set_chol_panel(int p);
 void set_chol_update2(int v);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
-int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s);
+// Ework (identity on entry) / Eout, optional: W = L^-1 rides along -- Eout receives (L^-1)^T, blocks on and above the diagonal
+int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s,
+                          double *Ework = nullptr, double *Eout = nullptr);
+int launch_transpose_lower(const double *Et, double *W, int Npad, hipStream_t s);
 // W = L^-1 (row-major, ld = Npad) using diag64 from launch_cholesky and a scratch T (Npad x Npad)
 int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s,
                  bool zero_fill = true);

@@ -400,22 +400,44 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *L, int Npad, int
 // workgroups of the first trailing column store their row block of L.  Two launches and their gaps per
 // column are gone; every product is rounded to fp64 at the same points as in the three-kernel sequence, so
 // the result is bit-identical to it.
+// W = L^-1 rides along: with E = I appended below the matrix, the factorisation's own "row block times inv(L_jj)^T,
+// then update the trailing tiles" turns E into (L^-1)^T block column by block column -- L21 L11^T = I.  Tile (i, k) of E
+// is touched by step jb only for i <= jb < k (row block i of E is zero left of its diagonal block until then), so a
+// step carries (jb + 1)(nb - jb - 1) extra tiles, run by the same code on CUs the factorisation leaves idle; the
+// recursive-doubling inversion (2 log2(nb) launches after the factorisation) disappears.
+// Tiles >= nchol are extra tiles: number e -> (i = e / m, k = jb + 1 + e % m), A_i from Ework, X_i to Eout.
+// HAVE_V: the diagonal block was factored by an earlier launch; its inverse is read from diag64 instead.
+template <bool HAVE_V>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npad, int jb,
-                      double *__restrict__ diag64, int *info)
+                      double *__restrict__ diag64, int *info, int nchol, int extra0, double *__restrict__ Ework,
+                      double *__restrict__ Eout)
 {
     __shared__ double S[64 * SD];
     __shared__ double V[64 * SD];
     __shared__ double T[64 * SD];
     TILE_IDS;
-    const int nb = Npad / 64;
-    int k = jb + 1, rem = blockIdx.x;
-    while (rem >= nb - k) { rem -= nb - k; k++; }
-    const int i = k + rem;
+    const int nb = Npad / 64, m = nb - jb - 1;
+    int i, k;
+    const double *Ai;
+    double *Xi, *C;
+    if ((int)blockIdx.x < nchol) {
+        k = jb + 1;
+        int rem = blockIdx.x;
+        while (rem >= nb - k) { rem -= nb - k; k++; }
+        i = k + rem;
+        Ai = L + (size_t)i * 64 * Npad + jb * 64;
+        Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
+        C = L + (size_t)i * 64 * Npad + k * 64;
+    } else {
+        const int e = (int)blockIdx.x - nchol + extra0;
+        i = e / m; k = jb + 1 + e % m;
+        Ai = Ework + (size_t)i * 64 * Npad + jb * 64;
+        Xi = Eout + (size_t)i * 64 * Npad + jb * 64;
+        C = Ework + (size_t)i * 64 * Npad + k * 64;
+    }
     const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
-    const double *Ai = L + (size_t)i * 64 * Npad + jb * 64, *Ak = L + (size_t)k * 64 * Npad + jb * 64;
-    double *Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
-    double *C = L + (size_t)i * 64 * Npad + k * 64;
+    const double *Ak = L + (size_t)k * 64 * Npad + jb * 64;
     // everything this workgroup will need from memory is requested before the chain starts
     SSTAMP(0);
     d2_t va[8], vb[8];
@@ -423,17 +445,23 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
     tile64_fetch(Ak, Npad, vb);
     d4_t c[2][2];
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int mm = 0; mm < 2; mm++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) c[m][n][r] = C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)];
-    diag64_load(L + doff, Npad, S, V);
-    __syncthreads();
-    SSTAMP(1);
-    diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
-    SSTAMP(2);
-    if (blockIdx.x == 0) diag64_store(Lout + doff, Npad, diag64 + (size_t)jb * 4096, S, V);
+            for (int r = 0; r < 4; r++) c[mm][n][r] = C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)];
+    if (HAVE_V) {
+        d2_t vv[8];
+        tile64_fetch(diag64 + (size_t)jb * 4096, 64, vv);
+        tile64_stash<false, SD>(V, vv);
+    } else {
+        diag64_load(L + doff, Npad, S, V);
+        __syncthreads();
+        SSTAMP(1);
+        diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
+        SSTAMP(2);
+        if (blockIdx.x == 0) diag64_store(Lout + doff, Npad, diag64 + (size_t)jb * 4096, S, V);
+    }
     __syncthreads();                                   // S is about to be reused
     SSTAMP(3);
     // X_i = A_i V^T, X_k = A_k V^T  (V[c][k] row-major is the "B^T" operand as it stands)
@@ -449,45 +477,45 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
     SSTAMP(6);
     if (k == jb + 1) {                                 // first trailing column: this row block of L is final
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int mm = 0; mm < 2; mm++)
 #pragma unroll
             for (int n = 0; n < 2; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) Xi[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = xi[m][n][r];
+                for (int r = 0; r < 4; r++) Xi[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] = xi[mm][n][r];
     }
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int mm = 0; mm < 2; mm++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                S[TILE_ROW(m, r) * SD + TILE_COL(n)] = -xi[m][n][r];
-                T[TILE_ROW(m, r) * SD + TILE_COL(n)] = xk[m][n][r];
+                S[TILE_ROW(mm, r) * SD + TILE_COL(n)] = -xi[mm][n][r];
+                T[TILE_ROW(mm, r) * SD + TILE_COL(n)] = xk[mm][n][r];
             }
     __syncthreads();
     SSTAMP(7);
     tile64_mma_nt<SD>(S, T, c);
     SSTAMP(8);
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int mm = 0; mm < 2; mm++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = c[m][n][r];
+            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] = c[mm][n][r];
     SSTAMP(9);
 }
 
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
 __global__ __launch_bounds__(256) void chol_trsm_kernel(double *L, int Npad, int jb,
                                                         const double *__restrict__ diag64,
-                                                        size_t lstride, size_t dstride, double *Lout)
+                                                        size_t lstride, size_t dstride, double *Lout, int row0 = -1)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
     L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
     if (!Lout) Lout = L; else Lout += blockIdx.z * lstride;
-    int ib = jb + 1 + blockIdx.x;
+    int ib = (row0 < 0 ? jb + 1 : row0) + blockIdx.x;      // row0: the E rows of the W = L^-1 ride-along start at 0
     const double *Ab = L + (size_t)ib * 64 * Npad + jb * 64;
     double *Ob = Lout + (size_t)ib * 64 * Npad + jb * 64;
     d2_t va[8], vb[8];
@@ -642,27 +670,66 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // Plain right-looking order with one fused launch per block column (chol_step_kernel): `work` holds the matrix
 // and is destroyed, the factor (lower blocks; the strict upper blocks are not touched) goes to `out`.
 // Bit-identical to launch_cholesky with panel = 1.
-int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s)
+int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s, double *Ework,
+                          double *Eout)
 {
     const int nb = Npad / 64;
     HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     for (int jb = 0; jb < nb; jb++) {
-        const int m = nb - jb - 1;
-        if (m > 0 && m * (m + 1) / 2 <= 256) {
+        const int m = nb - jb - 1, nchol = m * (m + 1) / 2;
+        const int nextra = (Ework && m > 0) ? (jb + 1) * m : 0;       // tiles of the W = L^-1 ride-along (chol_step_kernel)
+        int ridden = 0;
+        if (m > 0 && nchol <= 256) {
             // the trailing tiles fit on the chip at once: repeating the diagonal factorisation in each of them
-            // costs nothing and two launches disappear
-            hipLaunchKernelGGL(chol_step_kernel, dim3(m * (m + 1) / 2), dim3(256), 0, s, work, out, Npad, jb, diag64,
-                               info_dev);
+            // costs nothing and two launches disappear; spare CUs take extra tiles along
+            ridden = nextra < 256 - nchol ? nextra : 256 - nchol;
+            hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nchol + ridden), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                               info_dev, nchol, 0, Ework, Eout);
         } else {
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
                                (size_t)0, (size_t)0, out);
             if (m > 0) {
                 hipLaunchKernelGGL(chol_trsm_kernel, dim3(m), dim3(256), 0, s, work, Npad, jb, diag64, (size_t)0,
-                                   (size_t)0, out);
+                                   (size_t)0, out, -1);
                 launch_update(work, Npad, jb, jb + 1, jb + 1, nb, 1, 0, s, out);
             }
         }
+        // extra tiles that found no room read the block's inverse from diag64 (no second factorisation)
+        if (nextra > ridden)
+            hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nextra - ridden), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                               info_dev, 0, ridden, Ework, Eout);
+        // last block column of E: nothing trails it, its row blocks only need the multiplication by inv(L_jj)^T
+        if (Ework && m == 0)
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3(nb), dim3(256), 0, s, Ework, Npad, jb, diag64, (size_t)0, (size_t)0,
+                               Eout, 0);
     }
+    return (int)hipGetLastError();
+}
+
+// W[r][c] = Et[c][r] for c <= r, 0 above the diagonal (Et = (L^-1)^T from the ride-along; its blocks below the
+// diagonal were never written)
+__global__ void transpose_lower_kernel(const double *__restrict__ Et, double *__restrict__ W, int Npad)
+{
+    __shared__ double tile[64][65];
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 64;       // W block (row block y, column block x)
+    if (blockIdx.x > blockIdx.y) {
+        for (int e = threadIdx.x; e < 4096; e += 256) W[(size_t)(by + (e >> 6)) * Npad + bx + (e & 63)] = 0.0;
+        return;
+    }
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        tile[r][c] = Et[(size_t)(bx + r) * Npad + by + c];       // Et block (x, y)
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        W[(size_t)(by + r) * Npad + bx + c] = (bx + c <= by + r) ? tile[c][r] : 0.0;
+    }
+}
+
+int launch_transpose_lower(const double *Et, double *W, int Npad, hipStream_t s)
+{
+    hipLaunchKernelGGL(transpose_lower_kernel, dim3(Npad / 64, Npad / 64), dim3(256), 0, s, Et, W, Npad);
     return (int)hipGetLastError();
 }
 

@@ -891,7 +891,21 @@ def test_cholesky_panel_orders_agree(ibo):
     finally:
         _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 1))
     assert np.array_equal(fused.L, Lp) and np.array_equal(Ls[0], Lp)
-    assert np.array_equal(np.array(fused.posteriors(X[:7] + .01)), np.array(Wp))
+    # W = L^-1 comes out of the fused launches themselves (identity rows appended below the matrix) or, with
+    # chol_ride = 0 and beyond 24 block columns, from the recursive-doubling inversion: same W to rounding, and
+    # the latter is the very sequence the unfused path runs
+    close(np.array(fused.posteriors(X[:7] + .01)), np.array(Wp), rtol=1e-11, atol=1e-13)
+    _lib.check(_lib.lib.ibo_set_option(b"chol_ride", 0))
+    try:
+        noride = GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05)
+        assert np.array_equal(noride.L, Lp)
+        assert np.array_equal(np.array(noride.posteriors(X[:7] + .01)), np.array(Wp))
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"chol_ride", 1))
+    Wa = np.empty((1000, 1000)); Wb = np.empty((1000, 1000))
+    _lib.check(_lib.lib.ibo_gp_get_W(fused._handle(), _lib.dp(Wa))); _lib.check(_lib.lib.ibo_gp_get_W(noride._handle(), _lib.dp(Wb)))
+    close(Wa, Wb, rtol=1e-10, atol=1e-12)
+    assert np.all(np.triu(Wa, 1) == 0.0) and np.abs(Wa.dot(fused.L) - np.eye(1000)).max() < 1e-11
     thetas = np.exp(np.random.RandomState(3).uniform(np.log(.2), np.log(2), size=(7, 5)))
     vals, _ = nlml_grid(GaussianKernel_ard, thetas, X[:300], Y[:300], noise=.01)
     for b in (1, 2, 7):
