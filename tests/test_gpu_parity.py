@@ -684,6 +684,28 @@ def test_rccl_argmax_world_of_one(ibo):
     comm.close()
 
 
+def test_two_rank_rccl_bench_when_two_gpus_are_visible(ibo):
+    """RCCL with more than one rank: bench.py's own launcher on two GPUs (the candidate-sharded sweep with its
+    arg-max exchange, then the sharded C3 gallery and C5 grid of the `configs` block).  Needs two visible devices;
+    the single-GPU boxes skip it (the slot protocol itself runs on two and three gloo ranks in the CPU suite)."""
+    import json, os, subprocess, sys
+    from ibo_amd import _lib
+    from conftest import ROOT
+    if _lib.device_count() < 2:
+        pytest.skip("one GPU visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "IBO_COMM_ID_FILE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads(p.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 2 and j["rccl_nranks"] == 2 and j["value"] > 0
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert j["value"] > 1.5 * j1["value"]                                # weak scaling: two shards, one exchange per step
+    assert j["configs"]["c3_shard_sweep"]["value"] > 0 and j["configs"]["c5_nlml_grid"]["n_not_pd"] == 0
+
+
 def test_errors_are_loud(ibo):
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
