@@ -451,11 +451,17 @@ def worker(args):
                     fits["N%d_D%d" % (n, d)] = {"device_ms": ms, "host_to_ready_ms": float(np.median(host_ms)),
                                                 "roofline": roofline_mfma(f_fit(n, d), ms * 1e-3, flops_per_fit=f_fit(n, d),
                                                                           kernels="cov_matrix + chol_step/chol_* + trinv_* + pack_w + gemv")}
-                    # one more observation through addData (block extension of L and W, not a refit)
-                    xa = np.random.RandomState(8).rand(d)
-                    t0 = time.perf_counter()
-                    g.addData(xa, 0.0)
-                    fits["N%d_D%d" % (n, d)]["addData_1_point_ms"] = (time.perf_counter() - t0) * 1e3
+                    del g
+                    # one more observation through addData: an in-place extension of L, W and the packed copies
+                    # (ibo_gp_extend) while the row padding has room -- reserve_rows keeps some -- else a refit
+                    g = GaussianProcess(kern, Xf, Yf, noise=.1, device=local_rank, reserve_rows=8)
+                    xa = np.random.RandomState(8).rand(3, d)
+                    ext = []
+                    for q in range(3):
+                        t0 = time.perf_counter()
+                        g.addData(xa[q], 0.0)
+                        ext.append((time.perf_counter() - t0) * 1e3)
+                    fits["N%d_D%d" % (n, d)]["addData_1_point_ms"] = float(np.median(ext))
                     del g
                 cfgs["gp_fit"] = fits
             # C3: this rank's 2^19-candidate shard (at 8 GPUs this IS BASELINE configs[2])

@@ -489,8 +489,8 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
     }
 }
 
-int g_sweep_variant = 4;     // 4 (default): sweep2_kernel (sweep2.hip) where the dot form is admissible.  sweep_mfma_kernel <NW,RBW,CBW,KCH>:
-                             // 0: <16,2,4,32>  1: <8,4,4,32>  2: <16,2,4,64> (default of this kernel)  3: <16,4,2,64>  (ibo_set_option("sweep_variant"))
+int g_sweep_variant = 4;     // 4 (default): sweep2_kernel (sweep2.hip) where the dot form is admissible and the alpha vectors fit its LDS;
+                             // anything else: sweep_mfma_kernel<16,2,4,64> for every large batch  (ibo_set_option("sweep_variant"))
 
 template <int FAM, int NW, int RBW, int CBW, int KCH, bool DOT>
 static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)
@@ -505,9 +505,8 @@ static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 template <int FAM, bool DOT>
 static int launch_mfma_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
-    if (g_sweep_variant == 1) return launch_mfma_cfg<FAM, 8, 4, 4, 32, DOT>(a, ntiles, s);
-    if (g_sweep_variant == 0) return launch_mfma_cfg<FAM, 16, 2, 4, 32, DOT>(a, ntiles, s);
-    if (g_sweep_variant == 3) return launch_mfma_cfg<FAM, 16, 4, 2, 64, DOT>(a, ntiles, s);
+    // <16 waves, 2 row-blocks x 4 candidate-blocks per wave, 64-row stages> (the tile shapes <16,2,4,32>, <8,4,4,32> and
+    // <16,4,2,64> of round 1 measured 66-75 % against this one's 79 % and are gone)
     return launch_mfma_cfg<FAM, 16, 2, 4, 64, DOT>(a, ntiles, s);
 }
 
