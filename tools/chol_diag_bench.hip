@@ -1,6 +1,7 @@
 // Diagnostic: per-segment cycle stamps of chol_diag_kernel (built with -DIBO_STAMPS) on one 64x64 block.
 //   hipcc --offload-arch=gfx950 -O3 -DIBO_STAMPS -I ibo_amd/csrc tools/chol_diag_bench.hip -o tools/chol_diag_bench
 #include "../ibo_amd/csrc/linalg.hip"
+#include "../ibo_amd/csrc/update2.hip"
 #include <cstdio>
 #include <vector>
 int main()
@@ -43,7 +44,8 @@ int main()
             hipMemcpy(dW, M.data(), sizeof(double) * Np * Np, hipMemcpyHostToDevice);
             hipMemset(dinfo, 0, 4);
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(chol_step_kernel, dim3(15 * 16 / 2), dim3(256), 0, 0, dW, dO, Np, 0, d64, dinfo);
+            hipLaunchKernelGGL(chol_step_kernel<false>, dim3(15 * 16 / 2), dim3(256), 0, 0, dW, dO, Np, 0, d64, dinfo, 15 * 16 / 2, 0,
+                               (double *)nullptr, (double *)nullptr);
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
