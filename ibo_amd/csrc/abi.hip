@@ -51,6 +51,8 @@ void ibo_internal_set_error(const char *msg)
 extern int g_sweep_variant;     // sweep.hip
 static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
+static int g_zero_copy = 1;      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
+static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
 static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
@@ -182,6 +184,7 @@ struct ibo_gp {
     DevBuf<int64_t> parti, res_i;
     // kept sweep state (ibo_acq_sweep_incremental): (q, aY.k*, a1.k*) per candidate of ONE device candidate array
     DevBuf<double> state;
+    DevBuf<double> small_ws;        // small2.hip: k* in fragment order + partial sums of a small batch
     const double *st_cand = nullptr; int64_t st_M = 0; int st_N = 0; double st_sf2 = 0.0; unsigned st_epoch = 0;
     unsigned fit_epoch = 0;         // bumped by every full fit: a kept state never survives one
     int reserve = 0;                // rows of head-room the next fit leaves for ibo_gp_extend (ibo_gp_reserve)
@@ -224,6 +227,8 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_update2")) { set_chol_update2(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_ride")) { g_chol_ride = value; return IBO_OK; }
+    if (key && !strcmp(key, "small2")) { g_small2 = value; return IBO_OK; }
+    if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
@@ -311,7 +316,7 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->Xp.release(); g->Xs.release(); g->ak.release(); g->XA.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
     g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
-    g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release();
+    g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release(); g->small_ws.release();
     if (g->pin) (void)hipHostFree(g->pin);
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
     (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
@@ -788,7 +793,7 @@ static int exp_table(int device, const double **out)
 static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
                      double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,
                      int64_t index_base, double *mu_dev, double *s2_dev, double *acq_dev,
-                     double *best_val, int64_t *best_idx, bool incremental = false)
+                     double *best_val, int64_t *best_idx, bool incremental = false, bool timed = true)
 {
     if (!g->fitted) return fail(IBO_ERR_STATE, "sweep before a successful fit");
     if (M < 1 || !cand_dev) return fail(IBO_ERR_ARG, "empty candidate set");
@@ -824,7 +829,15 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     // small batches: spread the IBO_SPLIT_PANEL-row panels over the grid too (one tile per 64 candidates alone
     // would leave most of the 256 CUs idle); above ~128 tiles the plain kernel fills the chip
     bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256));
-    if (split) {
+    // batches up to 4096 candidates where the dot form holds: three short kernels spread over the chip (small2.hip;
+    // from ~8192 candidates on the panel-split kernel's tiles fill the chip by themselves and it is the faster one)
+    const bool small2 = split && g_force_path == 0 && g_small2 && M <= 4096 && a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad);
+    if (small2) {
+        IBO_TRY(exp_table(g->device, &a.exp_tab));
+        IBO_TRY(g->small_ws.ensure(small_sweep_workspace(g->Npad, M)));
+        KERNEL_TRY(launch_sweep_small(a, g->small_ws.p, s, timed ? g->ev0 : nullptr, timed ? g->ev1 : nullptr));
+        g->sweep_kernel = "wk_small_kernel";
+    } else if (split) {
         IBO_TRY(g->qpart.ensure((size_t)((g->Npad + IBO_SPLIT_PANEL - 1) / IBO_SPLIT_PANEL) * M)); IBO_TRY(g->mupart.ensure(2 * (size_t)M));
         a.qpart = g->qpart.p; a.mupart = g->mupart.p;
         KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
@@ -1003,17 +1016,34 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     hipStream_t s = g->stream;
     double *pin_in = g->pin, *pin_out = g->pin + (size_t)M * g->D;
     memcpy(pin_in, Q_host, sizeof(double) * M * g->D);
-    HIP_TRY(hipMemcpyAsync(g->cand.p, pin_in, sizeof(double) * M * g->D, hipMemcpyHostToDevice, s));
-    // outputs are contiguous on the device in the order (mu, s2, acq) restricted to the wanted ones
+    // Batches of at most 8192 points skip the copy launches altogether: pinned host memory is device-visible, the
+    // kernels read the few KB of candidates from it and store the results into it (two ~10 us launches per batch).
+    const bool zero_copy = M <= 8192 && g_zero_copy;
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(g->cand.p, pin_in, sizeof(double) * M * g->D, hipMemcpyHostToDevice, s));
+    // outputs are contiguous in the order (mu, s2, acq) restricted to the wanted ones
     int nout = 0;
+    double *obase = zero_copy ? pin_out : g->outs.p;
     double *dmu = nullptr, *ds2 = nullptr, *dacq = nullptr;
-    if (mu_host) dmu = g->outs.p + (size_t)M * nout++;
-    if (s2_host) ds2 = g->outs.p + (size_t)M * nout++;
-    if (acq_host) dacq = g->outs.p + (size_t)M * nout++;
-    IBO_TRY(run_sweep(g, M, g->cand.p, acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
-                      nullptr, nullptr));
-    HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (mu_host) dmu = obase + (size_t)M * nout++;
+    if (s2_host) ds2 = obase + (size_t)M * nout++;
+    if (acq_host) dacq = obase + (size_t)M * nout++;
+    IBO_TRY(run_sweep(g, M, zero_copy ? pin_in : g->cand.p, acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
+                      nullptr, nullptr, false, !zero_copy));        // small batches: no kernel-time events either
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
+    if (zero_copy) {
+        // a batch of this size is back in tens of microseconds: poll the completion event for a moment before handing the
+        // thread to the runtime's blocking wait (whose wake-up alone costs about as much as the batch)
+        HIP_TRY(hipEventRecord(g->fit1, s));
+        struct timespec w0, w1;
+        clock_gettime(CLOCK_MONOTONIC, &w0);
+        for (;;) {
+            hipError_t q = hipEventQuery(g->fit1);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIP_TRY(q);
+            clock_gettime(CLOCK_MONOTONIC, &w1);
+            if ((w1.tv_sec - w0.tv_sec) * 1e6 + (w1.tv_nsec - w0.tv_nsec) * 1e-3 > 300.0) { HIP_TRY(hipStreamSynchronize(s)); break; }
+        }
+    } else HIP_TRY(hipStreamSynchronize(s));
     nout = 0;
     if (mu_host) memcpy(mu_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
     if (s2_host) memcpy(s2_host, pin_out + (size_t)M * nout++, sizeof(double) * M);

@@ -197,7 +197,10 @@ int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
 // large batches, dot form: 32-candidate tiles, 1024-row panels, exponent GEMM on the MFMA unit (sweep2.hip)
 int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int launch_sweep2_refresh(const SweepArgs &a, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
-bool sweep2_fits(int Npad);      // its LDS budget holds both alpha vectors (N <= ~5000)
+bool sweep2_fits(int Npad);
+// small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
+int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+size_t small_sweep_workspace(int Npad, int64_t M);      // its LDS budget holds both alpha vectors (N <= ~5000)
 int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, int D, double *XA, hipStream_t s);
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 

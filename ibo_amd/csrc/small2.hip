@@ -1,0 +1,188 @@
+// small2.hip -- the sweep for small batches (16 < M <= 8192 candidates: DIRECT's ~100 batches of a few dozen
+// sample points per maximisation, posteriors of a few hundred points), second design.
+//
+// The panel-split form of sweep_mfma_kernel gives each 64-row panel of W to one workgroup, which regenerates k* for
+// all rows up to its diagonal and multiplies it alone: the workgroup of the last panel generates N rows and issues
+// N/4 MFMAs per wave on one CU while 200 CUs are idle -- 55-60 us at N = 2048 for a batch of 30 points.  Here the
+// batch goes through three short kernels, each spread over the chip:
+//   kstar_small_kernel   every (32-candidate tile, 128-row stage) pair is one workgroup: k* by the exponent GEMM and
+//                        the table exp of sweep2.hip, written to HBM in B-fragment order, plus that stage's part of the
+//                        two mean dot products;
+//   wk_small_kernel      every (tile, 16-row block of W) pair is one workgroup of 16 waves; wave w takes the 8-column
+//                        steps j = w, w+16, .. of the row-block (at most 16 steps = 64 MFMAs), the 16 partial V tiles
+//                        are summed through LDS in wave order, squared and reduced over the block's rows;
+//   small_finish_kernel  sums the row-blocks' q and the stages' mean parts in index order, then the acquisition.
+// All sums run in a fixed order (no atomics): the result does not depend on scheduling.  Candidates are read from,
+// and results written to, wherever the caller's pointers lead -- abi.hip passes pinned host memory, so a batch costs
+// no copy launches.
+#include "sweep2_dev.h"
+
+#define SM_TC 32                 // candidates per tile
+#define SM_NW 16
+
+// grid (ctiles, NA128 / 128); Kf[((ctile nk4 + s) 2 + cb) 64 + lane], nk4 = NA128 / 4; mupart[(stage 2 + which) Mp + c]
+template <int FAM, int KA4>
+__global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(SweepArgs a, double *__restrict__ Kf, double *__restrict__ mupart, int Mp)
+{
+    constexpr int KA = 4 * KA4;
+    __shared__ double lds_c[SM_TC * KA];
+    __shared__ double lds_tab[2048];
+    __shared__ double lds_al[2][128];
+    __shared__ double lds_m[2][SM_NW][16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ctile = blockIdx.x, t = blockIdx.y;
+    const int NA128 = (a.Npad + 127) & ~127;
+    lds_tab[tid] = a.exp_tab[tid];
+    lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
+    if (tid < 128) { lds_al[0][tid] = a.alphaY[t * 128 + tid]; lds_al[1][tid] = a.alpha1[t * 128 + tid]; }
+    s2_stage_candidates<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)ctile * SM_TC, lds_c);
+    const int rt = wave >> 1, gcb = wave & 1;
+    const int tile = t * 8 + rt;
+    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * KA + (lane >> 4)];
+    const double *xa = a.XA + (size_t)tile * KA4 * 64 + lane;
+    d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KA4; s++) y = mfma_f64(xa[s * 64], cfrag[4 * s], y);
+    double muY = 0.0, mu1 = 0.0;
+    double *dst = Kf + (((size_t)ctile * (NA128 / 4) + tile * 4) * 2 + gcb) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double kv = s2_kstar<FAM>(y[r], a.kp.sf2, lds_tab);
+        const int kl = rt * 16 + 4 * r + (lane >> 4);
+        muY = fma(lds_al[0][kl], kv, muY);
+        mu1 = fma(lds_al[1][kl], kv, mu1);
+        dst[r * 128] = kv;
+    }
+    muY += __shfl_xor(muY, 16); muY += __shfl_xor(muY, 32);
+    mu1 += __shfl_xor(mu1, 16); mu1 += __shfl_xor(mu1, 32);
+    if (lane < 16) { lds_m[0][wave][lane] = muY; lds_m[1][wave][lane] = mu1; }
+    __syncthreads();
+    if (tid < 2 * SM_TC) {
+        const int which = tid >> 5, c = tid & 31;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_NW / 2; w++) s += lds_m[which][2 * w + (c >> 4)][c & 15];
+        mupart[(size_t)(t * 2 + which) * Mp + ctile * SM_TC + c] = s;
+    }
+}
+
+// grid (ctiles, Npad / 16); qpart[g Mp + c] = sum over the 16 rows of row-block g of (W K*)^2
+__global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const double *__restrict__ Kf, double *__restrict__ qpart, int Mp)
+{
+    __shared__ double lds_v[SM_NW][2][256];          // partial V tiles: [wave][cand-block][lane 64 x 4]
+    __shared__ double lds_s[SM_TC][17];              // squared sums [cand][row]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ctile = blockIdx.x, g = blockIdx.y;
+    const int Npad = a.Npad, nk8 = Npad >> 3, NA128 = (Npad + 127) & ~127;
+    const int nsteps = 2 * g + 2;                    // 8-column steps in which row-block g has non-zeros
+    const double2 *Wp2 = (const double2 *)a.Wp + (size_t)g * nk8 * 64 + lane;
+    const double *Kb = Kf + (size_t)ctile * (NA128 / 4) * 128 + lane;
+    d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // this wave's steps j = wave, wave + 16, ..: every operand of a step is requested before the previous step's MFMAs
+    double2 av = {0.0, 0.0};
+    double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
+    int j = wave;
+    if (j < nsteps) {
+        av = Wp2[(size_t)j * 64];
+        b00 = Kb[(size_t)(2 * j) * 128]; b01 = Kb[(size_t)(2 * j) * 128 + 64];
+        b10 = Kb[(size_t)(2 * j + 1) * 128]; b11 = Kb[(size_t)(2 * j + 1) * 128 + 64];
+    }
+    while (j < nsteps) {
+        const int jn = j + SM_NW;
+        double2 avn = av;
+        double n00 = 0.0, n01 = 0.0, n10 = 0.0, n11 = 0.0;
+        if (jn < nsteps) {
+            avn = Wp2[(size_t)jn * 64];
+            n00 = Kb[(size_t)(2 * jn) * 128]; n01 = Kb[(size_t)(2 * jn) * 128 + 64];
+            n10 = Kb[(size_t)(2 * jn + 1) * 128]; n11 = Kb[(size_t)(2 * jn + 1) * 128 + 64];
+        }
+        acc0 = mfma_f64(av.x, b00, acc0); acc1 = mfma_f64(av.x, b01, acc1);
+        acc0 = mfma_f64(av.y, b10, acc0); acc1 = mfma_f64(av.y, b11, acc1);
+        av = avn; b00 = n00; b01 = n01; b10 = n10; b11 = n11;
+        j = jn;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { lds_v[wave][0][lane * 4 + r] = acc0[r]; lds_v[wave][1][lane * 4 + r] = acc1[r]; }
+    __syncthreads();
+    if (tid < 512) {
+        // element e of candidate block cb: lane l = e >> 2, r = e & 3 -> row (l >> 4) + 4 r, candidate 16 cb + (l & 15)
+        const int cb = tid >> 8, e = tid & 255, l = e >> 2, r = e & 3;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_NW; w++) v += lds_v[w][cb][e];
+        lds_s[16 * cb + (l & 15)][(l >> 4) + 4 * r] = v * v;
+    }
+    __syncthreads();
+    if (tid < SM_TC) {
+        double q = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) q += lds_s[tid][rr];
+        qpart[(size_t)g * Mp + ctile * SM_TC + tid] = q;
+    }
+}
+
+// one thread per candidate: q over the row-blocks, the mean parts over the stages (index order), the acquisition
+__global__ __launch_bounds__(64) void small_finish_kernel(SweepArgs a, const double *__restrict__ qpart, const double *__restrict__ mupart, int Mp,
+                                                          int nrb, int nst)
+{
+    const int lane = threadIdx.x;
+    const int64_t li = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = li < a.M;
+    const int64_t ci = valid ? li : a.M - 1;
+    double q = 0.0, my = 0.0, m1 = 0.0;
+    for (int g = 0; g < nrb; g++) q += qpart[(size_t)g * Mp + ci];
+    for (int t = 0; t < nst; t++) { my += mupart[(size_t)(2 * t) * Mp + ci]; m1 += mupart[(size_t)(2 * t + 1) * Mp + ci]; }
+    bool excl;
+    double val = s2_finish(a, a.cand + ci * a.kp.D, q, my, m1, li, valid, excl);
+    int64_t idx = a.index_base + li;
+    if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(val, o);
+        const int64_t oi = __shfl_xor(idx, o);
+        if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+    }
+    if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+}
+
+template <int FAM>
+static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, int Mp, dim3 grid, hipStream_t s)
+{
+    switch ((a.kp.D + 2 + 3) / 4) {
+    case 1: hipLaunchKernelGGL((kstar_small_kernel<FAM, 1>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
+    case 2: hipLaunchKernelGGL((kstar_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
+    case 3: hipLaunchKernelGGL((kstar_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
+    case 4: hipLaunchKernelGGL((kstar_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
+    default: hipLaunchKernelGGL((kstar_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
+    }
+    return (int)hipGetLastError();
+}
+
+// doubles of workspace: Kf (Mp NA128) + qpart (Npad/16 Mp) + mupart (2 NA128/128 Mp), Mp = M rounded up to 32
+size_t small_sweep_workspace(int Npad, int64_t M)
+{
+    const size_t Mp = (size_t)((M + SM_TC - 1) / SM_TC) * SM_TC, NA128 = (size_t)((Npad + 127) & ~127);
+    return Mp * NA128 + (size_t)(Npad / 16) * Mp + 2 * (NA128 / 128) * Mp;
+}
+
+int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int Mp = (int)((a.M + SM_TC - 1) / SM_TC) * SM_TC, ctiles = Mp / SM_TC;
+    const int NA128 = (a.Npad + 127) & ~127, nst = NA128 / 128, nrb = a.Npad / 16;
+    double *Kf = ws, *qpart = Kf + (size_t)Mp * NA128, *mupart = qpart + (size_t)nrb * Mp;
+    if (e0) (void)hipEventRecord(e0, s);
+    int rc;
+    const dim3 g1(ctiles, nst);
+    if (a.kp.family == FAM_SE) rc = launch_kstar_small<FAM_SE>(a, Kf, mupart, Mp, g1, s);
+    else if (a.kp.family == FAM_M3) rc = launch_kstar_small<FAM_M3>(a, Kf, mupart, Mp, g1, s);
+    else rc = launch_kstar_small<FAM_M5>(a, Kf, mupart, Mp, g1, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(wk_small_kernel, dim3(ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
+    if (e1) (void)hipEventRecord(e1, s);
+    const int64_t nfin = (a.M + 63) / 64;
+    hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(64), 0, s, a, qpart, mupart, Mp, nrb, nst);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return launch_argmax_final(a, nfin, s);
+}

@@ -33,80 +33,7 @@
 #define S2_KCH 128                     // k* rows per LDS stage
 #define S2_PANEL 1024                  // rows of W per pass: 16 waves x 4 row-blocks x 16
 
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t s2_rsrc(const void *p, size_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
-}
-
-__device__ __forceinline__ double s2_ld_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return __hiloint2double((int)v.y, (int)v.x);
-}
-
-__device__ __forceinline__ double s2_lo(const v4u_t &v) { return __hiloint2double((int)v.y, (int)v.x); }
-__device__ __forceinline__ double s2_hi(const v4u_t &v) { return __hiloint2double((int)v.w, (int)v.z); }
-
-// exp(y) for the k* generation in 11 VALU instructions (exp_fast in ibo_common.h takes 17, the library ~30): every
-// VALU instruction here is paid in MFMA issue slots.  A 2048-entry table of 2^(j/2048) in LDS (reads are not VALU
-// instructions) shortens the polynomial to degree 3:
-//   t = y 2048/ln2 + 1.5 2^52 puts n = rint(y 2048/ln2) in the low mantissa bits of t; r = y - n ln2/2048, |r| <=
-//   1.7e-4 (r^4/24 < 4e-17); j = n mod 2048 indexes the table and v_ldexp_f64 applies n div 2048, flushing to zero
-//   what underflows.  One FMA forms r: the rounding of ln2/2048 costs |n| 2.7e-20 relative -- 2.4e-15 at y = -30
-//   where k* is already 1e-13, 5.6e-14 at the underflow threshold.  Relative error < 5e-16 for |y| < 10.
-//   Needs |y| < 7e5 (n must fit 32 bits): the kernel's prologue bounds the scaled candidates so that it holds.
-__device__ __forceinline__ double s2_exp(double y, const double *tab)
-{
-    const double magic = 6755399441055744.0;               // 1.5 * 2^52
-    const double t = fma(y, 2954.6394437405970584, magic);              // 2048 / ln 2
-    const double n = t - magic;
-    const double r = fma(n, -3.384507717577858e-04, y);                 // ln2 / 2048
-    const int ti = __double2loint(t);
-    const double T = *(const double *)((const char *)tab + ((ti << 3) & (2047 << 3)));
-    double p = fma(r, 1.0 / 6.0, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return __builtin_amdgcn_ldexp(T * p, ti >> 11);
-}
-
-// acquisition epilogue of one candidate; coordinates are read from global memory where needed (prior,
-// exclusion balls) so that no per-lane coordinate array exists (dynamic indexing would put it in scratch)
-__device__ __forceinline__ double s2_finish(const SweepArgs &a, const double *x, double q, double muY, double mu1,
-                                            int64_t li, bool valid, bool &excluded)
-{
-    const int D = a.kp.D;
-    double m = 0.0;
-    if (a.prior.nb > 0) {
-        for (int i = 0; i < a.prior.nb; i++) {
-            double d = 0.0;
-            for (int j = 0; j < D; j++) {
-                double t = (x[j] - a.prior.lowerb[j]) / a.prior.width[j] - a.prior.means[(size_t)i * D + j];
-                d += t * t;
-            }
-            m += a.prior.beta[i] * exp(-a.prior.theta * d);
-        }
-    }
-    const double mu = (a.prior.nb > 0) ? (m + muY - m * mu1) : muY;
-    double s2 = 1.0 + a.noise - q;
-    if (s2 < a.clamp_lo) s2 = a.clamp_lo;
-    else if (s2 > 10.0) s2 = 10.0;
-    const double val = (a.acq == 3) ? mu : acq_value_dev(a.acq, a.erf_mode, mu, sqrt(s2), a.ymax, a.parm);
-    excluded = false;
-    for (int e = 0; e < a.n_excl; e++) {
-        double d2 = 0.0;
-        for (int j = 0; j < D; j++) { double t = x[j] - a.excl[(size_t)e * D + j]; d2 += t * t; }
-        if (!(sqrt(d2) > a.excl_radius)) excluded = true;
-    }
-    if (valid) {
-        if (a.out_mu) a.out_mu[li] = mu;
-        if (a.out_s2) a.out_s2[li] = s2;
-        if (a.out_acq) a.out_acq[li] = val;
-    }
-    return val;
-}
+#include "sweep2_dev.h"
 
 // KA4 = ceil((D + 2) / 4): k4-steps of the exponent GEMM
 template <int FAM, int KA4>
