@@ -430,6 +430,45 @@ def test_sweep2_kernel_against_oracle_and_the_other_kernels(ibo, oracle):
         _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 0))
 
 
+def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
+    """batches of 17..4096 candidates (DIRECT's, posteriors of a few hundred points) run through small2.hip's three
+    kernels: values against the CPU oracle, the panel-split kernel and the GEMV kernel; DIRECT takes the same samples
+    whichever of them evaluates its batches"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.acquisition import sweep, gpuDirectGP
+    opt = lambda k, v: _lib.check(_lib.lib.ibo_set_option(k, v))
+    try:
+        for N, D, kern, (okind, ohyp), M in ((1024, 4, K.GaussianKernel_ard([.3] * 4), ("ard", [.3] * 4), 57), (200, 3, K.GaussianKernel_iso([.4]), ("iso", [.4]), 17),
+                                             (1000, 6, K.MaternKernel3([.6, 1.0]), ("m3", [.6, 1.0]), 600), (2048, 8, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0]), 31),
+                                             (1500, 5, K.GaussianKernel_ard([.3] * 5), ("ard", [.3] * 5), 4096), (1100, 16, K.GaussianKernel_ard([.9] * 16), ("ard", [.9] * 16), 333)):
+            X, Y = synth(N + D, N, D)
+            GP = GaussianProcess(kern, X, Y, noise=.1)
+            cand = np.random.RandomState(N).rand(M, D); cand[7] = X[5]
+            opt(b"small2", 1); r = sweep(GP, cand, outputs=("mu", "s2", "acq"))
+            assert r["kernel"] == "wk_small_kernel"
+            opt(b"small2", 0); r0 = sweep(GP, cand, outputs=("mu", "s2", "acq"))
+            assert r0["kernel"] == "sweep_mfma_kernel<split>" and r0["best_idx"] == r["best_idx"]
+            opt(b"sweep_path", 1); rg = sweep(GP, cand[:40], outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
+            for k in ("mu", "s2", "acq"):
+                close(r[k], r0[k], rtol=1e-9, atol=1e-11); close(r[k][:40], rg[k], rtol=1e-9, atol=1e-11)
+            ogp = oracle.GP(oracle.Kern(okind, ohyp), X, Y, noise=.1)
+            idx = np.arange(0, M, max(1, M // 30))
+            o = oracle.sweep_native(ogp, cand[idx], oracle.ACQ_EI, .01)
+            close(r["mu"][idx], o["mu"], atol=1e-9); close(r["s2"][idx], o["s2"]); close(r["acq"][idx], o["acq"], atol=ACQ_ATOL)
+        X, Y = synth(21, 300, 3)
+        GP = GaussianProcess(K.GaussianKernel_ard([.25, .3, .35]), X, Y)
+        runs = []
+        for s2, zc in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            opt(b"small2", s2); opt(b"zero_copy", zc)
+            runs.append(gpuDirectGP(GP, [[0., 1.]] * 3, 30, 30, 10000, acqfunc='ei', xi=.01, return_samples=True))
+        for v, x, ns in runs[1:]:
+            assert ns == runs[0][2] and np.array_equal(x, runs[0][1]); close(v, runs[0][0], rtol=1e-9)
+    finally:
+        opt(b"small2", 1); opt(b"zero_copy", 1); opt(b"sweep_path", 0)
+
+
 def test_incremental_sweep_state_equals_full_sweeps(ibo):
     """sweep(incremental=True) on a fixed candidate array while the model grows by addData (the gallery's rounds):
     every round's per-candidate mu / s2 / EI and arg-max equal a full sweep of a freshly fitted model -- values at
