@@ -31,12 +31,13 @@ LinAlgError = np.linalg.LinAlgError
 # The device twin is erf_nr_dev in csrc/ibo_common.h.
 # ---------------------------------------------------------------------------
 def erf(z):
-    t = 1.0 / (1.0 + 0.5 * abs(z))
+    """works on scalars and on arrays (the preference GP evaluates it for every pair at once)"""
+    t = 1.0 / (1.0 + 0.5 * np.abs(z))
     poly = 0.17087277
     for c in (-0.82215223, 1.48851587, -1.13520398, 0.27886807, -0.18628806, 0.09678418, 0.37409196, 1.00002368):
         poly = c + t * poly
     ans = 1 - t * np.exp(-z * z - 1.26551223 + t * poly)
-    return ans if z >= 0.0 else -ans
+    return np.where(np.asarray(z) >= 0.0, ans, -ans) if np.ndim(z) else (ans if z >= 0.0 else -ans)
 
 
 def CDF(x):
@@ -224,9 +225,9 @@ class GaussianProcess(object):
                 yd = mu - ym - parm
                 Z = yd / sig
                 if acq == _lib.ACQ_PI:
-                    val = np.array([CDF(float(z)) for z in Z])
+                    val = CDF(Z)
                 else:
-                    val = np.array([float(d) * CDF(float(z)) + float(s) * PDF(float(z)) for d, z, s in zip(yd, Z, sig)])
+                    val = yd * CDF(Z) + sig * PDF(Z)
             return {"mu": mu, "s2": s2, "acq": val, "best_val": float(np.max(val)), "best_idx": int(np.argmax(val))}
         cand = _lib.DeviceArray.from_host(Q, self._dev.device)
         outs = {k: _lib.DeviceArray((M,), self._dev.device) for k in want}
@@ -363,7 +364,7 @@ class PrefGaussianProcess(GaussianProcess):
         (:351-385) with gradient and the per-pair Hessian weights.  Phi is the reference's CDF
         (NR erf, truncated 1/sqrt 2) so S is the same function; its derivative uses the exact pdf."""
         z = (y[v] - y[u]) / np.sqrt(2)
-        cdf = np.array([CDF(zz) for zz in z]) + 1e-10
+        cdf = CDF(z) + 1e-10
         t = z * 0.707106
         pdf = 0.707106 / np.sqrt(np.pi) * np.exp(-t * t)           # d CDF / dz
         Ry = Rinv.dot(y)
@@ -485,14 +486,16 @@ class PrefGaussianProcess(GaussianProcess):
         _lib.check(_lib.lib.ibo_gp_set_y(self._handle(), _lib.dp(_lib.f64(self.Y))))
         mu = self._posterior_arrays(self.X, getvar=False)[0]      # L = chol(R) at this point
         n = len(self.X)
+        # one weight per pair (all pairs at once), scattered into the four entries it touches; np.add.at keeps the
+        # reference's accumulation for points that occur in several pairs
+        pv = np.array([p[0] for p in prefinds], dtype=int); pu = np.array([p[1] for p in prefinds], dtype=int)
+        d = (mu[pv] - mu[pu]) / (np.sqrt(2) * np.sqrt(self.noise))
+        cdf = np.maximum(CDF(d), 1e-10)
+        pdf = np.maximum(PDF(d), 1e-10)
+        w = 1.0 / (2 * self.noise) * (pdf ** 2 / cdf ** 2 + d * pdf / cdf)
         C = np.eye(n) * 5
-        for v, u, _ in prefinds:
-            d = (mu[v] - mu[u]) / (np.sqrt(2) * np.sqrt(self.noise))
-            cdf = max(CDF(d), 1e-10)
-            pdf = max(PDF(d), 1e-10)
-            w = 1.0 / (2 * self.noise) * (pdf ** 2 / cdf ** 2 + d * pdf / cdf)
-            C[v, u] -= w; C[u, v] -= w
-            C[v, v] += w; C[u, u] += w
+        np.add.at(C, (pv, pu), -w); np.add.at(C, (pu, pv), -w)
+        np.add.at(C, (pv, pv), w); np.add.at(C, (pu, pu), w)
         self.C = C
         R = self.R.copy()
         for i in range(11):
