@@ -176,6 +176,35 @@ __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs
     }
 }
 
+// The same product when B (64x64, row-major in Bs) is LOWER TRIANGULAR -- the inverse of a diagonal factor: column
+// block cb of the result needs only k < 16 (cb + 1); the skipped terms are exact zeros, so the result equals the full
+// product's.  The waves' column blocks are (0, 3) and (1, 2) instead of (0, 1) and (2, 3): 40 MFMAs per wave either
+// way instead of 64.  Accumulator (m, n) is rows wr*32 + m*16.., columns 16 TRI_CB(n)...
+#define TRI_CB(n) (wc ? ((n) ? 2 : 1) : ((n) ? 3 : 0))
+template <int LD = T64_LD>
+__device__ __forceinline__ void tile64_mma_nt_tri(const double *As, const double *Bs, d4_t (&acc)[2][2])
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
+    const int cb0 = TRI_CB(0), cb1 = TRI_CB(1);
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4++) {
+        double a[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+        if (k4 < 4 * (cb0 + 1)) {
+            const double b = Bs[(cb0 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[m][0] = mfma_f64(a[m], b, acc[m][0]);
+        }
+        if (k4 < 4 * (cb1 + 1)) {
+            const double b = Bs[(cb1 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[m][1] = mfma_f64(a[m], b, acc[m][1]);
+        }
+    }
+}
+#define TILE_COL_TRI(n) (TRI_CB(n) * 16 + (lane & 15))
+
 // C[row][col] for accumulator element (m, n, r) of this lane
 #define TILE_ROW(m, r) (wr * 32 + (m) * 16 + (lane >> 4) + 4 * (r))
 #define TILE_COL(n) (wc * 32 + (n) * 16 + (lane & 15))
@@ -245,7 +274,7 @@ __device__ __forceinline__ double rcp_newton(double d)
     return fma(y, fma(-d, y, 1.0), y);
 }
 
-__device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *S, double *V)
+__device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *S, double *V, double *T)
 {
     const int t = threadIdx.x;
     double v[16];                          // all 16 loads in flight before the first LDS write
@@ -256,6 +285,9 @@ __device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *
         S[(4 * u + (t >> 6)) * SD + (t & 63)] = v[u];
         V[(4 * u + (t >> 6)) * SD + (t & 63)] = 0.0;
     }
+#ifndef IBO_DIAG_V1
+    if (t < 256) T[(t >> 4) * SD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;       // diag64_dpp.h: the identity rows
+#endif
 }
 
 __device__ __forceinline__ void diag64_store(double *Lb, int Npad, double *Db, const double *S, const double *V)
@@ -269,6 +301,9 @@ __device__ __forceinline__ void diag64_store(double *Lb, int Npad, double *Db, c
     }
 }
 
+#ifndef IBO_DIAG_V1
+#include "diag64_dpp.h"
+#else          // round 1's chain (v_readlane broadcasts, all four inverses at the end): kept for tools/chol_diag_bench
 // S: the 64x64 block (row stride SD), V: zeros.  On return S holds the factor (lower triangle; the strict upper
 // part is scratch), V its inverse.  T is scratch.  Called by all 256 threads; ends with a barrier.
 __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info)
@@ -368,6 +403,7 @@ __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, doubl
     }
     __syncthreads();
 }
+#endif
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *L, int Npad, int jb,
                                                         double *__restrict__ diag64, int *info,
@@ -380,7 +416,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *L, int Npad, int
     if (!Lout) Lout = L; else Lout += blockIdx.z * lstride;
     const size_t off = (size_t)jb * 64 * Npad + jb * 64;
     CSTAMP(31);
-    diag64_load(L + off, Npad, S, V);
+    diag64_load(L + off, Npad, S, V, T);
     CSTAMP(0);
     __syncthreads();
     CSTAMP(1);
@@ -455,7 +491,7 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
         tile64_fetch(diag64 + (size_t)jb * 4096, 64, vv);
         tile64_stash<false, SD>(V, vv);
     } else {
-        diag64_load(L + doff, Npad, S, V);
+        diag64_load(L + doff, Npad, S, V, T);
         __syncthreads();
         SSTAMP(1);
         diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
@@ -470,8 +506,8 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
     __syncthreads();
     SSTAMP(4);
     d4_t xi[2][2] = {}, xk[2][2] = {};
-    tile64_mma_nt<SD>(S, V, xi);
-    tile64_mma_nt<SD>(T, V, xk);
+    tile64_mma_nt_tri<SD>(S, V, xi);
+    tile64_mma_nt_tri<SD>(T, V, xk);
     SSTAMP(5);
     __syncthreads();
     SSTAMP(6);
@@ -481,7 +517,7 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
 #pragma unroll
             for (int n = 0; n < 2; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) Xi[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] = xi[mm][n][r];
+                for (int r = 0; r < 4; r++) Xi[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL_TRI(n)] = xi[mm][n][r];
     }
 #pragma unroll
     for (int mm = 0; mm < 2; mm++)
@@ -489,8 +525,8 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                S[TILE_ROW(mm, r) * SD + TILE_COL(n)] = -xi[mm][n][r];
-                T[TILE_ROW(mm, r) * SD + TILE_COL(n)] = xk[mm][n][r];
+                S[TILE_ROW(mm, r) * SD + TILE_COL_TRI(n)] = -xi[mm][n][r];
+                T[TILE_ROW(mm, r) * SD + TILE_COL_TRI(n)] = xk[mm][n][r];
             }
     __syncthreads();
     SSTAMP(7);
@@ -525,14 +561,14 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *L, int Npad, int
     tile64_stash(Bs, vb);
     __syncthreads();
     d4_t acc[2][2] = {};
-    tile64_mma_nt(As, Bs, acc);
+    tile64_mma_nt_tri(As, Bs, acc);
     // the tile is overwritten in place: it was read completely before the barrier
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(m, r) * Npad + TILE_COL(n)] = acc[m][n][r];
+            for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(m, r) * Npad + TILE_COL_TRI(n)] = acc[m][n][r];
 }
 
 // (amdgpu_waves_per_eu(2, 2) on the kernels with a K loop: with (1, 2) hipcc puts the accumulators in AGPRs and
