@@ -450,9 +450,8 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     if (fused) {
         // small enough for the plain right-looking order: one fused launch per block column, out of place, with
         // W = L^-1 riding along (E = I in W's buffer turns into (L^-1)^T in Wp's, then is transposed into W)
-        // up to 24 block columns nearly every step's extra tiles find idle CUs; beyond that the middle steps would need a
-        // second launch each and the recursive-doubling inversion (launch_trinv) is the shorter chain
-        const bool ride = g_chol_ride != 0 && Np / 64 <= 24;
+        // (a step's trailing + extra tiles number at most nb (nb - 1) / 2: 496 at N = 2048, two per workgroup)
+        const bool ride = g_chol_ride != 0;
         if (ride) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, g->W.p, Np, 1.0, s));       // identity
         KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s, ride ? g->W.p : nullptr,
                                          ride ? g->Wp.p : nullptr));

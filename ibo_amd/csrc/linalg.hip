@@ -181,27 +181,34 @@ __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs
 // product's.  The waves' column blocks are (0, 3) and (1, 2) instead of (0, 1) and (2, 3): 40 MFMAs per wave either
 // way instead of 64.  Accumulator (m, n) is rows wr*32 + m*16.., columns 16 TRI_CB(n)...
 #define TRI_CB(n) (wc ? ((n) ? 2 : 1) : ((n) ? 3 : 0))
+template <int LD, int CB0, int CB1>
+__device__ __forceinline__ void tile64_mma_nt_tri_body(const double *As, const double *Bs, d4_t (&acc)[2][2], int wr, int lane)
+{
+    // all fragments first (one LDS latency), then the MFMAs
+    double a[16][2], b0[4 * (CB0 + 1)], b1[4 * (CB1 + 1)];
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) a[k4][m] = As[(wr * 32 + m * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+        if (k4 < 4 * (CB0 + 1)) b0[k4] = Bs[(CB0 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+        b1[k4] = Bs[(CB1 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+        if (k4 < 4 * (CB0 + 1)) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[m][0] = mfma_f64(a[k4][m], b0[k4], acc[m][0]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) acc[m][1] = mfma_f64(a[k4][m], b1[k4], acc[m][1]);
+    }
+}
 template <int LD = T64_LD>
 __device__ __forceinline__ void tile64_mma_nt_tri(const double *As, const double *Bs, d4_t (&acc)[2][2])
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
-    const int cb0 = TRI_CB(0), cb1 = TRI_CB(1);
-#pragma unroll
-    for (int k4 = 0; k4 < 16; k4++) {
-        double a[2];
-#pragma unroll
-        for (int m = 0; m < 2; m++) a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
-        if (k4 < 4 * (cb0 + 1)) {
-            const double b = Bs[(cb0 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
-#pragma unroll
-            for (int m = 0; m < 2; m++) acc[m][0] = mfma_f64(a[m], b, acc[m][0]);
-        }
-        if (k4 < 4 * (cb1 + 1)) {
-            const double b = Bs[(cb1 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
-#pragma unroll
-            for (int m = 0; m < 2; m++) acc[m][1] = mfma_f64(a[m], b, acc[m][1]);
-        }
-    }
+    if (wc) tile64_mma_nt_tri_body<LD, 1, 2>(As, Bs, acc, wr, lane);
+    else tile64_mma_nt_tri_body<LD, 0, 3>(As, Bs, acc, wr, lane);
 }
 #define TILE_COL_TRI(n) (TRI_CB(n) * 16 + (lane & 15))
 
@@ -274,20 +281,31 @@ __device__ __forceinline__ double rcp_newton(double d)
     return fma(y, fma(-d, y, 1.0), y);
 }
 
-__device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *S, double *V, double *T)
+// the block's loads are issued by diag64_fetch and land in LDS by diag64_stash: a caller with more to request puts
+// its other loads between the two (loads return in order, so the block is waited for alone)
+__device__ __forceinline__ void diag64_fetch(const double *Lb, int Npad, double (&v)[16])
 {
     const int t = threadIdx.x;
-    double v[16];                          // all 16 loads in flight before the first LDS write
 #pragma unroll
     for (int u = 0; u < 16; u++) v[u] = Lb[(size_t)(4 * u + (t >> 6)) * Npad + (t & 63)];
+}
+__device__ __forceinline__ void diag64_stash(const double (&v)[16], double *S, double *V, double *T)
+{
+    const int t = threadIdx.x;
 #pragma unroll
     for (int u = 0; u < 16; u++) {
         S[(4 * u + (t >> 6)) * SD + (t & 63)] = v[u];
         V[(4 * u + (t >> 6)) * SD + (t & 63)] = 0.0;
     }
 #ifndef IBO_DIAG_V1
-    if (t < 256) T[(t >> 4) * SD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;       // diag64_dpp.h: the identity rows
+    T[(t >> 4) * SD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;       // diag64_dpp.h: the identity rows
 #endif
+}
+__device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *S, double *V, double *T)
+{
+    double v[16];
+    diag64_fetch(Lb, Npad, v);
+    diag64_stash(v, S, V, T);
 }
 
 __device__ __forceinline__ void diag64_store(double *Lb, int Npad, double *Db, const double *S, const double *V)
@@ -443,102 +461,132 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *L, int Npad, int
 // recursive-doubling inversion (2 log2(nb) launches after the factorisation) disappears.
 // Tiles >= nchol are extra tiles: number e -> (i = e / m, k = jb + 1 + e % m), A_i from Ework, X_i to Eout.
 // HAVE_V: the diagonal block was factored by an earlier launch; its inverse is read from diag64 instead.
+// A workgroup takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... < ntiles: with more tiles than CUs (N = 2048 with
+// the ride-along: up to 496) the second tile of a workgroup reuses the inverse that is already in its LDS -- its operands
+// are requested before the first tile's products start -- where a second launch would pay for launch, fetch and (without
+// diag64) the chain again.
 template <bool HAVE_V>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npad, int jb,
                       double *__restrict__ diag64, int *info, int nchol, int extra0, double *__restrict__ Ework,
-                      double *__restrict__ Eout)
+                      double *__restrict__ Eout, int ntiles)
 {
     __shared__ double S[64 * SD];
     __shared__ double V[64 * SD];
     __shared__ double T[64 * SD];
     TILE_IDS;
     const int nb = Npad / 64, m = nb - jb - 1;
-    int i, k;
-    const double *Ai;
-    double *Xi, *C;
-    if ((int)blockIdx.x < nchol) {
-        k = jb + 1;
-        int rem = blockIdx.x;
-        while (rem >= nb - k) { rem -= nb - k; k++; }
-        i = k + rem;
-        Ai = L + (size_t)i * 64 * Npad + jb * 64;
-        Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
-        C = L + (size_t)i * 64 * Npad + k * 64;
-    } else {
-        const int e = (int)blockIdx.x - nchol + extra0;
-        i = e / m; k = jb + 1 + e % m;
-        Ai = Ework + (size_t)i * 64 * Npad + jb * 64;
-        Xi = Eout + (size_t)i * 64 * Npad + jb * 64;
-        C = Ework + (size_t)i * 64 * Npad + k * 64;
-    }
+    struct Tile { int k; const double *Ai, *Ak; double *Xi, *C; };
+    auto decode = [&](int t) {
+        Tile q;
+        int i;
+        if (t < nchol) {
+            q.k = jb + 1;
+            int rem = t;
+            while (rem >= nb - q.k) { rem -= nb - q.k; q.k++; }
+            i = q.k + rem;
+            q.Ai = L + (size_t)i * 64 * Npad + jb * 64;
+            q.Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
+            q.C = L + (size_t)i * 64 * Npad + q.k * 64;
+        } else {
+            const int e = t - nchol + extra0;
+            i = e / m; q.k = jb + 1 + e % m;
+            q.Ai = Ework + (size_t)i * 64 * Npad + jb * 64;
+            q.Xi = Eout + (size_t)i * 64 * Npad + jb * 64;
+            q.C = Ework + (size_t)i * 64 * Npad + q.k * 64;
+        }
+        q.Ak = L + (size_t)q.k * 64 * Npad + jb * 64;
+        return q;
+    };
+    auto fetch = [&](const Tile &q, d2_t (&va)[8], d2_t (&vb)[8], d4_t (&c)[2][2]) {
+        tile64_fetch(q.Ai, Npad, va);
+        tile64_fetch(q.Ak, Npad, vb);
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) c[mm][n][r] = q.C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)];
+    };
     const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
-    const double *Ak = L + (size_t)k * 64 * Npad + jb * 64;
+    int t = blockIdx.x;
+    Tile cur = decode(t);
     // everything this workgroup will need from memory is requested before the chain starts
     SSTAMP(0);
+    double vd[16];
+    d2_t vv[8];
+    if (HAVE_V) tile64_fetch(diag64 + (size_t)jb * 4096, 64, vv);
+    else diag64_fetch(L + doff, Npad, vd);              // first: the chain starts when these are back
     d2_t va[8], vb[8];
-    tile64_fetch(Ai, Npad, va);
-    tile64_fetch(Ak, Npad, vb);
     d4_t c[2][2];
-#pragma unroll
-    for (int mm = 0; mm < 2; mm++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) c[mm][n][r] = C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)];
+    fetch(cur, va, vb, c);
     if (HAVE_V) {
-        d2_t vv[8];
-        tile64_fetch(diag64 + (size_t)jb * 4096, 64, vv);
         tile64_stash<false, SD>(V, vv);
     } else {
-        diag64_load(L + doff, Npad, S, V, T);
+        diag64_stash(vd, S, V, T);
         __syncthreads();
         SSTAMP(1);
         diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
         SSTAMP(2);
         if (blockIdx.x == 0) diag64_store(Lout + doff, Npad, diag64 + (size_t)jb * 4096, S, V);
     }
-    __syncthreads();                                   // S is about to be reused
-    SSTAMP(3);
-    // X_i = A_i V^T, X_k = A_k V^T  (V[c][k] row-major is the "B^T" operand as it stands)
-    tile64_stash<false, SD>(S, va);
-    tile64_stash<false, SD>(T, vb);
-    __syncthreads();
-    SSTAMP(4);
-    d4_t xi[2][2] = {}, xk[2][2] = {};
-    tile64_mma_nt_tri<SD>(S, V, xi);
-    tile64_mma_nt_tri<SD>(T, V, xk);
-    SSTAMP(5);
-    __syncthreads();
-    SSTAMP(6);
-    if (k == jb + 1) {                                 // first trailing column: this row block of L is final
+    for (;;) {
+        __syncthreads();                                   // S (and T) are about to be reused
+        SSTAMP(3);
+        // X_i = A_i V^T, X_k = A_k V^T  (V[c][k] row-major is the "B^T" operand as it stands)
+        tile64_stash<false, SD>(S, va);
+        tile64_stash<false, SD>(T, vb);
+        const int tn = t + gridDim.x;
+        const bool more = tn < ntiles;
+        Tile nxt = cur;
+        d4_t cn[2][2];
+        if (more) {                                        // the next tile's operands travel during this tile's products
+            nxt = decode(tn);
+            fetch(nxt, va, vb, cn);
+        }
+        __syncthreads();
+        SSTAMP(4);
+        d4_t xi[2][2] = {}, xk[2][2] = {};
+        tile64_mma_nt_tri<SD>(S, V, xi);
+        tile64_mma_nt_tri<SD>(T, V, xk);
+        SSTAMP(5);
+        __syncthreads();
+        SSTAMP(6);
+        if (cur.k == jb + 1) {                             // first trailing column: this row block of L is final
+#pragma unroll
+            for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) cur.Xi[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL_TRI(n)] = xi[mm][n][r];
+        }
 #pragma unroll
         for (int mm = 0; mm < 2; mm++)
 #pragma unroll
             for (int n = 0; n < 2; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) Xi[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL_TRI(n)] = xi[mm][n][r];
+                for (int r = 0; r < 4; r++) {
+                    S[TILE_ROW(mm, r) * SD + TILE_COL_TRI(n)] = -xi[mm][n][r];
+                    T[TILE_ROW(mm, r) * SD + TILE_COL_TRI(n)] = xk[mm][n][r];
+                }
+        __syncthreads();
+        SSTAMP(7);
+        tile64_mma_nt<SD>(S, T, c);
+        SSTAMP(8);
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) cur.C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] = c[mm][n][r];
+        SSTAMP(9);
+        if (!more) break;
+        t = tn; cur = nxt;
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) c[mm][n] = cn[mm][n];
     }
-#pragma unroll
-    for (int mm = 0; mm < 2; mm++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                S[TILE_ROW(mm, r) * SD + TILE_COL_TRI(n)] = -xi[mm][n][r];
-                T[TILE_ROW(mm, r) * SD + TILE_COL_TRI(n)] = xk[mm][n][r];
-            }
-    __syncthreads();
-    SSTAMP(7);
-    tile64_mma_nt<SD>(S, T, c);
-    SSTAMP(8);
-#pragma unroll
-    for (int mm = 0; mm < 2; mm++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] = c[mm][n][r];
-    SSTAMP(9);
 }
 
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
@@ -710,17 +758,19 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
                           double *Eout)
 {
     const int nb = Npad / 64;
+    const int CU = 256, MAXT = 2 * CU;                  // tiles one fused launch takes: two per workgroup
     HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     for (int jb = 0; jb < nb; jb++) {
         const int m = nb - jb - 1, nchol = m * (m + 1) / 2;
         const int nextra = (Ework && m > 0) ? (jb + 1) * m : 0;       // tiles of the W = L^-1 ride-along (chol_step_kernel)
         int ridden = 0;
-        if (m > 0 && nchol <= 256) {
-            // the trailing tiles fit on the chip at once: repeating the diagonal factorisation in each of them
-            // costs nothing and two launches disappear; spare CUs take extra tiles along
-            ridden = nextra < 256 - nchol ? nextra : 256 - nchol;
-            hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nchol + ridden), dim3(256), 0, s, work, out, Npad, jb, diag64,
-                               info_dev, nchol, 0, Ework, Eout);
+        if (m > 0 && nchol <= MAXT) {
+            // the trailing tiles fit on the chip (two rounds at most): repeating the diagonal factorisation in each
+            // workgroup costs nothing and two launches disappear; extra tiles come along
+            ridden = nextra < MAXT - nchol ? nextra : MAXT - nchol;
+            const int nt = nchol + ridden;
+            hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < CU ? nt : CU), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                               info_dev, nchol, 0, Ework, Eout, nt);
         } else {
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
                                (size_t)0, (size_t)0, out);
@@ -731,9 +781,11 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
             }
         }
         // extra tiles that found no room read the block's inverse from diag64 (no second factorisation)
-        if (nextra > ridden)
-            hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nextra - ridden), dim3(256), 0, s, work, out, Npad, jb, diag64,
-                               info_dev, 0, ridden, Ework, Eout);
+        if (nextra > ridden) {
+            const int nt = nextra - ridden;
+            hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nt < CU ? nt : CU), dim3(256), 0, s, work, out, Npad, jb,
+                               diag64, info_dev, 0, ridden, Ework, Eout, nt);
+        }
         // last block column of E: nothing trails it, its row blocks only need the multiplication by inv(L_jj)^T
         if (Ework && m == 0)
             hipLaunchKernelGGL(chol_trsm_kernel, dim3(nb), dim3(256), 0, s, Ework, Npad, jb, diag64, (size_t)0, (size_t)0,

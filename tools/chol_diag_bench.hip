@@ -45,7 +45,7 @@ int main()
             hipMemset(dinfo, 0, 4);
             hipEventRecord(e0, 0);
             hipLaunchKernelGGL(chol_step_kernel<false>, dim3(15 * 16 / 2), dim3(256), 0, 0, dW, dO, Np, 0, d64, dinfo, 15 * 16 / 2, 0,
-                               (double *)nullptr, (double *)nullptr);
+                               (double *)nullptr, (double *)nullptr, 15 * 16 / 2);
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
