@@ -226,6 +226,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_update2")) { set_chol_update2(value); return IBO_OK; }
+    if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_ride")) { g_chol_ride = value; return IBO_OK; }
     if (key && !strcmp(key, "small2")) { g_small2 = value; return IBO_OK; }
     if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
@@ -1110,6 +1111,8 @@ extern "C" int ibo_direct_max(ibo_gp_t *g, int D, const double *lb, const double
 struct NlmlWorkspace {
     DevBuf<double> dX, dY, dout, dL, d64, dP;       // dP: packed panels of the trailing updates (update2.hip)
     DevBuf<int> dinfo;
+    const double *padded = nullptr;                 // dL as it was when its matrices got their identity pad,
+    int pad_Np = 0, pad_N = 0, pad_B = 0;           // and for which geometry
 };
 static NlmlWorkspace g_nlml_ws[16];
 struct GradWorkspace {
@@ -1123,6 +1126,7 @@ extern "C" int ibo_trim(int device)
     IBO_TRY(use_device(device));
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
     ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release();
+    ws.padded = nullptr;
     GradWorkspace &gw = g_grad_ws[device & 15];
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
     gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
@@ -1164,8 +1168,12 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     IBO_TRY(ws.dP.ensure(pws * B));
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
-    // identity pad once: the factorisation leaves the pad rows/columns as it found them
-    for (int k = 0; k < B; k++) KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p + nn * k, Np, 1.0, s));
+    // identity pad once: the factorisation leaves the pad rows/columns as it found them, so the workspace of an
+    // earlier call with the same geometry still has them (a learning loop calls this again and again)
+    if (ws.padded != dL.p || ws.pad_Np != Np || ws.pad_N != N || ws.pad_B < B) {
+        for (int k = 0; k < B; k++) KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p + nn * k, Np, 1.0, s));
+        ws.padded = dL.p; ws.pad_Np = Np; ws.pad_N = N; ws.pad_B = B;
+    }
     for (int t0 = 0; t0 < n_theta; t0 += B) {
         const int nb = n_theta - t0 < B ? n_theta - t0 : B;
         for (int k = 0; k < nb; k++) {

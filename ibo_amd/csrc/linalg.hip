@@ -630,14 +630,14 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double *L, int Npad, int
 // of tiles -- 16 operand strips of 64 x 64(j1-j0) serve 64 tiles out of L2 instead of being re-fetched
 // from the Infinity Cache (with the operands also kept out of scratch, K = 256 updates went from 18 to 35 TFLOP/s at N = 4096).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void chol_update_kernel(double *L, int Npad, int j0, int j1,
-                                                          int k0, int k1, int nsb, size_t lstride, const double *P)
+                                                          int k0, int k1, int nsb, size_t lstride, const double *P, int iend)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * T64_LD];
     TILE_IDS;
     L += blockIdx.z * lstride;
     if (!P) P = L; else P += blockIdx.z * lstride;          // where the finished block columns live
-    const int nb = Npad / 64;
+    const int nb = iend > 0 ? iend : Npad / 64;             // block rows [k, nb) of every block column k
     int i, k;
     if (nsb > 0) {
         const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -693,21 +693,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     USTAMP(20);
 }
 
-static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,
-                          hipStream_t s, const double *P = nullptr)
+// The rows below a panel of P <= 4 block columns [p0, pend) whose diagonal (64 P)^2 block is factored already: row block i
+// (one workgroup) turns its P blocks A_i,j into the factor's blocks
+//     X_i,j = (A_i,j - sum_{j' < j} X_i,j' L_j,j'^T) inv(L_jj)^T,   j = p0 .. pend-1,
+// the updates of a block applied in ascending j', each as 16 k4-steps on accumulators that start as the block -- the
+// arithmetic, in order, of the sequence "trsm of column j, K = 64 update of the panel's later columns" that it replaces
+// (bit-identical), without that sequence's 2 P - 1 launches over all rows and without its traffic: there every update
+// tile reads and writes 128 KB for half a megaflop; here a row block is read once and written once, and its operands
+// (6 blocks of the diagonal block, 4 inverses) are shared by all row blocks through L2.
+// LDS: -X_i,j' for the (at most 3) earlier columns, one stage for the L / inverse block of the product at hand.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void chol_panel_rows_kernel(double *L, int Npad, int p0, int pend, const double *__restrict__ diag64, size_t lstride,
+                            size_t dstride)
 {
-    const int nb = Npad / 64, nsr = (nb - k0 + 7) / 8, nsc = (k1 - k0 + 7) / 8;
+    __shared__ double Xs[3][64 * SD];
+    __shared__ double Bs[64 * SD];
+    TILE_IDS;
+    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
+    const int i = pend + blockIdx.x, P = pend - p0;
+    double *Ai = L + (size_t)i * 64 * Npad + (size_t)p0 * 64;
+    // operand blocks in the order they are used: (jj, jp < jj): L_{p0+jj, p0+jp};  (jj, jj): inv(L_{p0+jj})
+    auto fetch_b = [&](int jj, int jp, d2_t (&vb)[8]) {
+        if (jp < jj) tile64_fetch(L + (size_t)(p0 + jj) * 64 * Npad + (size_t)(p0 + jp) * 64, Npad, vb);
+        else tile64_fetch(diag64 + (size_t)(p0 + jj) * 4096, 64, vb);
+    };
+    auto load_acc = [&](int jj, d4_t (&acc)[2][2]) {
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[m][n][r] = Ai[(size_t)TILE_ROW(m, r) * Npad + jj * 64 + TILE_COL(n)];
+    };
+    d2_t vb[8];
+    d4_t acc[2][2], accn[2][2];
+    fetch_b(0, 0, vb);
+    load_acc(0, acc);
+    for (int jj = 0; jj < P; jj++) {
+        for (int jp = 0; jp < jj; jp++) {
+            tile64_stash<false, SD>(Bs, vb);
+            __syncthreads();                            // also: -X of the previous column is in place
+            fetch_b(jj, jp + 1, vb);
+            tile64_mma_nt<SD>(Xs[jp], Bs, acc);
+            __syncthreads();
+        }
+        double *As = Xs[jj < 3 ? jj : 0];               // the last column's earlier blocks are not needed any more
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) As[TILE_ROW(m, r) * SD + TILE_COL(n)] = acc[m][n][r];
+        tile64_stash<false, SD>(Bs, vb);
+        __syncthreads();
+        if (jj + 1 < P) {
+            fetch_b(jj + 1, 0, vb);
+            load_acc(jj + 1, accn);
+        }
+        d4_t x[2][2] = {};
+        tile64_mma_nt_tri<SD>(As, Bs, x);
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Ai[(size_t)TILE_ROW(m, r) * Npad + jj * 64 + TILE_COL_TRI(n)] = x[m][n][r];
+        __syncthreads();
+        if (jj + 1 < P) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) As[TILE_ROW(m, r) * SD + TILE_COL_TRI(n)] = -x[m][n][r];
+                    acc[m][n] = accn[m][n];
+                }
+        }
+    }
+}
+
+static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,
+                          hipStream_t s, const double *P = nullptr, int iend = 0)
+{
+    const int nb = iend > 0 ? iend : Npad / 64, nsr = (nb - k0 + 7) / 8, nsc = (k1 - k0 + 7) / 8;
     int tiles = 0;
     for (int k = k0; k < k1; k++) tiles += nb - k;
     if ((size_t)tiles * batch <= 512) {
-        hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1, 0, lstride, P);
+        hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1, 0, lstride, P, iend);
         return;
     }
     int nsb = 0;
     for (int c = 0; c < nsc; c++) nsb += nsr - c;
     const int groups = (nsb + 7) / 8;                // every XCD gets `groups` super-blocks of 64 workgroups
     hipLaunchKernelGGL(chol_update_kernel, dim3(groups * 512, 1, batch), dim3(256), 0, s, L, Npad, j0, j1, k0, k1,
-                       nsb, lstride, P);
+                       nsb, lstride, P, iend);
 }
 
 // `batch` matrices, `lstride` doubles apart (diag64: (Npad/64)*4096 apart, info: consecutive ints), are
@@ -716,6 +795,8 @@ static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, i
 // panel to the rest of the matrix once, with K = 64 P (fewer passes over the trailing matrix: large N, batches).
 static int g_chol_panel = 0;                         // 0 = choose; ibo_set_option("chol_panel", P)
 void set_chol_panel(int p) { g_chol_panel = p; }
+static int g_panel_rows = 1;                         // ibo_set_option("chol_panel_rows", 0/1): chol_panel_rows_kernel
+void set_chol_panel_rows(int v) { g_panel_rows = v; }
 static int g_update2 = 1;                            // ibo_set_option("chol_update2", 0/1): packed-panel trailing update (update2.hip)
 void set_chol_update2(int v) { g_update2 = v; }
 
@@ -730,15 +811,23 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
     HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
     for (int p0 = 0; p0 < nb; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
+        // P <= 4: the per-column launches stay inside the panel's diagonal block, the rows below it take the whole panel
+        // in one launch (chol_panel_rows_kernel; the same arithmetic in the same order)
+        // (taken when the rows fill the chip: with few of them the short launches it replaces finish sooner; either way
+        // the bits are the same)
+        const bool rows_fused = g_panel_rows && pend - p0 <= 4 && (size_t)(nb - pend) * batch >= 256;
         for (int jb = p0; jb < pend; jb++) {
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, info_dev,
                                lstride, dstride, (double *)nullptr);
-            const int m = nb - jb - 1;
+            const int m = (rows_fused ? pend : nb) - jb - 1;
             if (m > 0)
                 hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, lstride,
                                    dstride, (double *)nullptr);
-            if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s);
+            if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s, nullptr, rows_fused ? pend : 0);
         }
+        if (rows_fused && pend < nb)
+            hipLaunchKernelGGL(chol_panel_rows_kernel, dim3(nb - pend, 1, batch), dim3(256), 0, s, L, Npad, p0, pend, diag64,
+                               lstride, dstride);
         if (pend < nb) {
             // the big update (K = 64 P): packed-panel kernel when the caller lent a workspace, bit-identical to the other
             const int nI2 = (Npad - 64 * pend + 127) / 128;
@@ -1235,11 +1324,18 @@ int launch_extend_rows(int N, int Npad, double noise, const double *z, const dou
 // being factored ([[K, y],[y^T, c]]); after the Cholesky that row IS z = L^-1 y, produced by
 // the factorisation's own trsm/syrk kernels.  c is huge so the extra pivot never fails.
 // ------------------------------------------------------------------------
+// The pad rows below the y row are rewritten as identity rows every time: a factorisation that failed (not positive
+// definite) leaves NaNs in them, and the matrix slot is used again.
 __global__ void aug_row_kernel(double *__restrict__ L, int Npad, int N, const double *__restrict__ y)
 {
-    int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < N) L[(size_t)N * Npad + k] = y[k];
-    else if (k == N) L[(size_t)N * Npad + N] = 1e300;
+    const int k = blockIdx.x * 256 + threadIdx.x, r = N + blockIdx.y;
+    if (k >= Npad) return;
+    if (blockIdx.y == 0) {
+        if (k < N) L[(size_t)N * Npad + k] = y[k];
+        else if (k == N) L[(size_t)N * Npad + N] = 1e300;
+    } else {
+        L[(size_t)r * Npad + k] = (k == r) ? 1.0 : 0.0;
+    }
 }
 
 __global__ __launch_bounds__(256) void nlml_reduce_kernel(const double *__restrict__ L, int Npad, int N,
@@ -1264,7 +1360,7 @@ __global__ __launch_bounds__(256) void nlml_reduce_kernel(const double *__restri
 
 int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s)
 {
-    hipLaunchKernelGGL(aug_row_kernel, dim3((N + 256) / 256), dim3(256), 0, s, L, Npad, N, y);
+    hipLaunchKernelGGL(aug_row_kernel, dim3((Npad + 255) / 256, Npad - N), dim3(256), 0, s, L, Npad, N, y);
     return (int)hipGetLastError();
 }
 

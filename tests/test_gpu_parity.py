@@ -976,6 +976,29 @@ def test_cholesky_panel_orders_agree(ibo):
         finally:
             _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 0))
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[4:5], X[:300], Y[:300], noise=.01)[0], vals[4:5])
+    # a theta whose matrix is not positive definite (length scales so long that K is numerically singular) yields 100
+    # and leaves nothing behind in the matrix slot the next theta is factored in (nlml_batch = 1: the same slot),
+    # nor in the workspace a later call finds
+    bad = np.r_[[np.full(5, 3e3)], thetas[:2]]
+    _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 1))
+    try:
+        v3, _ = nlml_grid(GaussianKernel_ard, bad, X[:300], Y[:300], noise=1e-14)
+        ref, _ = nlml_grid(GaussianKernel_ard, thetas[:2], X[:300], Y[:300], noise=1e-14)
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 0))
+    assert not np.isfinite(v3[0]) or v3[0] == 100.0
+    assert np.all(np.isfinite(ref)) and np.array_equal(v3[1:], ref)
+    # the rows below a panel in one launch (chol_panel_rows_kernel, taken when rows x batch fill the chip) or as the
+    # per-column trsm / update launches it replaces: the same bits
+    Xb, Yb = synth(12, 1100, 4)
+    tb = np.exp(np.random.RandomState(4).uniform(np.log(.2), np.log(2), size=(24, 4)))
+    va, _ = nlml_grid(GaussianKernel_ard, tb, Xb, Yb, noise=.01)
+    _lib.check(_lib.lib.ibo_set_option(b"chol_panel_rows", 0))
+    try:
+        vb, _ = nlml_grid(GaussianKernel_ard, tb, Xb, Yb, noise=.01)
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"chol_panel_rows", 1))
+    assert np.all(np.isfinite(va)) and np.array_equal(va, vb)
 
 
 def test_randomised_parity_sweep(ibo, oracle):
