@@ -509,14 +509,18 @@ def worker(args):
                 for i in range(512):
                     a_, b_ = pts[2 * i], pts[2 * i + 1]
                     prefs.append((a_, b_, 0) if hartman6(a_) > hartman6(b_) else (b_, a_, 0))
-                t0 = time.perf_counter()
-                PG = PrefGaussianProcess(GaussianKernel_ard([0.53, 0.57, 2.5, 0.34, 0.27, 0.35]), prefs, device=local_rank)
-                pms = (time.perf_counter() - t0) * 1e3
+                pref_ms = []
+                for _ in range(3):                  # the first call pays for this handle type's buffers and code objects
+                    t0 = time.perf_counter()
+                    PG = PrefGaussianProcess(GaussianKernel_ard([0.53, 0.57, 2.5, 0.34, 0.27, 0.35]), prefs, device=local_rank)
+                    pref_ms.append((time.perf_counter() - t0) * 1e3)
+                pms = min(pref_ms[1:])
                 cand4 = DeviceArray.from_host(np.random.RandomState(104).rand(1 << 20, 6), local_rank)
                 t0 = time.perf_counter()
                 fastUCBGallery(PG, [[0., 1.]] * 6, 8, candidates=cand4)
                 cfgs["c4_prefgp"] = {"workload": "PrefGaussianProcess, 512 pairs -> 1024 points, D=6; gallery of 8 over 2^20 candidates",
-                                     "addPreferences_ms": pms, "gallery8_ms": (time.perf_counter() - t0) * 1e3}
+                                     "addPreferences_ms": pms, "addPreferences_first_call_ms": pref_ms[0],
+                                     "gallery8_ms": (time.perf_counter() - t0) * 1e3}
                 del PG, cand4
             if rank == 0:
                 out["configs"] = cfgs

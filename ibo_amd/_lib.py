@@ -71,6 +71,10 @@ _sig("ibo_gp_fit_with_matrix", c_int, c_void_p, c_int, c_int, c_int, _DP, _DP, _
      _DP, POINTER(c_int))
 _sig("ibo_gp_extend", c_int, c_void_p, c_int, _DP, _DP, POINTER(c_int))
 _sig("ibo_gp_reserve", c_int, c_void_p, c_int)
+_sig("ibo_pref_begin", c_int, c_void_p)
+_sig("ibo_pref_rinv_mul", c_int, c_void_p, _DP, _DP)
+_sig("ibo_pref_newton_step", c_int, c_void_p, c_int, POINTER(c_int64), _DP, _DP, _DP, _DP, POINTER(c_int))
+_sig("ibo_pref_finish", c_int, c_void_p, c_int, POINTER(c_int64), _DP, c_double, POINTER(c_int))
 _sig("ibo_gp_set_y", c_int, c_void_p, _DP)
 _sig("ibo_gp_set_kstar_sf2", c_int, c_void_p, c_double)
 _sig("ibo_gp_set_prior", c_int, c_void_p, c_int, _DP, _DP, c_double, _DP, _DP)
@@ -110,7 +114,7 @@ _sig("logCDFs", c_double, c_int, POINTER(c_int), _DP)
 EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device_name", "ibo_selftest_mfma",
             "ibo_set_option", "ibo_trim", "ibo_dev_alloc", "ibo_dev_free", "ibo_memcpy_h2d", "ibo_memcpy_d2h",
             "ibo_device_synchronize", "ibo_gp_create", "ibo_gp_destroy", "ibo_gp_fit", "ibo_gp_fit_with_matrix",
-            "ibo_gp_extend", "ibo_gp_reserve", "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
+            "ibo_gp_extend", "ibo_gp_reserve", "ibo_pref_begin", "ibo_pref_rinv_mul", "ibo_pref_newton_step", "ibo_pref_finish", "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
             "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_spd_solve", "ibo_spd_inverse", "ibo_posterior_batch",
             "ibo_acq_sweep", "ibo_acq_sweep_incremental", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_host", "ibo_nlml_grid", "ibo_nlml_grad",
             "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_count", "ibo_comm_argmax", "ibo_comm_allreduce_sum", "ibo_comm_barrier",

@@ -189,6 +189,14 @@ struct ibo_gp {
     unsigned fit_epoch = 0;         // bumped by every full fit: a kept state never survives one
     int reserve = 0;                // rows of head-room the next fit leaves for ibo_gp_extend (ibo_gp_reserve)
     DevBuf<int> info;
+    // preference GP (ibo_pref_*): R^-1, the matrix being factored and its factors, vectors, sparse terms
+    struct PrefWork {
+        DevBuf<double> Rinv, A, Lh, E, Et, d64, vec, tmp, val;
+        DevBuf<long long> lin;
+        DevBuf<int> info;
+        bool ready = false;
+        int epoch = -1;
+    } pw;
     // prior
     int nb = 0; double ptheta = 0.0;
     DevBuf<double> pmeans, pbeta, plowerb, pwidth;
@@ -319,6 +327,8 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release(); g->small_ws.release();
     if (g->pin) (void)hipHostFree(g->pin);
+    g->pw.Rinv.release(); g->pw.A.release(); g->pw.Lh.release(); g->pw.E.release(); g->pw.Et.release(); g->pw.d64.release();
+    g->pw.vec.release(); g->pw.tmp.release(); g->pw.val.release(); g->pw.lin.release(); g->pw.info.release();
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
     (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
     (void)hipEventDestroy(g->fit0); (void)hipEventDestroy(g->fit1);
@@ -422,25 +432,13 @@ static int check_info(ibo_gp *g, int *info)
     return IBO_OK;
 }
 
-static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const double *Y,
-                    const double *hyper, int nhyper, double sf2, double noise, const double *A_host, int *info)
+// Everything of a fit after the data are staged: R, L = chol(R) -- or chol(A) for a matrix already in g->A (N x N) --,
+// W = L^-1 and its packed copy, both alpha vectors.
+static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool have_A, int *info)
 {
-    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
-    IBO_TRY(use_device(g->device));
-    KParams kp;
-    IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
-    g->fitted = false;
-    IBO_TRY(stage_data(g, N, D, X, Y, false));
-    g->kp = kp; g->kp_fit = kp; g->noise = noise;
     const int Np = g->Npad;
     hipStream_t s = g->stream;
-    KERNEL_TRY(launch_scale_x(kp, g->Xp.p, Np, g->DP, g->Xs.p, g->ak.p, s));
-    KERNEL_TRY(launch_pack_xa(g->Xs.p, g->ak.p, N, Np, g->DP, D, g->XA.p, s));
-    g->dot_form = dot_form_ok(kp, X, N, D);
-    if (A_host) {
-        IBO_TRY(g->A.ensure((size_t)N * N));
-        HIP_TRY(hipMemcpyAsync(g->A.p, A_host, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
-    }
+    const double *A_host = have_A ? g->A.p : nullptr;      // (only tested for presence below)
     HIP_TRY(hipEventRecord(g->fit0, s));
     // R, and in the same pass the identity-padded copy the factorisation works on
     const bool fused = Np / 64 <= 32 && g_chol_fused;
@@ -470,9 +468,31 @@ static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const d
     IBO_TRY(check_info(g, info));
     HIP_TRY(hipEventElapsedTime(&g->fit_ms, g->fit0, g->fit1));
     g->fitted = true;
-    g->plain_fit = (A_host == nullptr);
+    g->plain_fit = !have_A;
     g->fit_epoch++;
     return IBO_OK;
+}
+
+static int fit_impl(ibo_gp *g, int ktype, int N, int D, const double *X, const double *Y,
+                    const double *hyper, int nhyper, double sf2, double noise, const double *A_host, int *info)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    IBO_TRY(use_device(g->device));
+    KParams kp;
+    IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
+    g->fitted = false;
+    IBO_TRY(stage_data(g, N, D, X, Y, false));
+    g->kp = kp; g->kp_fit = kp; g->noise = noise;
+    const int Np = g->Npad;
+    hipStream_t s = g->stream;
+    KERNEL_TRY(launch_scale_x(kp, g->Xp.p, Np, g->DP, g->Xs.p, g->ak.p, s));
+    KERNEL_TRY(launch_pack_xa(g->Xs.p, g->ak.p, N, Np, g->DP, D, g->XA.p, s));
+    g->dot_form = dot_form_ok(kp, X, N, D);
+    if (A_host) {
+        IBO_TRY(g->A.ensure((size_t)N * N));
+        HIP_TRY(hipMemcpyAsync(g->A.p, A_host, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice, s));
+    }
+    return fit_factor(g, kp, N, noise, A_host != nullptr, info);
 }
 
 // Append observations to a fitted model without refactoring: the block extension of
@@ -606,6 +626,137 @@ extern "C" int ibo_gp_set_y(ibo_gp_t *g, const double *Y_host)
     KERNEL_TRY(launch_alpha(g->W.p, g->N, g->Npad, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return IBO_OK;
+}
+
+// ------------------------------------------------------------------------ preference GP on the device
+// PrefGaussianProcess.addPreferences (ego/gaussianprocess/__init__.py:347-498) minimises
+//     S(y) = -sum_pairs (d + 1) log Phi((y_v - y_u)/sqrt 2) + y^T R^-1 y / 2
+// and then factors R + C^-1.  The O(pairs) terms (Phi, its derivatives, the line search) stay with the host; every
+// N x N object -- R^-1 = W^T W, the Hessian R^-1 + sum rho (e_v - e_u)(e_v - e_u)^T and its factorisation, C, C^-1,
+// R + C^-1 -- lives on the device, and only vectors and the pairs' distinct matrix entries cross the bus.
+static int pref_alloc(ibo_gp *g)
+{
+    const int Np = g->Npad;
+    const size_t nn = (size_t)Np * Np;
+    auto &pw = g->pw;
+    IBO_TRY(pw.Rinv.ensure(nn)); IBO_TRY(pw.A.ensure(nn)); IBO_TRY(pw.Lh.ensure(nn)); IBO_TRY(pw.E.ensure(nn));
+    IBO_TRY(pw.Et.ensure(nn)); IBO_TRY(pw.d64.ensure((size_t)(Np / 64) * 4096)); IBO_TRY(pw.vec.ensure(4 * (size_t)Np));
+    IBO_TRY(pw.tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64)); IBO_TRY(pw.info.ensure(1));
+    return IBO_OK;
+}
+// pw.A (N x N in an identity-padded Npad x Npad frame; destroyed) -> pw.E = the inverse of its Cholesky factor, pad rows zero
+static int pref_factor(ibo_gp *g, int *info)
+{
+    auto &pw = g->pw;
+    const int N = g->N, Np = g->Npad;
+    hipStream_t s = g->stream;
+    if (Np / 64 <= 32 && g_chol_fused && g_chol_ride) {
+        KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, pw.E.p, Np, 1.0, s));                  // identity
+        KERNEL_TRY(launch_cholesky_fused(pw.A.p, pw.Lh.p, Np, pw.d64.p, pw.info.p, s, pw.E.p, pw.Et.p));
+        KERNEL_TRY(launch_transpose_lower(pw.Et.p, pw.E.p, Np, s));
+    } else {
+        KERNEL_TRY(launch_cholesky(pw.A.p, Np, pw.d64.p, pw.info.p, s, pw.Lh.p));
+        KERNEL_TRY(launch_trinv(pw.A.p, Np, pw.d64.p, pw.E.p, pw.Et.p, s, false));
+    }
+    KERNEL_TRY(launch_pack_w(pw.E.p, N, Np, 0, pw.E.p, pw.Et.p, s));                     // zero the pad rows (Et: scratch)
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, pw.info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (info) *info = h;
+    if (h != 0) return fail(IBO_ERR_NOT_PD, "matrix is not positive definite (pivot %d)", h);
+    return IBO_OK;
+}
+static int pref_sparse(ibo_gp *g, int nnz, const int64_t *lin_host, const double *val_host)
+{
+    auto &pw = g->pw;
+    if (nnz < 0 || (nnz > 0 && (!lin_host || !val_host))) return fail(IBO_ERR_ARG, "bad sparse term");
+    for (int e = 0; e < nnz; e++)
+        if (lin_host[e] < 0 || lin_host[e] >= (int64_t)g->N * g->N) return fail(IBO_ERR_ARG, "matrix entry %d out of range", e);
+    if (nnz == 0) return IBO_OK;
+    IBO_TRY(pw.lin.ensure(nnz)); IBO_TRY(pw.val.ensure(nnz));
+    HIP_TRY(hipMemcpyAsync(pw.lin.p, lin_host, sizeof(int64_t) * nnz, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(pw.val.p, val_host, sizeof(double) * nnz, hipMemcpyHostToDevice, g->stream));
+    return IBO_OK;
+}
+
+extern "C" int ibo_pref_begin(ibo_gp_t *g)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    if (!g->fitted || !g->plain_fit || g->reversed) return fail(IBO_ERR_STATE, "ibo_pref_begin needs a plain fitted model (L = chol(R))");
+    IBO_TRY(use_device(g->device));
+    IBO_TRY(pref_alloc(g));
+    KERNEL_TRY(launch_wtw(g->W.p, g->pw.Et.p, g->pw.Rinv.p, g->Npad, g->stream));       // R^-1 = W^T W (zero on the pad)
+    g->pw.ready = true; g->pw.epoch = g->fit_epoch;
+    return IBO_OK;
+}
+
+static int pref_check(ibo_gp *g)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    if (!g->pw.ready || g->pw.epoch != g->fit_epoch || !g->fitted || !g->plain_fit)
+        return fail(IBO_ERR_STATE, "no ibo_pref_begin since the last plain fit of this model");
+    return use_device(g->device);
+}
+
+extern "C" int ibo_pref_rinv_mul(ibo_gp_t *g, const double *y_host, double *out_host)
+{
+    IBO_TRY(pref_check(g));
+    if (!y_host || !out_host) return fail(IBO_ERR_ARG, "NULL argument");
+    auto &pw = g->pw;
+    const int N = g->N, Np = g->Npad;
+    hipStream_t s = g->stream;
+    std::vector<double> yp(Np, 0.0);
+    for (int i = 0; i < N; i++) yp[i] = y_host[i];
+    HIP_TRY(hipMemcpyAsync(pw.vec.p, yp.data(), sizeof(double) * Np, hipMemcpyHostToDevice, s));
+    KERNEL_TRY(launch_alpha(g->W.p, N, Np, pw.vec.p, pw.tmp.p, pw.vec.p + Np, pw.vec.p + 2 * (size_t)Np, s));
+    HIP_TRY(hipMemcpyAsync(out_host, pw.vec.p + Np, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return IBO_OK;
+}
+
+extern "C" int ibo_pref_newton_step(ibo_gp_t *g, int nnz, const int64_t *lin_host, const double *val_host,
+                                    const double *grad_host, double *delta_host, double *rdelta_host, int *info)
+{
+    IBO_TRY(pref_check(g));
+    if (!grad_host || !delta_host || !rdelta_host) return fail(IBO_ERR_ARG, "NULL argument");
+    auto &pw = g->pw;
+    const int N = g->N, Np = g->Npad;
+    hipStream_t s = g->stream;
+    IBO_TRY(pref_sparse(g, nnz, lin_host, val_host));
+    std::vector<double> bp(Np, 0.0);
+    for (int i = 0; i < N; i++) bp[i] = -grad_host[i];
+    HIP_TRY(hipMemcpyAsync(pw.vec.p, bp.data(), sizeof(double) * Np, hipMemcpyHostToDevice, s));
+    KERNEL_TRY(launch_pref_build(pw.Rinv.p, N, Np, 0.0, nnz, pw.lin.p, pw.val.p, pw.A.p, s));
+    IBO_TRY(pref_factor(g, info));                      // synchronises: bp may go
+    double *delta = pw.vec.p + Np, *rdelta = pw.vec.p + 2 * (size_t)Np, *junk = pw.vec.p + 3 * (size_t)Np;
+    KERNEL_TRY(launch_alpha(pw.E.p, N, Np, pw.vec.p, pw.tmp.p, delta, junk, s));        // delta = H^-1 (-g)
+    KERNEL_TRY(launch_alpha(g->W.p, N, Np, delta, pw.tmp.p, rdelta, junk, s));           // R^-1 delta, for the line search
+    HIP_TRY(hipMemcpyAsync(delta_host, delta, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(rdelta_host, rdelta, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return IBO_OK;
+}
+
+// C = diag I + the pairs' entries; the handle's factor becomes chol(R + C^-1) (W, alpha vectors with it), as
+// ibo_gp_fit_with_matrix(R + C^-1) would leave it.  IBO_ERR_NOT_PD (from C or from the sum): nothing usable is left
+// but the data; the caller adds to `diag` and calls again, or refits.
+extern "C" int ibo_pref_finish(ibo_gp_t *g, int nnz, const int64_t *lin_host, const double *val_host, double diag, int *info)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    if (!g->pw.ready || g->reversed || g->N < 1) return fail(IBO_ERR_STATE, "no ibo_pref_begin on this model");
+    IBO_TRY(use_device(g->device));
+    auto &pw = g->pw;
+    const int N = g->N, Np = g->Npad;
+    hipStream_t s = g->stream;
+    IBO_TRY(pref_sparse(g, nnz, lin_host, val_host));
+    KERNEL_TRY(launch_pref_build(nullptr, N, Np, diag, nnz, pw.lin.p, pw.val.p, pw.A.p, s));
+    g->fitted = false;                                   // from here on the old factor is not to be trusted
+    IBO_TRY(pref_factor(g, info));
+    KERNEL_TRY(launch_wtw(pw.E.p, pw.Et.p, pw.A.p, Np, s));                              // C^-1
+    IBO_TRY(g->A.ensure((size_t)N * N));
+    // R: the plain fit left it on the handle (and every fit writes it again)
+    KERNEL_TRY(launch_pref_sum(g->R.p, pw.A.p, N, Np, g->A.p, s));
+    return fit_factor(g, g->kp_fit, N, g->noise, true, info);
 }
 
 extern "C" int ibo_gp_set_kstar_sf2(ibo_gp_t *g, double sf2)

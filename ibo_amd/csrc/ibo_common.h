@@ -249,4 +249,8 @@ int launch_extend_rows(int N, int Npad, double noise, const double *z, const dou
 int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s);
 int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);
+// preference GP: out = base (or 0) + diag I + sparse entries (lin = row * N + col, distinct), identity pad;  A = R + Cinv
+int launch_pref_build(const double *base, int N, int Npad, double diag, int nnz, const long long *lin, const double *val,
+                      double *out, hipStream_t s);
+int launch_pref_sum(const double *R, const double *Cinv, int N, int Npad, double *A, hipStream_t s);
 int launch_mfma_selftest(double *out_err, hipStream_t s);

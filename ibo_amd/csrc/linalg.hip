@@ -1327,6 +1327,49 @@ int launch_extend_rows(int N, int Npad, double noise, const double *z, const dou
 }
 
 // ------------------------------------------------------------------------
+// Preference GP (ego/gaussianprocess/__init__.py:351-498): the matrices of its Newton steps and of L = chol(R + C^-1)
+// are assembled where they are factored.  out (Npad x Npad) = base (or 0) + diag I on [0, N)^2, the identity on the pad;
+// a matrix that is a sum of per-pair terms w (e_v - e_u)(e_v - e_u)^T arrives as its distinct entries (row * N + col,
+// value), summed on the host in the order the reference's scatter-adds take.
+// ------------------------------------------------------------------------
+__global__ void pref_build_kernel(const double *__restrict__ base, int N, int Npad, double diag, double *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= Npad) return;
+    double v;
+    if (i < N && j < N) v = (base ? base[(size_t)i * Npad + j] : 0.0) + (i == j ? diag : 0.0);
+    else v = (i == j) ? 1.0 : 0.0;
+    out[(size_t)i * Npad + j] = v;
+}
+__global__ void pref_scatter_kernel(int nnz, const long long *__restrict__ lin, const double *__restrict__ val, int N,
+                                    int Npad, double *__restrict__ out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const long long i = lin[e] / N, j = lin[e] - i * N;
+    out[(size_t)i * Npad + j] += val[e];                 // entries are distinct
+}
+// A (N x N, dense) = R + Cinv (both with row stride Npad)
+__global__ void pref_sum_kernel(const double *__restrict__ R, const double *__restrict__ Cinv, int N, int Npad,
+                                double *__restrict__ A)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j < N) A[(size_t)i * N + j] = R[(size_t)i * Npad + j] + Cinv[(size_t)i * Npad + j];
+}
+int launch_pref_build(const double *base, int N, int Npad, double diag, int nnz, const long long *lin, const double *val,
+                      double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(pref_build_kernel, dim3((Npad + 255) / 256, Npad), dim3(256), 0, s, base, N, Npad, diag, out);
+    if (nnz > 0) hipLaunchKernelGGL(pref_scatter_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, nnz, lin, val, N, Npad, out);
+    return (int)hipGetLastError();
+}
+int launch_pref_sum(const double *R, const double *Cinv, int N, int Npad, double *A, hipStream_t s)
+{
+    hipLaunchKernelGGL(pref_sum_kernel, dim3((N + 255) / 256, N), dim3(256), 0, s, R, Cinv, N, Npad, A);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
 // Marginal likelihood scalars |L^-1 y|^2 and sum log L_ii (ego/gaussianprocess/trainhyper.py:60-68)
 // without a separate triangular solve: append y as row N of the matrix
 // being factored ([[K, y],[y^T, c]]); after the Cholesky that row IS z = L^-1 y, produced by

@@ -359,15 +359,14 @@ class PrefGaussianProcess(GaussianProcess):
             self.addPreferences(prefs)
 
     @staticmethod
-    def _S_terms(y, v, u, w, Rinv, hess=True):
+    def _S_terms(y, Ry, v, u, w, hess=True):
         """MAP functional S(y) = -sum (d+1) log(Phi((y_v-y_u)/sqrt 2) + 1e-10) + y^T R^-1 y / 2
-        (:351-385) with gradient and the per-pair Hessian weights.  Phi is the reference's CDF
+        (:351-385) with gradient and the per-pair Hessian weights; Ry = R^-1 y.  Phi is the reference's CDF
         (NR erf, truncated 1/sqrt 2) so S is the same function; its derivative uses the exact pdf."""
         z = (y[v] - y[u]) / np.sqrt(2)
         cdf = CDF(z) + 1e-10
         t = z * 0.707106
         pdf = 0.707106 / np.sqrt(np.pi) * np.exp(-t * t)           # d CDF / dz
-        Ry = Rinv.dot(y)
         S = -np.sum(w * np.log(cdf)) + 0.5 * y.dot(Ry)
         ratio = pdf / cdf
         gz = -w * ratio / np.sqrt(2)
@@ -380,33 +379,53 @@ class PrefGaussianProcess(GaussianProcess):
         rho = w * (2 * 0.707106 * t * ratio + ratio * ratio) / 2.0
         return S, g, rho
 
-    def _map_newton(self, start, prefinds, Rinv, tol=1e-9, maxit=100):
-        """minimise the (convex) MAP functional by damped Newton; each step solves
-        (R^-1 + C_pref) delta = -g on the GPU (ibo_spd_solve)."""
+    @staticmethod
+    def _pair_sum_entries(n, v, u, w):
+        """the distinct entries of sum_p w_p (e_v - e_u)(e_v - e_u)^T as (row * n + col, value), each summed in the
+        order the reference's four scatter-adds visit it (the (v,v) terms, then (u,u), (v,u), (u,v))"""
+        lin = np.concatenate([v * n + v, u * n + u, v * n + u, u * n + v]).astype(np.int64)
+        val = np.concatenate([w, w, -w, -w])
+        uniq, inv = np.unique(lin, return_inverse=True)
+        acc = np.zeros(len(uniq))
+        np.add.at(acc, inv, val)
+        return np.ascontiguousarray(uniq, dtype=np.int64), np.ascontiguousarray(acc)
+
+    def _map_newton(self, start, prefinds, tol=1e-9, maxit=100):
+        """minimise the (convex) MAP functional by damped Newton.  Each step solves (R^-1 + C_pref) delta = -g on
+        the GPU, where R^-1 and the Hessian live (ibo_pref_newton_step): vectors and the pairs' matrix entries
+        travel, nothing N x N does.  The line search needs R^-1 (y + t delta) = R^-1 y + t R^-1 delta only."""
+        import ctypes
+        h = self._handle()
         v = np.array([i[0] for i in prefinds]); u = np.array([i[1] for i in prefinds])
         w = np.array([i[2] + 1.0 for i in prefinds])
-        y = np.array(start, dtype=float)
+        y = _lib.f64(np.array(start, dtype=float))
         N = len(y)
-        S, g, rho = self._S_terms(y, v, u, w, Rinv)
+        Ry = np.empty(N)
+        _lib.check(_lib.lib.ibo_pref_rinv_mul(h, _lib.dp(y), _lib.dp(Ry)))
+        S, g, rho = self._S_terms(y, Ry, v, u, w)
+        info = ctypes.c_int(0)
         for it in range(maxit):
             if np.max(np.abs(g)) < tol * max(1.0, np.max(np.abs(y))):
                 break
-            H = Rinv.copy()
-            np.add.at(H, (v, v), rho); np.add.at(H, (u, u), rho)
-            np.add.at(H, (v, u), -rho); np.add.at(H, (u, v), -rho)
-            delta = np.empty(N)
-            Hc = _lib.f64(H); gc = _lib.f64(-g)
-            _lib.check(_lib.lib.ibo_spd_solve(self._dev.device, N, _lib.dp(Hc), 1, _lib.dp(gc), _lib.dp(delta), None))
+            lin, val = self._pair_sum_entries(N, v, u, rho)
+            delta = np.empty(N); Rdelta = np.empty(N)
+            gc = _lib.f64(g)
+            _lib.check(_lib.lib.ibo_pref_newton_step(h, len(lin), lin.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _lib.dp(val),
+                                                     _lib.dp(gc), _lib.dp(delta), _lib.dp(Rdelta), ctypes.byref(info)))
             step = 1.0
             while True:
-                Sn, gn, rn = self._S_terms(y + step * delta, v, u, w, Rinv)
+                Sn, gn, rn = self._S_terms(y + step * delta, Ry + step * Rdelta, v, u, w)
                 if np.isfinite(Sn) and Sn <= S + 1e-4 * step * g.dot(delta):
                     break
                 step *= 0.5
                 if step < 1e-10:
                     return y
             y = y + step * delta
+            Ry = Ry + step * Rdelta
             S, g, rho = Sn, gn, rn
+            if it % 8 == 7:                           # R^-1 y afresh now and then: the running sum drifts by rounding only
+                _lib.check(_lib.lib.ibo_pref_rinv_mul(h, _lib.dp(_lib.f64(y)), _lib.dp(Ry)))
+                S, g, rho = self._S_terms(y, Ry, v, u, w)
         return y
 
     @staticmethod
@@ -454,14 +473,11 @@ class PrefGaussianProcess(GaussianProcess):
         self._augdev = None
         self.augR = self.augL = self.augX = None
         self._fit_device()
-        N = len(newX)
-        W = np.empty((N, N))
-        _lib.check(_lib.lib.ibo_gp_get_W(self._handle(), _lib.dp(W)))
-        Rinv = W.T.dot(W)
+        _lib.check(_lib.lib.ibo_pref_begin(self._handle()))       # R^-1 = W^T W, on the device
 
         # MAP (:442).  The reference runs fmin_bfgs with numerical gradients (gtol 1e-5) on this
         # convex functional; Newton with the analytic Hessian reaches the same optimum in ~10 solves.
-        Y = self._map_newton(start, prefinds, Rinv)
+        Y = self._map_newton(start, prefinds)
         for r, c, _ in prefinds:                      # order fix-up (:445-457)
             if Y[r] <= Y[c]:
                 if not any(c1 == r for _, c1, _ in prefinds):
@@ -497,15 +513,28 @@ class PrefGaussianProcess(GaussianProcess):
         np.add.at(C, (pv, pu), -w); np.add.at(C, (pu, pv), -w)
         np.add.at(C, (pv, pv), w); np.add.at(C, (pu, pu), w)
         self.C = C
-        R = self.R.copy()
+        # L = chol(R + C^-1) (:488-497): C, its inverse and the sum are formed on the device from the pairs' entries
+        # (ibo_pref_finish); a C too ill-conditioned to factor gets the reference's regulariser, one identity at a time
+        import ctypes
+        if not plain_fitted:                         # (addPreferences has done this before its Newton steps)
+            _lib.check(_lib.lib.ibo_pref_begin(self._handle()))
+        lin, val = self._pair_sum_entries(n, pv, pu, w)
+        info = ctypes.c_int(0)
         for i in range(11):
-            try:
-                self._fit_device(A=R + self._inv_spd(self.C))
-                break
-            except NotPositiveDefinite:
+            rc = _lib.lib.ibo_pref_finish(self._handle(), len(lin), lin.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _lib.dp(val),
+                                          5.0 + i, ctypes.byref(info))
+            if rc == _lib.ERR_NOT_PD:
                 print('[addPreferences] GP.C matrix is ill-conditioned, adding regularizer delta = %d' % (i + 1))
                 self.C += np.eye(n)
-        self._cache["R"] = R
+                continue
+            _lib.check(rc)
+            break
+        else:
+            raise NotPositiveDefinite(_lib.ERR_NOT_PD, "R + C^-1 could not be factored")
+        self._cache = {}
+        self._prior_pushed = False
+        self._push_prior()
+        self._fit_spec = None
 
     def addObservationPoint(self, X):
         """add a point to observe at, without its observation (:502-519)"""

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IBO_ABI_VERSION 2   /* 2: + ibo_gp_extend, ibo_comm_count */
+#define IBO_ABI_VERSION 3   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_* */
 
 /* status codes */
 #define IBO_OK              0
@@ -140,6 +140,26 @@ int ibo_gp_extend(ibo_gp_t *gp, int n, const double *Xnew_host, const double *Y_
  * that many observations can be appended by ibo_gp_extend before a refit is due (a gallery of n points on a model
  * whose size is a multiple of 64 would otherwise refit, and sweep in full, in its very first round) */
 int ibo_gp_reserve(ibo_gp_t *gp, int rows);
+
+/*
+ * Preference GP on the device (PrefGaussianProcess.addPreferences, ego/gaussianprocess/__init__.py:347-498: the MAP of
+ *     S(y) = -sum_pairs (d+1) log Phi((y_v - y_u)/sqrt 2) + y^T R^-1 y / 2     (:351-385)
+ * and then L = chol(R + C^-1), :459-498).  The host keeps what is O(pairs) -- Phi, its derivatives, the line search --
+ * and the device everything that is N x N: only vectors and the distinct entries of the pair sums cross the bus
+ * (round 1 shipped an N x N Hessian per Newton step through ibo_spd_solve, and C and C^-1 through ibo_spd_inverse).
+ *   ibo_pref_begin        after a plain ibo_gp_fit of the points: R^-1 = W^T W is formed on the handle
+ *   ibo_pref_rinv_mul     out = R^-1 y
+ *   ibo_pref_newton_step  H = R^-1 + sum of the sparse term (lin[e] = row * N + col, distinct entries: the host sums
+ *                         the per-pair contributions rho (e_v - e_u)(e_v - e_u)^T); delta = -H^-1 grad; rdelta = R^-1 delta
+ *   ibo_pref_finish       C = diag I + sparse term; the handle is refactored from R + C^-1 exactly as
+ *                         ibo_gp_fit_with_matrix would (Y as set by ibo_gp_set_y).  IBO_ERR_NOT_PD: call again with a
+ *                         larger diag (the reference's regulariser loop, :489-497) or refit.
+ */
+int ibo_pref_begin(ibo_gp_t *gp);
+int ibo_pref_rinv_mul(ibo_gp_t *gp, const double *y_host, double *out_host);
+int ibo_pref_newton_step(ibo_gp_t *gp, int nnz, const int64_t *lin_host, const double *val_host,
+                         const double *grad_host, double *delta_host, double *rdelta_host, int *info);
+int ibo_pref_finish(ibo_gp_t *gp, int nnz, const int64_t *lin_host, const double *val_host, double diag, int *info);
 
 /* replace Y (and the alpha vectors) without refactoring: the preference GP's
  * C-matrix loop re-reads mu with L fixed (ego/gaussianprocess/__init__.py:476) */
