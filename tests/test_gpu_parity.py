@@ -578,6 +578,52 @@ def test_pref_orderings(ibo):
         GP.addData(x1, 1.0)
 
 
+def test_pref_device_steps_match_dense_algebra(ibo):
+    """ibo_pref_*: one Newton step and the final factorisation of the preference GP against the same algebra in
+    NumPy -- delta = -(R^-1 + sum rho (e_v - e_u)(e_v - e_u)^T)^-1 g, R^-1 delta, L = chol(R + (5 I + sum w ...)^-1);
+    points that occur in several pairs (accumulated entries) and a size that is not a multiple of 64"""
+    import ctypes
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess, PrefGaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    n, D, P = 150, 3, 220
+    rs = np.random.RandomState(77)
+    X = rs.rand(n, D)
+    GP = GaussianProcess(GaussianKernel_ard([.4] * D), X, rs.randn(n), noise=.05)
+    h = GP._handle()
+    _lib.check(_lib.lib.ibo_pref_begin(h))
+    R = GP.R
+    Rinv = np.linalg.inv(R)
+    v = rs.randint(0, n, P); u = (v + 1 + rs.randint(0, n - 1, P)) % n
+    rho = rs.rand(P) + .1
+    g = rs.randn(n)
+    lin, val = PrefGaussianProcess._pair_sum_entries(n, v, u, rho)
+    assert len(lin) < 4 * P                                         # some entries really are sums
+    H = Rinv.copy()
+    for a, b, r in zip(v, u, rho):
+        H[a, a] += r; H[b, b] += r; H[a, b] -= r; H[b, a] -= r
+    delta = np.empty(n); rdelta = np.empty(n); out = np.empty(n); info = ctypes.c_int(0)
+    i64 = ctypes.POINTER(ctypes.c_int64)
+    _lib.check(_lib.lib.ibo_pref_newton_step(h, len(lin), lin.ctypes.data_as(i64), _lib.dp(val), _lib.dp(g), _lib.dp(delta),
+                                             _lib.dp(rdelta), ctypes.byref(info)))
+    ref = -np.linalg.solve(H, g)
+    close(delta, ref, rtol=1e-8, atol=1e-10); close(rdelta, Rinv.dot(ref), rtol=1e-7, atol=1e-9)
+    _lib.check(_lib.lib.ibo_pref_rinv_mul(h, _lib.dp(g), _lib.dp(out)))
+    close(out, Rinv.dot(g), rtol=1e-8, atol=1e-10)
+    C = 5 * np.eye(n)
+    for a, b, r in zip(v, u, rho):
+        C[a, a] += r; C[b, b] += r; C[a, b] -= r; C[b, a] -= r
+    _lib.check(_lib.lib.ibo_pref_finish(h, len(lin), lin.ctypes.data_as(i64), _lib.dp(val), 5.0, ctypes.byref(info)))
+    L = np.empty((n, n))
+    _lib.check(_lib.lib.ibo_gp_get_L(h, _lib.dp(L)))
+    close(np.tril(L), np.linalg.cholesky(R + np.linalg.inv(C)), rtol=1e-9, atol=1e-11)
+    # a matrix entry out of range, a step without a begin since the last fit: refused
+    bad = np.array([n * n], dtype=np.int64)
+    assert _lib.lib.ibo_pref_finish(h, 1, bad.ctypes.data_as(i64), _lib.dp(np.ones(1)), 5.0, ctypes.byref(info)) == _lib.ERR_ARG
+    GP._fit_device()
+    assert _lib.lib.ibo_pref_rinv_mul(h, _lib.dp(g), _lib.dp(out)) == _lib.ERR_STATE
+
+
 def test_g2_g8_marginal_likelihood(ibo):
     from ibo_amd.gaussianprocess import kernel as K
     from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood, nlml_grid, nlml
