@@ -18,6 +18,8 @@ for N, D in ((256, 3), (1024, 4), (2048, 8), (4096, 16)):
     line = "N=%4d D=%2d  NLML+gradient %.2f ms" % (N, D, per)
     if N <= 2048:
         t0 = time.perf_counter()
-        th = fmin_bfgs(nlml, np.log(np.full(D, .5)), dnlml, args=(GaussianKernel_ard, X, Y), maxiter=30, disp=False)
-        line += "   BFGS (<=30 it) %.0f ms -> theta %s" % ((time.perf_counter() - t0) * 1e3, np.round(np.exp(th), 3))
+        th, fopt, gopt, Bopt, fc, gc, warn = fmin_bfgs(nlml, np.log(np.full(D, .5)), dnlml, args=(GaussianKernel_ard, X, Y), maxiter=30,
+                                                       disp=False, full_output=True)
+        line += "   BFGS (<=30 it, %d evaluations: its line search is sensitive to the last bits) %.0f ms -> theta %s" % (
+            fc, (time.perf_counter() - t0) * 1e3, np.round(np.exp(th), 3))
     print(line, flush=True)
