@@ -52,6 +52,7 @@ extern int g_sweep_variant;     // sweep.hip
 static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
 static int g_zero_copy = 1;      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
+static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
 static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
 static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
@@ -237,6 +238,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_ride")) { g_chol_ride = value; return IBO_OK; }
     if (key && !strcmp(key, "small2")) { g_small2 = value; return IBO_OK; }
+    if (key && !strcmp(key, "gemv_max")) { g_gemv_max = value; return IBO_OK; }
     if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
@@ -976,13 +978,16 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     a.part_val = g->partv.p; a.part_idx = g->parti.p;
     const bool want_best = best_val || best_idx;
     a.result_val = want_best ? g->res_v.p : nullptr; a.result_idx = want_best ? g->res_i.p : nullptr;
-    bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16);
+    // batches up to 4096 candidates where the dot form holds: three short kernels spread over the chip (small2.hip;
+    // from ~8192 candidates on the panel-split kernel's tiles fill the chip by themselves and it is the faster one).
+    // They beat the GEMV kernel down to a single candidate (N = 2048: 22 us against 87; N = 1024: 16 against 38), which
+    // is left with the models they do not take (no dot form, rows beyond sweep2's LDS budget).
+    const bool small2_ok = g_force_path == 0 && g_small2 && M <= 4096 && a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad);
+    bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16 && (!small2_ok || M <= g_gemv_max));
     // small batches: spread the IBO_SPLIT_PANEL-row panels over the grid too (one tile per 64 candidates alone
     // would leave most of the 256 CUs idle); above ~128 tiles the plain kernel fills the chip
     bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256));
-    // batches up to 4096 candidates where the dot form holds: three short kernels spread over the chip (small2.hip;
-    // from ~8192 candidates on the panel-split kernel's tiles fill the chip by themselves and it is the faster one)
-    const bool small2 = split && g_force_path == 0 && g_small2 && M <= 4096 && a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad);
+    const bool small2 = split && small2_ok;
     if (small2) {
         IBO_TRY(exp_table(g->device, &a.exp_tab));
         IBO_TRY(g->small_ws.ensure(small_sweep_workspace(g->Npad, M)));

@@ -431,7 +431,7 @@ def test_sweep2_kernel_against_oracle_and_the_other_kernels(ibo, oracle):
 
 
 def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
-    """batches of 17..4096 candidates (DIRECT's, posteriors of a few hundred points) run through small2.hip's three
+    """batches of 1..4096 candidates (DIRECT's, posterior(x), posteriors of a few hundred points) run through small2.hip's three
     kernels: values against the CPU oracle, the panel-split kernel and the GEMV kernel; DIRECT takes the same samples
     whichever of them evaluates its batches"""
     from ibo_amd import _lib
@@ -442,14 +442,17 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
     try:
         for N, D, kern, (okind, ohyp), M in ((1024, 4, K.GaussianKernel_ard([.3] * 4), ("ard", [.3] * 4), 57), (200, 3, K.GaussianKernel_iso([.4]), ("iso", [.4]), 17),
                                              (1000, 6, K.MaternKernel3([.6, 1.0]), ("m3", [.6, 1.0]), 600), (2048, 8, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0]), 31),
-                                             (1500, 5, K.GaussianKernel_ard([.3] * 5), ("ard", [.3] * 5), 4096), (1100, 16, K.GaussianKernel_ard([.9] * 16), ("ard", [.9] * 16), 333)):
+                                             (1500, 5, K.GaussianKernel_ard([.3] * 5), ("ard", [.3] * 5), 4096), (1100, 16, K.GaussianKernel_ard([.9] * 16), ("ard", [.9] * 16), 333),
+                                             # down to a single candidate (posterior(x), DIRECT's first rectangles): also small2.hip since round 2
+                                             (1024, 4, K.GaussianKernel_ard([.3] * 4), ("ard", [.3] * 4), 1), (2048, 8, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0]), 3),
+                                             (200, 3, K.GaussianKernel_iso([.4]), ("iso", [.4]), 16), (64, 1, K.GaussianKernel_iso([.4]), ("iso", [.4]), 2)):
             X, Y = synth(N + D, N, D)
             GP = GaussianProcess(kern, X, Y, noise=.1)
-            cand = np.random.RandomState(N).rand(M, D); cand[7] = X[5]
+            cand = np.random.RandomState(N).rand(M, D); cand[min(M - 1, 7)] = X[5]
             opt(b"small2", 1); r = sweep(GP, cand, outputs=("mu", "s2", "acq"))
             assert r["kernel"] == "wk_small_kernel"
             opt(b"small2", 0); r0 = sweep(GP, cand, outputs=("mu", "s2", "acq"))
-            assert r0["kernel"] == "sweep_mfma_kernel<split>" and r0["best_idx"] == r["best_idx"]
+            assert r0["kernel"] == ("sweep_gemv_kernel" if M <= 16 else "sweep_mfma_kernel<split>") and r0["best_idx"] == r["best_idx"]
             opt(b"sweep_path", 1); rg = sweep(GP, cand[:40], outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
             for k in ("mu", "s2", "acq"):
                 close(r[k], r0[k], rtol=1e-9, atol=1e-11); close(r[k][:40], rg[k], rtol=1e-9, atol=1e-11)
