@@ -52,6 +52,7 @@ extern int g_sweep_variant;     // sweep.hip
 static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
 static int g_zero_copy = 1;      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
+static int g_flag_poll = 1;      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
 static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
 static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
 static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
@@ -190,6 +191,10 @@ struct ibo_gp {
     unsigned fit_epoch = 0;         // bumped by every full fit: a kept state never survives one
     int reserve = 0;                // rows of head-room the next fit leaves for ibo_gp_extend (ibo_gp_reserve)
     DevBuf<int> info;
+    unsigned long long *done_flag = nullptr;   // pinned host word small2.hip's last kernel writes; done_seq: last value asked for
+    unsigned long long done_seq = 0;
+    bool signal_pending = false;
+    DevBuf<unsigned> done_count;
     // preference GP (ibo_pref_*): R^-1, the matrix being factored and its factors, vectors, sparse terms
     struct PrefWork {
         DevBuf<double> Rinv, A, Lh, E, Et, d64, vec, tmp, val;
@@ -239,6 +244,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_ride")) { g_chol_ride = value; return IBO_OK; }
     if (key && !strcmp(key, "small2")) { g_small2 = value; return IBO_OK; }
     if (key && !strcmp(key, "gemv_max")) { g_gemv_max = value; return IBO_OK; }
+    if (key && !strcmp(key, "flag_poll")) { g_flag_poll = value; return IBO_OK; }
     if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
@@ -329,6 +335,8 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release(); g->small_ws.release();
     if (g->pin) (void)hipHostFree(g->pin);
+    if (g->done_flag) (void)hipHostFree(g->done_flag);
+    g->done_flag = nullptr; g->done_count.release();
     g->pw.Rinv.release(); g->pw.A.release(); g->pw.Lh.release(); g->pw.E.release(); g->pw.Et.release(); g->pw.d64.release();
     g->pw.vec.release(); g->pw.tmp.release(); g->pw.val.release(); g->pw.lin.release(); g->pw.info.release();
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
@@ -946,7 +954,7 @@ static int exp_table(int device, const double **out)
 static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
                      double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,
                      int64_t index_base, double *mu_dev, double *s2_dev, double *acq_dev,
-                     double *best_val, int64_t *best_idx, bool incremental = false, bool timed = true)
+                     double *best_val, int64_t *best_idx, bool incremental = false, bool timed = true, bool signal = false)
 {
     if (!g->fitted) return fail(IBO_ERR_STATE, "sweep before a successful fit");
     if (M < 1 || !cand_dev) return fail(IBO_ERR_ARG, "empty candidate set");
@@ -991,6 +999,16 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     if (small2) {
         IBO_TRY(exp_table(g->device, &a.exp_tab));
         IBO_TRY(g->small_ws.ensure(small_sweep_workspace(g->Npad, M)));
+        if (signal && !want_best) {                  // the caller will spin on a host-visible word the last kernel writes
+            if (!g->done_flag) {
+                HIP_TRY(hipHostMalloc((void **)&g->done_flag, 64, hipHostMallocDefault));
+                *g->done_flag = 0;
+                IBO_TRY(g->done_count.ensure(1));
+                HIP_TRY(hipMemsetAsync(g->done_count.p, 0, sizeof(unsigned), s));
+            }
+            a.done_flag = g->done_flag; a.done_seq = ++g->done_seq; a.done_count = g->done_count.p;
+            g->signal_pending = true;
+        }
         KERNEL_TRY(launch_sweep_small(a, g->small_ws.p, s, timed ? g->ev0 : nullptr, timed ? g->ev1 : nullptr));
         g->sweep_kernel = "wk_small_kernel";
     } else if (split) {
@@ -1183,19 +1201,27 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     if (mu_host) dmu = obase + (size_t)M * nout++;
     if (s2_host) ds2 = obase + (size_t)M * nout++;
     if (acq_host) dacq = obase + (size_t)M * nout++;
+    g->signal_pending = false;
     IBO_TRY(run_sweep(g, M, zero_copy ? pin_in : g->cand.p, acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
-                      nullptr, nullptr, false, !zero_copy));        // small batches: no kernel-time events either
+                      nullptr, nullptr, false, !zero_copy, zero_copy && g_flag_poll));    // small batches: no kernel-time events either
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
     if (zero_copy) {
-        // a batch of this size is back in tens of microseconds: poll the completion event for a moment before handing the
-        // thread to the runtime's blocking wait (whose wake-up alone costs about as much as the batch)
-        HIP_TRY(hipEventRecord(g->fit1, s));
+        // a batch of this size is back in tens of microseconds: spin for a moment before handing the thread to the runtime's
+        // blocking wait (whose wake-up alone costs about as much as the batch) -- on the word small2.hip's last kernel stores
+        // behind its results (no event to record, signal and query), or on a completion event for the other kernels
+        const bool flag = g->signal_pending;
+        if (!flag) HIP_TRY(hipEventRecord(g->fit1, s));
         struct timespec w0, w1;
         clock_gettime(CLOCK_MONOTONIC, &w0);
-        for (;;) {
-            hipError_t q = hipEventQuery(g->fit1);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) HIP_TRY(q);
+        for (int spin = 0;; spin++) {
+            if (flag) {
+                if (*(volatile unsigned long long *)g->done_flag == g->done_seq) break;
+                if (spin & 63) continue;
+            } else {
+                hipError_t q = hipEventQuery(g->fit1);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) HIP_TRY(q);
+            }
             clock_gettime(CLOCK_MONOTONIC, &w1);
             if ((w1.tv_sec - w0.tv_sec) * 1e6 + (w1.tv_nsec - w0.tv_nsec) * 1e-3 > 300.0) { HIP_TRY(hipStreamSynchronize(s)); break; }
         }

@@ -190,6 +190,9 @@ struct SweepArgs {
     double *mupart;                      // gemv path scratch: 2 x M
     double *result_val; int64_t *result_idx;   // device, single element each
     int rank1_row;                             // sweep2_rank1_kernel: the appended row of W being folded into the state
+    // small2.hip: when set, the last workgroup of the last kernel stores done_seq there (host-visible memory) after all
+    // results are out -- the host spins on that word instead of going through an event
+    unsigned long long *done_flag; unsigned long long done_seq; unsigned *done_count;
 };
 
 int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);

@@ -144,6 +144,18 @@ __global__ __launch_bounds__(64) void small_finish_kernel(SweepArgs a, const dou
         if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
     }
     if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+    if (a.done_flag) {
+        // every lane's results (possibly in host memory) are out before this workgroup takes its ticket; the last ticket
+        // publishes the sequence number the host is waiting for
+        __threadfence_system();
+        if (lane == 0) {
+            if (atomicAdd(a.done_count, 1u) == gridDim.x - 1) {
+                *a.done_count = 0;
+                __threadfence_system();
+                *(volatile unsigned long long *)a.done_flag = a.done_seq;
+            }
+        }
+    }
 }
 
 template <int FAM>
