@@ -150,8 +150,11 @@ int launch_zero_upper(double *A, int Npad, hipStream_t s)
 // ------------------------------------------------------------------------
 // K = 64 in one stage (the factorisation's trsm / syrk tiles): both 64x64 operand tiles are fetched with
 // every load in flight at once -- one global-memory latency instead of four.  acc += A * B^T.
-// As, Bs: 64 * T64_LD doubles each.
-#define T64_LD 68
+// As, Bs: 64 * T64_LD doubles each.  The row stride is ODD: an MFMA fragment read takes, per 16-lane pass, the rows
+// r = 0..15 at one k -- 8-byte words r * LD + k, which fall on 16 distinct bank pairs only if LD is odd (LD = 68, the
+// first choice, put them on 4: a four-way conflict on every fragment read; fit 0.357 -> 0.345 ms at N = 1024, the
+// C5 grid 45.3 -> 43.1 ms).  The price is scalar instead of 16-byte stores when a tile is stashed.
+#define T64_LD 65
 typedef double d2_t __attribute__((ext_vector_type(2)));   // (HIP's double2 struct arrays end up in scratch here)
 __device__ __forceinline__ void tile64_fetch(const double *__restrict__ A, int lda, d2_t (&v)[8])
 {
@@ -164,7 +167,13 @@ __device__ __forceinline__ void tile64_stash(double *As, const d2_t (&v)[8])
 {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < 8; u++) *(d2_t *)(As + (8 * u + (t >> 5)) * LD + (t & 31) * 2) = NEG ? -v[u] : v[u];
+    for (int u = 0; u < 8; u++) {
+        double *dst = As + (8 * u + (t >> 5)) * LD + (t & 31) * 2;
+        if (LD & 1) {                               // odd row stride: rows are 8-byte aligned only
+            dst[0] = NEG ? -v[u].x : v[u].x;
+            dst[1] = NEG ? -v[u].y : v[u].y;
+        } else *(d2_t *)dst = NEG ? -v[u] : v[u];
+    }
 }
 template <int LD = T64_LD>
 __device__ __forceinline__ void tile64_mma_nt(const double *As, const double *Bs, d4_t (&acc)[2][2])
@@ -228,7 +237,7 @@ __device__ __forceinline__ void tile64_mma_nt_tri(const double *As, const double
 // ------------------------------------------------------------------------
 // blocked right-looking Cholesky, NB = 64
 // ------------------------------------------------------------------------
-#define SD 68
+#define SD 65
 #ifdef IBO_STAMPS      // diagnostic build (tools/chol_diag_bench.hip): where does the diagonal block's time go?
 __device__ unsigned long long g_chol_stamps[32];
 #define CSTAMP(i) do { if (threadIdx.x == 0) g_chol_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
