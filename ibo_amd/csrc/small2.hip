@@ -25,7 +25,7 @@ template <int FAM, int KA4>
 __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(SweepArgs a, double *__restrict__ Kf, double *__restrict__ mupart, int Mp)
 {
     constexpr int KA = 4 * KA4;
-    __shared__ double lds_c[SM_TC * KA];
+    __shared__ double lds_c[SM_TC * (KA + 1)];
     __shared__ double lds_tab[2048];
     __shared__ double lds_al[2][128];
     __shared__ double lds_m[2][SM_NW][16];
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(SweepArgs a, do
     s2_stage_candidates<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)ctile * SM_TC, lds_c);
     const int rt = wave >> 1, gcb = wave & 1;
     const int tile = t * 8 + rt;
-    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * KA + (lane >> 4)];
+    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * (KA + 1) + (lane >> 4)];
     const double *xa = a.XA + (size_t)tile * KA4 * 64 + lane;
     d4_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4;
     static_assert(CBW == 2 && S2_NW * RBW * 16 == S2_PANEL && (S2_KCH / 16) * CBW == S2_NW, "tile geometry");
     __shared__ double lds_k[2][S2_KCH * TCAND];    // K* stages in B-fragment order: [k4-step][cand-block][lane]
-    __shared__ double lds_c[TCAND * KA];            // augmented, scaled candidates [cand][KA]
+    __shared__ double lds_c[TCAND * (KA + 1)];            // augmented, scaled candidates [cand][KA]
     __shared__ double lds_q[S2_NW][TCAND];
     __shared__ double lds_m[2][S2_NW][16];
     __shared__ double lds_tab[2048];                // 2^(j/2048)
@@ -65,28 +65,28 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
         const int c = e / KA, col = e - c * KA;
         int64_t gi = tile0 + c;
         if (gi > a.M - 1) gi = a.M - 1;
-        lds_c[e] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
+        lds_c[c * (KA + 1) + col] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
     }
     __syncthreads();
     if (tid < TCAND) {
         double n2 = 0.0;
-        for (int d = 0; d < D; d++) { const double v = lds_c[tid * KA + d]; n2 = fma(v, v, n2); }
+        for (int d = 0; d < D; d++) { const double v = lds_c[tid * (KA + 1) + d]; n2 = fma(v, v, n2); }
         // A candidate more than 775 length scales from the origin (hence > 450 from every observation: |x~| <= 316
         // where the dot form is in use) has k* = 0 exactly; it is pulled in to that radius, where k* is still 0, so
         // that the exponent stays within what s2_exp's integer arithmetic covers (|y| < 7e5).
         if (n2 > 6e5) {
             const double sc = sqrt(6e5 / n2);
-            for (int d = 0; d < D; d++) lds_c[tid * KA + d] *= sc;
+            for (int d = 0; d < D; d++) lds_c[tid * (KA + 1) + d] *= sc;
             n2 = 6e5;
         }
-        lds_c[tid * KA + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
+        lds_c[tid * (KA + 1) + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
     }
     __syncthreads();
     // this wave generates the 16 x 16 tile (row-tile rt, candidate block gcb) of every stage
     const int rt = wave >> 1, gcb = wave & 1;
     // its B-fragments of the exponent GEMM, c~aug[candidate 16 gcb + (lane&15)][4 s + (lane>>4)], are re-read from
     // LDS at every generation (KA4 reads, no VALU) rather than held in 2 KA4 registers
-    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * KA + (lane >> 4)];
+    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * (KA + 1) + (lane >> 4)];
 
     const int Npad = a.Npad;
     const int nk8 = Npad >> 3;
@@ -314,7 +314,7 @@ template <int FAM, int KA4>
 __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
 {
     constexpr int TCAND = IBO_S2_TCAND, KA = 4 * KA4;
-    __shared__ double lds_c[TCAND * KA];
+    __shared__ double lds_c[TCAND * (KA + 1)];
     __shared__ double lds_m[3][S2_NW][16];
     __shared__ double lds_tab[2048];
     extern __shared__ __attribute__((aligned(16))) double lds_vec[];     // alphaY, alpha1, new row of W: NA128 each
@@ -334,22 +334,22 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
         const int c = e / KA, col = e - c * KA;
         int64_t gi = tile0 + c;
         if (gi > a.M - 1) gi = a.M - 1;
-        lds_c[e] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
+        lds_c[c * (KA + 1) + col] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
     }
     __syncthreads();
     if (tid < TCAND) {                               // as sweep2_kernel: radius guard, then b_c
         double n2 = 0.0;
-        for (int d = 0; d < D; d++) { const double v = lds_c[tid * KA + d]; n2 = fma(v, v, n2); }
+        for (int d = 0; d < D; d++) { const double v = lds_c[tid * (KA + 1) + d]; n2 = fma(v, v, n2); }
         if (n2 > 6e5) {
             const double sc = sqrt(6e5 / n2);
-            for (int d = 0; d < D; d++) lds_c[tid * KA + d] *= sc;
+            for (int d = 0; d < D; d++) lds_c[tid * (KA + 1) + d] *= sc;
             n2 = 6e5;
         }
-        lds_c[tid * KA + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
+        lds_c[tid * (KA + 1) + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
     }
     __syncthreads();
     const int rt = wave >> 1, gcb = wave & 1;
-    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * KA + (lane >> 4)];
+    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * (KA + 1) + (lane >> 4)];
     const __amdgpu_buffer_rsrc_t rXA = s2_rsrc(a.XA, (size_t)(NA128 / 16) * KA4 * 64 * sizeof(double));
     const unsigned lane8 = lane * 8;
     const double *vq = lds_vec + (lane >> 4);
@@ -425,8 +425,9 @@ int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, 
     return (int)hipGetLastError();
 }
 
-// dynamic LDS: the two alpha vectors (rows padded to 128); static: 64 KiB of k* stages + ~13 KiB
-#define S2_STATIC_LDS (80 * 1024)
+// dynamic LDS: the two alpha vectors (rows padded to 128); static: 64 KiB of k* stages, 16 KiB exp table, candidates
+// (32 x 21), q and mean partials (4 + 4 KiB): 95.5 KiB
+#define S2_STATIC_LDS (96 * 1024)
 bool sweep2_fits(int Npad)
 {
     return (size_t)((Npad + 127) & ~127) * 16 + S2_STATIC_LDS <= 160 * 1024;      // (the refresh kernel's 24 B/row + 27 KiB fit whenever this does)

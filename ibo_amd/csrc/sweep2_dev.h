@@ -91,7 +91,7 @@ __device__ __forceinline__ double s2_kstar(double y, double sf2, const double *t
     return sf2 * poly * s2_exp(-rr, tab);
 }
 
-// TCAND candidates of a tile -> lds_c[cand][KA] = [c~ (D) | 1 | b_c | 0..]  (c~ = c sqrt(w)).  A candidate more than 775
+// TCAND candidates of a tile -> lds_c[cand][KA (+1: odd row stride, conflict-free fragment reads)] = [c~ (D) | 1 | b_c | 0..]  (c~ = c sqrt(w)).  A candidate more than 775
 // length scales from the origin (hence > 450 from every observation: |x~| <= 316 where the dot form is in use) has k* = 0
 // exactly; it is pulled in to that radius, where k* is still 0, so that the exponent stays within what s2_exp's integer
 // arithmetic covers (|y| < 7e5).  Called by the whole workgroup; ends with a barrier.
@@ -103,18 +103,18 @@ __device__ __forceinline__ void s2_stage_candidates(const SweepArgs &a, int64_t 
         const int c = e / KA, col = e - c * KA;
         int64_t gi = tile0 + c;
         if (gi > a.M - 1) gi = a.M - 1;
-        lds_c[e] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
+        lds_c[c * (KA + 1) + col] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
     }
     __syncthreads();
     if (tid < TCAND) {
         double n2 = 0.0;
-        for (int d = 0; d < D; d++) { const double v = lds_c[tid * KA + d]; n2 = fma(v, v, n2); }
+        for (int d = 0; d < D; d++) { const double v = lds_c[tid * (KA + 1) + d]; n2 = fma(v, v, n2); }
         if (n2 > 6e5) {
             const double sc = sqrt(6e5 / n2);
-            for (int d = 0; d < D; d++) lds_c[tid * KA + d] *= sc;
+            for (int d = 0; d < D; d++) lds_c[tid * (KA + 1) + d] *= sc;
             n2 = 6e5;
         }
-        lds_c[tid * KA + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
+        lds_c[tid * (KA + 1) + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
     }
     __syncthreads();
 }
