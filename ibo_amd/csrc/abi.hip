@@ -194,6 +194,7 @@ struct ibo_gp {
     unsigned long long *done_flag = nullptr;   // pinned host word small2.hip's last kernel writes; done_seq: last value asked for
     unsigned long long done_seq = 0;
     bool signal_pending = false;
+    const double *alpha_tail_Y = nullptr, *alpha_tail_1 = nullptr; int alpha_tail_Np = 0;   // where the alpha vectors' zero tails are
     DevBuf<unsigned> done_count;
     // preference GP (ibo_pref_*): R^-1, the matrix being factored and its factors, vectors, sparse terms
     struct PrefWork {
@@ -408,8 +409,11 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
     IBO_TRY(g->T.ensure(nn)); IBO_TRY(g->Wp.ensure(nn)); IBO_TRY(g->diag64.ensure((size_t)(Np / 64) * 4096));
     // sweep2's stages cover rows up to the next multiple of 128: the tail of both alpha vectors stays zero
     IBO_TRY(g->alphaY.ensure((size_t)Np + 128)); IBO_TRY(g->alpha1.ensure((size_t)Np + 128));
-    HIP_TRY(hipMemsetAsync(g->alphaY.p + Np, 0, 128 * sizeof(double), g->stream));
-    HIP_TRY(hipMemsetAsync(g->alpha1.p + Np, 0, 128 * sizeof(double), g->stream));
+    if (g->alpha_tail_Y != g->alphaY.p || g->alpha_tail_1 != g->alpha1.p || g->alpha_tail_Np != Np) {     // (nothing writes there)
+        HIP_TRY(hipMemsetAsync(g->alphaY.p + Np, 0, 128 * sizeof(double), g->stream));
+        HIP_TRY(hipMemsetAsync(g->alpha1.p + Np, 0, 128 * sizeof(double), g->stream));
+        g->alpha_tail_Y = g->alphaY.p; g->alpha_tail_1 = g->alpha1.p; g->alpha_tail_Np = Np;
+    }
     IBO_TRY(g->tmp.ensure(3 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));     // launch_alpha's scratch + one vector (ibo_gp_extend)
     IBO_TRY(g->info.ensure(1));
     std::vector<double> xp((size_t)Np * DP, 0.0), yp(Np, 0.0);
@@ -453,26 +457,33 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     // R, and in the same pass the identity-padded copy the factorisation works on
     const bool fused = Np / 64 <= 32 && g_chol_fused;
     double *work = fused ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
+    // (with the working copy the same pass writes the identity the ride-along starts from and clears the info word)
+    const bool ride = fused && g_chol_ride != 0;
+    const bool one_pass = ride && !A_host;
     KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, Np, s,
-                                 A_host ? nullptr : work, Np));
+                                 A_host ? nullptr : work, Np, 0, one_pass ? g->W.p : nullptr, one_pass ? g->info.p : nullptr));
     if (A_host) KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
+    bool packed = false;
     if (fused) {
         // small enough for the plain right-looking order: one fused launch per block column, out of place, with
-        // W = L^-1 riding along (E = I in W's buffer turns into (L^-1)^T in Wp's, then is transposed into W)
-        // (a step's trailing + extra tiles number at most nb (nb - 1) / 2: 496 at N = 2048, two per workgroup)
-        const bool ride = g_chol_ride != 0;
-        if (ride) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, g->W.p, Np, 1.0, s));       // identity
+        // W = L^-1 riding along (E = I in W's buffer turns into (L^-1)^T in Wp's, which is transposed into W and packed
+        // into T's buffer -- free by then -- in one pass; T and Wp then trade places)
+        // (a step's trailing + extra tiles number at most nb (nb + 1) / 2 - 1: 527 at N = 2048, two per workgroup)
+        if (ride && !one_pass) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, g->W.p, Np, 1.0, s));       // identity
         KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s, ride ? g->W.p : nullptr,
-                                         ride ? g->Wp.p : nullptr));
+                                         ride ? g->Wp.p : nullptr, one_pass));
         g->L_upper_dirty = true;    // the strict upper blocks of L are scratch until someone asks for L
-        if (ride) KERNEL_TRY(launch_transpose_lower(g->Wp.p, g->W.p, Np, s));
-        else KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
+        if (ride) {
+            KERNEL_TRY(launch_transpose_pack(g->Wp.p, N, Np, g->W.p, g->T.p, s));
+            std::swap(g->T, g->Wp);
+            packed = true;
+        } else KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     } else {
         KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s, g->T.p));      // T: free until launch_trinv
         g->L_upper_dirty = true;
         KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     }
-    KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));
+    if (!packed) KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));
     KERNEL_TRY(launch_alpha(g->W.p, N, Np, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, s));
     HIP_TRY(hipEventRecord(g->fit1, s));
     IBO_TRY(check_info(g, info));

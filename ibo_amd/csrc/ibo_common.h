@@ -208,7 +208,8 @@ int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, 
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
-                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2 = nullptr, int np2 = 0, int lower_only = 0);
+                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2 = nullptr, int np2 = 0, int lower_only = 0,
+                      double *Eye = nullptr, int *zero_word = nullptr);     // Eye: np2 x np2 identity written in the same pass (with K2)
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the
 // inverses of the 64x64 diagonal blocks; info (device int) gets the 1-based failing pivot or 0
 // ws (optional): workspace of 2 * Npad * 64 * panel doubles per matrix (wstride apart) for the packed-panel trailing
@@ -224,8 +225,10 @@ void set_chol_panel_rows(int v);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
 // Ework (identity on entry) / Eout, optional: W = L^-1 rides along -- Eout receives (L^-1)^T, blocks on and above the diagonal
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s,
-                          double *Ework = nullptr, double *Eout = nullptr);
+                          double *Ework = nullptr, double *Eout = nullptr, bool info_is_zero = false);
 int launch_transpose_lower(const double *Et, double *W, int Npad, hipStream_t s);
+// W = Et^T (lower, rows >= N zero) and its MFMA-fragment-order copy Wp (another buffer than Et) in one pass
+int launch_transpose_pack(const double *Et, int N, int Npad, double *W, double *Wp, hipStream_t s);
 // W = L^-1 (row-major, ld = Npad) using diag64 from launch_cholesky and a scratch T (Npad x Npad)
 int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s,
                  bool zero_fill = true);

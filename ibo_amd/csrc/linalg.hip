@@ -27,12 +27,23 @@
 __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
                                                          const double *__restrict__ A2, int ldp, int square,
                                                          int diag_rule, double noise, double *__restrict__ K, int ldk,
-                                                         double *__restrict__ K2, int np2, int lower_only)
+                                                         double *__restrict__ K2, int np2, int lower_only,
+                                                         double *__restrict__ Eye, int *__restrict__ zero_word)
 {
     __shared__ double As[64 * COV_LD], Bs[64 * COV_LD];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64, D = kp.D;
+    if (zero_word && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) *zero_word = 0;
     if (lower_only && j0 > i0 + 63) return;          // a factorisation only reads the lower triangle
+    if (Eye) {                                       // an np2 x np2 identity in the same pass (the fit's ride-along rows)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int i = i0 + ty * 4 + r, j = j0 + tx + 16 * c;
+                if (i < np2 && j < np2) Eye[(size_t)i * np2 + j] = (i == j) ? 1.0 : 0.0;
+            }
+    }
     for (int e = t; e < 64 * D; e += 256) {
         const int r = e / D, d = e - r * D;
         As[r * COV_LD + d] = (i0 + r < n1) ? A1[(size_t)(i0 + r) * ldp + d] : 0.0;
@@ -80,14 +91,15 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
 // K2 (optional, square case): a second, np2 x np2 copy of K padded with the identity -- the matrix the
 // factorisation works on, written by the same kernel instead of a separate pad-and-copy pass.
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
-                      int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2, int lower_only)
+                      int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2, int lower_only,
+                      double *Eye, int *zero_word)
 {
     int square = (A2 == nullptr);
     if (square) { A2 = A1; n2 = n1; }
     const int c = K2 ? np2 : n2, r = K2 ? np2 : n1;
     dim3 grid((c + 63) / 64, (r + 63) / 64);
     hipLaunchKernelGGL(cov_matrix_kernel, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
-                       diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0);
+                       diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0, K2 ? Eye : nullptr, zero_word);
     return (int)hipGetLastError();
 }
 
@@ -861,11 +873,11 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // and is destroyed, the factor (lower blocks; the strict upper blocks are not touched) goes to `out`.
 // Bit-identical to launch_cholesky with panel = 1.
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s, double *Ework,
-                          double *Eout)
+                          double *Eout, bool info_is_zero)
 {
     const int nb = Npad / 64;
     const int CU = 256, MAXT = 2 * CU;                  // tiles one fused launch takes: two per workgroup
-    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    if (!info_is_zero) HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     for (int jb = 0; jb < nb; jb++) {
         const int m = nb - jb - 1, nchol = m * (m + 1) / 2;
         const int nextra = (Ework && m > 0) ? (jb + 1) * m : 0;       // tiles of the W = L^-1 ride-along (chol_step_kernel)
@@ -919,6 +931,42 @@ __global__ void transpose_lower_kernel(const double *__restrict__ Et, double *__
         const int r = e >> 6, c = e & 63;
         W[(size_t)(by + r) * Npad + bx + c] = (bx + c <= by + r) ? tile[c][r] : 0.0;
     }
+}
+
+// The same with the result's rows >= N zeroed, and a second copy in MFMA fragment order (pack_w_kernel's layout, mode 0):
+// the fit's transpose and packing passes in one.  Wp must not be Et's buffer.
+__global__ void transpose_pack_kernel(const double *__restrict__ Et, int N, int Npad, double *__restrict__ W,
+                                      double *__restrict__ Wp)
+{
+    __shared__ double tile[64][65];
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 64;       // W block (row block y, column block x)
+    const int nk8 = Npad / 8;
+    const bool lower = blockIdx.x <= blockIdx.y;
+    if (lower) {
+        for (int e = threadIdx.x; e < 4096; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            tile[r][c] = Et[(size_t)(bx + r) * Npad + by + c];   // Et block (x, y)
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        const int row = by + r, col = bx + c;
+        W[(size_t)row * Npad + col] = (lower && row < N && col <= row) ? tile[c][r] : 0.0;
+    }
+    // packed copy: the block's 4 row groups x 8 column steps, 128 consecutive doubles each
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int h = e & 1, lane = (e >> 1) & 63, chunk = e >> 7;       // chunk = g_local * 8 + j_local
+        const int r = 16 * (chunk >> 3) + (lane & 15), c = 8 * (chunk & 7) + 4 * h + (lane >> 4);
+        const int row = by + r, col = bx + c;
+        const size_t dst = ((((size_t)(row >> 4) * nk8 + (col >> 3)) * 64 + lane) << 1) + h;
+        Wp[dst] = (lower && row < N && col <= row) ? tile[c][r] : 0.0;
+    }
+}
+int launch_transpose_pack(const double *Et, int N, int Npad, double *W, double *Wp, hipStream_t s)
+{
+    hipLaunchKernelGGL(transpose_pack_kernel, dim3(Npad / 64, Npad / 64), dim3(256), 0, s, Et, N, Npad, W, Wp);
+    return (int)hipGetLastError();
 }
 
 int launch_transpose_lower(const double *Et, double *W, int Npad, hipStream_t s)
