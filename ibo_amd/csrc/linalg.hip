@@ -326,9 +326,7 @@ __device__ __forceinline__ void diag64_stash(const double (&v)[16], double *S, d
         S[(4 * u + (t >> 6)) * SD + (t & 63)] = v[u];
         V[(4 * u + (t >> 6)) * SD + (t & 63)] = 0.0;
     }
-#ifndef IBO_DIAG_V1
     T[(t >> 4) * SD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;       // diag64_dpp.h: the identity rows
-#endif
 }
 __device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *S, double *V, double *T)
 {
@@ -348,109 +346,7 @@ __device__ __forceinline__ void diag64_store(double *Lb, int Npad, double *Db, c
     }
 }
 
-#ifndef IBO_DIAG_V1
 #include "diag64_dpp.h"
-#else          // round 1's chain (v_readlane broadcasts, all four inverses at the end): kept for tools/chol_diag_bench
-// S: the 64x64 block (row stride SD), V: zeros.  On return S holds the factor (lower triangle; the strict upper
-// part is scratch), V its inverse.  T is scratch.  Called by all 256 threads; ends with a barrier.
-__device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info)
-{
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    for (int b = 0; b < 4; b++) {
-        const int o = 16 * b;
-        if (wv == 0) {
-            // (i) panel factorisation, lane = row o+lane (lanes past row 63 work on a copy of it, unused)
-            const int rr = min(o + lane, 63);
-            double r[16];
-            int bad = -1;
-#pragma unroll
-            for (int k = 0; k < 16; k++) r[k] = S[rr * SD + o + k];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const double d = lane_bcast(r[j], j);
-                // a pivot <= 0 (or NaN) only has to be recorded: it turns the rest of the block into
-                // NaN, nothing traps, and the host reports info.  Keeping the test off the dependent
-                // chain (no select on d) is worth ~10 % of this kernel.
-                bad = (d > 0.0 || bad >= 0) ? bad : j;
-                const double y0 = __builtin_amdgcn_rsq(d);
-                const double l0 = r[j] * y0;
-                const double e = fma(-d * y0, y0, 1.0);               // 1 - d y0^2
-                const double l = fma(l0 * e, fma(0.375, e, 0.5), l0); // r[j] / sqrt(d)
-                r[j] = l;
-#pragma unroll
-                for (int k = j + 1; k < 16; k++) r[k] = fma(-l, lane_bcast(l, k), r[k]);
-            }
-            if (bad >= 0 && lane == 0 && info) atomicCAS(info, 0, pivot0 + o + bad + 1);
-            if (o + lane < 64) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) S[rr * SD + o + k] = (k <= lane) ? r[k] : 0.0;
-            }
-            CSTAMP(2 + 5 * b);
-        }
-        __syncthreads();
-        CSTAMP(4 + 5 * b);
-        const int nt = 3 - b;                       // 16-row tiles below the panel
-        // (iii) trailing update: S22 -= X X^T, tiles (it, kt <= it)
-        for (int p = wv; p < nt * (nt + 1) / 2; p += 4) {
-            const int it = (p >= 3) ? 2 : (p >= 1) ? 1 : 0, kt = p - it * (it + 1) / 2;
-            d4_t acc = lds_mm16<true, 16>(S + (o + 16 + 16 * it) * SD + o, S + (o + 16 + 16 * kt) * SD + o);
-            double *C = S + (o + 16 + 16 * it) * SD + o + 16 + 16 * kt;
-#pragma unroll
-            for (int r = 0; r < 4; r++) C[MM16_ROW(r) * SD + MM16_COL] -= acc[r];
-        }
-        if (nt > 0) __syncthreads();
-        CSTAMP(6 + 5 * b);
-    }
-    // inverse of the 16x16 diagonal factor `wv`: lane i holds row i of the factor, lane c computes
-    // column c of the inverse (x[i] = V16[i][c]); right-looking, so the 15-k updates of a step are independent
-    {
-        const int o = 16 * wv, rr = o + min(lane, 15);
-        double r[16], x[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            r[k] = S[rr * SD + o + k];
-            x[k] = (k == lane) ? 1.0 : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            x[k] *= rcp_newton(lane_bcast(r[k], k));
-#pragma unroll
-            for (int i = k + 1; i < 16; i++) x[i] = fma(-lane_bcast(r[k], i), x[k], x[i]);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) V[(o + i) * SD + o + lane] = x[i];
-        }
-    }
-    __syncthreads();
-    CSTAMP(21);
-    // inverse by recursive doubling over 16-blocks: [L11 0; L21 L22]^-1 = [V11 0; -V22 L21 V11, V22]
-    // level 16: two nodes (o = 0, 32), one tile each
-    if (wv < 2) {
-        const int o = 32 * wv;
-        d4_t acc = lds_mm16<false, 16>(S + (o + 16) * SD + o, V + o * SD + o);
-#pragma unroll
-        for (int r = 0; r < 4; r++) T[(o + 16 + MM16_ROW(r)) * SD + o + MM16_COL] = acc[r];
-        // the same wave consumes its own T tile: LDS operations of one wave complete in order
-        acc = lds_mm16<false, 16>(V + (o + 16) * SD + o + 16, T + (o + 16) * SD + o);
-#pragma unroll
-        for (int r = 0; r < 4; r++) V[(o + 16 + MM16_ROW(r)) * SD + o + MM16_COL] = -acc[r];
-    }
-    __syncthreads();
-    // level 32: one node, 2x2 tiles
-    {
-        const int ti = wv >> 1, tj = wv & 1;
-        d4_t acc = lds_mm16<false, 32>(S + (32 + 16 * ti) * SD, V + 16 * tj);
-#pragma unroll
-        for (int r = 0; r < 4; r++) T[(32 + 16 * ti + MM16_ROW(r)) * SD + 16 * tj + MM16_COL] = acc[r];
-        __syncthreads();
-        acc = lds_mm16<false, 32>(V + (32 + 16 * ti) * SD + 32, T + 32 * SD + 16 * tj);
-#pragma unroll
-        for (int r = 0; r < 4; r++) V[(32 + 16 * ti + MM16_ROW(r)) * SD + 16 * tj + MM16_COL] = -acc[r];
-    }
-    __syncthreads();
-}
-#endif
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *L, int Npad, int jb,
                                                         double *__restrict__ diag64, int *info,
