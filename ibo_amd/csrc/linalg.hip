@@ -1149,10 +1149,18 @@ __global__ __launch_bounds__(256) void gemv_lower2_kernel(const double *__restri
     if (row >= Npad) return;
     const double *w = W + (size_t)row * Npad;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = lane; k <= row && k < N; k += 64) {
-        double v = w[k];
-        s0 += v * y[k];
-        s1 += v;
+    const int kend = row < N - 1 ? row : N - 1;                 // last column of this row
+    for (int k0 = lane; k0 <= kend; k0 += 8 * 64) {             // a lane's terms in index order, eight loads in flight
+        double v[8], yy[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + 64 * u;
+            v[u] = k <= kend ? w[k] : 0.0;
+            yy[u] = k <= kend ? y[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k0 + 64 * u <= kend) { s0 += v[u] * yy[u]; s1 += v[u]; }
     }
     for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
     if (lane == 0) { t2[row] = s0; t2[Npad + row] = s1; }
@@ -1190,9 +1198,17 @@ __global__ void alpha_reduce_kernel(const double *__restrict__ partial, int Npad
     if (j >= Npad) return;
     int nch = Npad / 64;
     double s0 = 0.0, s1 = 0.0;
-    for (int c = 0; c < nch; c++) {
-        s0 += partial[(size_t)c * Npad + j];
-        s1 += partial[(size_t)(nch + c) * Npad + j];
+    // index order, eight terms' loads in flight at a time (one by one the L2 round trip of every term is on the chain:
+    // 64 terms at N = 4096 took 20 us)
+    for (int c0 = 0; c0 < nch; c0 += 8) {
+        double v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            v0[u] = c0 + u < nch ? partial[(size_t)(c0 + u) * Npad + j] : 0.0;
+            v1[u] = c0 + u < nch ? partial[(size_t)(nch + c0 + u) * Npad + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (c0 + u < nch) { s0 += v0[u]; s1 += v1[u]; }
     }
     aY[j] = s0; a1[j] = s1;
 }
@@ -1348,10 +1364,17 @@ __global__ __launch_bounds__(256) void nlml_reduce_kernel(const double *__restri
     __shared__ double rq[256], rl[256];
     const int t = threadIdx.x;
     double q = 0.0, ld = 0.0;
-    for (int k = t; k < N; k += 256) {
-        double z = L[(size_t)N * Npad + k];
-        q = fma(z, z, q);
-        ld += log(L[(size_t)k * Npad + k]);
+    for (int k0 = t; k0 < N; k0 += 8 * 256) {         // same order of the sums; eight diagonal entries' loads in flight
+        double z[8], dg[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + 256 * u;
+            z[u] = k < N ? L[(size_t)N * Npad + k] : 0.0;
+            dg[u] = k < N ? L[(size_t)k * Npad + k] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k0 + 256 * u < N) { q = fma(z[u], z[u], q); ld += log(dg[u]); }
     }
     rq[t] = q; rl[t] = ld;
     __syncthreads();

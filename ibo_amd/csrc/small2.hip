@@ -131,9 +131,27 @@ __global__ __launch_bounds__(64) void small_finish_kernel(SweepArgs a, const dou
     const int64_t li = (int64_t)blockIdx.x * 64 + lane;
     const bool valid = li < a.M;
     const int64_t ci = valid ? li : a.M - 1;
+    // The sums keep their index order, but the loads of 16 terms are in flight together: one term at a time, each
+    // load's L2 round trip (~270 ns) sat on the dependent chain -- 128 + 32 of them at N = 2048 made this the longest
+    // of the three kernels (35 us against 15 for the product itself).
     double q = 0.0, my = 0.0, m1 = 0.0;
-    for (int g = 0; g < nrb; g++) q += qpart[(size_t)g * Mp + ci];
-    for (int t = 0; t < nst; t++) { my += mupart[(size_t)(2 * t) * Mp + ci]; m1 += mupart[(size_t)(2 * t + 1) * Mp + ci]; }
+    for (int g0 = 0; g0 < nrb; g0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = g0 + u < nrb ? qpart[(size_t)(g0 + u) * Mp + ci] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (g0 + u < nrb) q += v[u];
+    }
+    for (int t0 = 0; t0 < nst; t0 += 8) {
+        double vy[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            vy[u] = t0 + u < nst ? mupart[(size_t)(2 * (t0 + u)) * Mp + ci] : 0.0;
+            v1[u] = t0 + u < nst ? mupart[(size_t)(2 * (t0 + u) + 1) * Mp + ci] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (t0 + u < nst) { my += vy[u]; m1 += v1[u]; }
+    }
     bool excl;
     double val = s2_finish(a, a.cand + ci * a.kp.D, q, my, m1, li, valid, excl);
     int64_t idx = a.index_base + li;

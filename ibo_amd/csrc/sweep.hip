@@ -454,7 +454,13 @@ __global__ __launch_bounds__(64) void sweep_gemv_finish_kernel(SweepArgs a, int 
     bool valid = li < a.M;
     int64_t ci = valid ? li : a.M - 1;
     double q = 0.0;
-    for (int rc = 0; rc < nrc; rc++) q += a.qpart[(size_t)rc * a.M + ci];
+    for (int r0 = 0; r0 < nrc; r0 += 8) {              // index order; eight loads in flight
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = r0 + u < nrc ? a.qpart[(size_t)(r0 + u) * a.M + ci] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (r0 + u < nrc) q += v[u];
+    }
     double xq[IBO_DMAX];
     for (int d = 0; d < a.kp.D; d++) xq[d] = a.cand[ci * a.kp.D + d];
     bool excl;
