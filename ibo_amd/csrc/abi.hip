@@ -1426,17 +1426,29 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     for (int i = 0; i < N; i++) yp[i] = Y[i];
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, yp.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
-    KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p, Np, 1.0, s));                         // identity pad
-    KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p, Np, s));
-    KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
+    // up to 2048 rows: the fit's route -- fused steps with W = L^-1 riding along (dT: the matrix being reduced, dKi: (L^-1)^T
+    // until the transpose) -- instead of the three-kernel columns and the recursive-doubling inversion
+    const bool fused = Np / 64 <= 32 && g_chol_fused && g_chol_ride;
+    if (fused) {
+        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dKi.p, Np, s, dT.p, Np, 0,
+                                     dW.p, dinfo.p));
+        KERNEL_TRY(launch_cholesky_fused(dT.p, dL.p, Np, d64.p, dinfo.p, s, dW.p, dKi.p, true));
+    } else {
+        KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p, Np, 1.0, s));                     // identity pad
+        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p, Np, s));
+        KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
+    }
     int h = 0;
     HIP_TRY(hipMemcpy(&h, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
     int rc = IBO_OK;
     if (h != 0) rc = fail(IBO_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d)", h);
     else {
-        KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
-        KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
-        KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));                      // zero the pad rows
+        if (fused) KERNEL_TRY(launch_transpose_pack(dKi.p, N, Np, dW.p, dT.p, s));     // W, pad rows zero (dT: the packed copy, unused)
+        else {
+            KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
+            KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
+            KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));                  // zero the pad rows
+        }
         KERNEL_TRY(launch_alpha(dW.p, N, Np, dY.p, tmp.p, dal.p, da1.p, s));
         KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s));
         KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, dKi.p, Np, dal.p, dpart.p, dout.p, s));
