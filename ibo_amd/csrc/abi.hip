@@ -1420,7 +1420,7 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(Np)); IBO_TRY(dL.ensure(nn)); IBO_TRY(dW.ensure(nn));
     IBO_TRY(dT.ensure(nn)); IBO_TRY(dKi.ensure(nn)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096));
     IBO_TRY(dal.ensure(Np)); IBO_TRY(da1.ensure(Np)); IBO_TRY(tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));
-    IBO_TRY(dpart.ensure((size_t)ngrad * nblk)); IBO_TRY(dout.ensure(ngrad)); IBO_TRY(dinfo.ensure(1));
+    IBO_TRY(dpart.ensure((size_t)ngrad * nblk)); IBO_TRY(dout.ensure(ngrad + 2)); IBO_TRY(dinfo.ensure(1));
     hipStream_t s = nullptr;
     std::vector<double> yp(Np, 0.0);
     for (int i = 0; i < N; i++) yp[i] = Y[i];
@@ -1438,29 +1438,25 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
         KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p, Np, s));
         KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
     }
-    int h = 0;
-    HIP_TRY(hipMemcpy(&h, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
-    int rc = IBO_OK;
-    if (h != 0) rc = fail(IBO_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d)", h);
+    // no look at the info word until everything is queued: a failed factorisation only turns the rest into NaNs
+    if (fused) KERNEL_TRY(launch_transpose_pack(dKi.p, N, Np, dW.p, dT.p, s));         // W, pad rows zero (dT: the packed copy, unused)
     else {
-        if (fused) KERNEL_TRY(launch_transpose_pack(dKi.p, N, Np, dW.p, dT.p, s));     // W, pad rows zero (dT: the packed copy, unused)
-        else {
-            KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
-            KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
-            KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));                  // zero the pad rows
-        }
-        KERNEL_TRY(launch_alpha(dW.p, N, Np, dY.p, tmp.p, dal.p, da1.p, s));
-        KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s));
-        KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, dKi.p, Np, dal.p, dpart.p, dout.p, s));
-        std::vector<double> al(N), dg(N);
-        HIP_TRY(hipMemcpy(al.data(), dal.p, sizeof(double) * N, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy2D(dg.data(), sizeof(double), dL.p, sizeof(double) * (Np + 1), sizeof(double), N, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(grad_host, dout.p, sizeof(double) * ngrad, hipMemcpyDeviceToHost));
-        double quad = 0.0, logdet = 0.0;
-        for (int i = 0; i < N; i++) { quad += Y[i] * al[i]; logdet += log(dg[i]); }
-        *nlml_host = 0.5 * quad + logdet + 0.5 * N * log(2.0 * M_PI);
+        KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
+        KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
+        KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));                      // zero the pad rows
     }
-    return rc;
+    KERNEL_TRY(launch_alpha(dW.p, N, Np, dY.p, tmp.p, dal.p, da1.p, s));
+    KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s, 1));
+    KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, dKi.p, Np, dal.p, dpart.p, dout.p, s));
+    KERNEL_TRY(launch_nlml_scalars(dL.p, Np, N, dY.p, dal.p, dout.p + ngrad, s));        // (y . alpha, sum log L_ii) behind the gradient
+    std::vector<double> res(ngrad + 2);
+    int h = 0;
+    HIP_TRY(hipMemcpy(res.data(), dout.p, sizeof(double) * (ngrad + 2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&h, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (h != 0) return fail(IBO_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d)", h);
+    for (int i = 0; i < ngrad; i++) grad_host[i] = res[i];
+    *nlml_host = 0.5 * res[ngrad] + res[ngrad + 1] + 0.5 * N * log(2.0 * M_PI);
+    return IBO_OK;
 }
 
 // ------------------------------------------------------------------------ legacy libego symbols

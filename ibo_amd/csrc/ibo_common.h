@@ -243,7 +243,7 @@ int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2
 // Xs = Xp * sqrt(w), ak = -|Xs_k|^2/2; maxnorm2 (device double) receives max_k |Xs_k|^2
 int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double *Xs, double *ak, hipStream_t s);
 // C = W^T W (Wt: scratch for the transpose), all Npad x Npad
-int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s);
+int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, int lower_only = 0);     // lower_only: blocks on and below the diagonal
 int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double *X, int ldx, const double *Kinv, int ldk,
                      const double *alpha, double *partial, double *out, hipStream_t s);
 // one-point block extension (ibo_gp_extend): kvec[i] = k(x_i, x_N) for i < N (zero beyond) and row / column N of R
@@ -253,6 +253,7 @@ int launch_extend_kvec(const KParams &kp, const double *Xp, int ldp, int N, int 
 int launch_extend_rows(int N, int Npad, double noise, const double *z, const double *u, double *L, double *W, double *Wp,
                        int *info, hipStream_t s);
 int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s);
+int launch_nlml_scalars(const double *L, int Npad, int N, const double *y, const double *alpha, double *out2, hipStream_t s);
 int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);
 // preference GP: out = base (or 0) + diag I + sparse entries (lin = row * N + col, distinct), identity pad;  A = R + Cinv
