@@ -197,3 +197,11 @@ class DeviceArray(object):
 
     def __del__(self):
         self.free()
+
+
+def rows(X):
+    """an (N, D) float64 C-contiguous matrix from a matrix or a sequence of points; a matrix passes through without the
+    per-row work np.vstack does (0.9 ms for 2048 rows -- as much as the factorisation it precedes)"""
+    if isinstance(X, np.ndarray) and X.ndim == 2:
+        return f64(X)
+    return f64(np.vstack(X))

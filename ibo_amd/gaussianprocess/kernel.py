@@ -37,7 +37,7 @@ class Kernel(object):
 
     def covMatrix(self, X, device=None):
         """K[i,j] = cov(X[i], X[j]), diagonal included (kernel.py:46-53); GPU-assembled."""
-        X = _lib.f64(np.vstack(X))
+        X = _lib.rows(X)
         n, D = X.shape
         ktype, hyper, sf2, _ = self._ibo_spec()
         K = np.empty((n, n))
@@ -62,7 +62,7 @@ class SVKernel(object):
 
 
 def _sqdiff(X):
-    X = np.vstack(X).astype(float)
+    X = _lib.rows(X)
     return X[:, None, :] - X[None, :, :]
 
 
@@ -137,7 +137,7 @@ class GaussianKernel_ard(Kernel):
         return [(0, d) for d in range(D)]
 
     def derivative(self, X, hp):
-        NA = np.vstack(X).shape[1]
+        NA = _lib.rows(X).shape[1]
         if not hp < NA:
             raise ValueError
         K = self.covMatrix(X)

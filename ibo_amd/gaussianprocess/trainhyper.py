@@ -26,7 +26,7 @@ def _spec_rows(kernels):
 
 def nlml_values(kernels, X, Y, noise=1e-3, device=None):
     """NLML for a list of kernel objects of one class (a theta grid); NaN where K is not PD."""
-    X = _lib.f64(np.vstack(X)); Y = _lib.f64(Y)
+    X = _lib.rows(X); Y = _lib.f64(Y)
     N, D = X.shape
     ktype, thetas, sf2 = _spec_rows(kernels)
     out = np.empty(len(kernels))
@@ -57,7 +57,7 @@ def marginalLikelihood(kernel, X, Y, nhyper, computeGradient=True, useCholesky=T
     # value and gradient in one device call: Cholesky, L^-1, K^-1 = W^T W, then
     # dnlml_i = sum((K^-1 - alpha alpha^T) * dK/dtheta_i) / 2   (:70-71)
     import ctypes
-    Xa = _lib.f64(np.vstack(X)); Ya = _lib.f64(Y)
+    Xa = _lib.rows(X); Ya = _lib.f64(Y)
     N, D = Xa.shape
     ktype, hyper, sf2, _ = kernel._ibo_spec()
     spec = kernel._ibo_grad_spec(D)[:nhyper]
@@ -85,7 +85,7 @@ def _value_and_grad(loghyper, kernel, X, Y):
     # keyed on the CONTENT of the data (a digest: 0.1 ms at N=4096, D=16 against a 9 ms factorisation), so an
     # in-place edit of X or Y can never return the pair computed for the old data
     import hashlib
-    dig = hashlib.blake2b(_lib.f64(np.vstack(X)).tobytes(), digest_size=16)
+    dig = hashlib.blake2b(_lib.rows(X).tobytes(), digest_size=16)
     dig.update(_lib.f64(Y).tobytes())
     key = (loghyper.tobytes(), kernel, dig.digest())
     if _last["key"] != key:
