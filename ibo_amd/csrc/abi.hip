@@ -1132,7 +1132,7 @@ static int ensure_pinned(ibo_gp *g, size_t need)
 // streams while chunk c is in the sweep kernel, so the call costs about the kernel time, not kernel + PCIe +
 // pageable staging.
 static int eval_host_points_pipelined(ibo_gp *g, int64_t M, const double *Q_host, int acq, double parm, int erf_mode,
-                                      double clamp_lo, double *mu_host, double *s2_host, double *acq_host)
+                                      double clamp_lo, double *mu_host, double *s2_host, double *acq_host, double ymax)
 {
     const int64_t CH = (int64_t)1 << 17;
     const int D = g->D;
@@ -1176,7 +1176,7 @@ static int eval_host_points_pipelined(ibo_gp *g, int64_t M, const double *Q_host
         double *dmu = mu_host ? dev_out[b] + m * k++ : nullptr;
         double *ds2 = s2_host ? dev_out[b] + m * k++ : nullptr;
         double *dacq = acq_host ? dev_out[b] + m * k++ : nullptr;
-        IBO_TRY(run_sweep(g, m, dev_in[b], acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
+        IBO_TRY(run_sweep(g, m, dev_in[b], acq, parm, erf_mode, clamp_lo, ymax, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
                           nullptr, nullptr));
         HIP_TRY(hipEventRecord(g->pe_k[b], g->stream));
         HIP_TRY(hipStreamWaitEvent(g->d2h_stream, g->pe_k[b], 0));
@@ -1189,10 +1189,10 @@ static int eval_host_points_pipelined(ibo_gp *g, int64_t M, const double *Q_host
 }
 
 static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq, double parm, int erf_mode,
-                            double clamp_lo, double *mu_host, double *s2_host, double *acq_host)
+                            double clamp_lo, double *mu_host, double *s2_host, double *acq_host, double ymax = NAN)
 {
     if (M >= ((int64_t)1 << 18) && g_host_pipeline)
-        return eval_host_points_pipelined(g, M, Q_host, acq, parm, erf_mode, clamp_lo, mu_host, s2_host, acq_host);
+        return eval_host_points_pipelined(g, M, Q_host, acq, parm, erf_mode, clamp_lo, mu_host, s2_host, acq_host, ymax);
     IBO_TRY(g->cand.ensure((size_t)M * g->D));
     IBO_TRY(g->outs.ensure(3 * (size_t)M));
     // pinned staging (input points + up to 3 output arrays): pageable copies cost ~15 us each and
@@ -1213,7 +1213,7 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     if (s2_host) ds2 = obase + (size_t)M * nout++;
     if (acq_host) dacq = obase + (size_t)M * nout++;
     g->signal_pending = false;
-    IBO_TRY(run_sweep(g, M, zero_copy ? pin_in : g->cand.p, acq, parm, erf_mode, clamp_lo, NAN, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
+    IBO_TRY(run_sweep(g, M, zero_copy ? pin_in : g->cand.p, acq, parm, erf_mode, clamp_lo, ymax, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
                       nullptr, nullptr, false, !zero_copy, zero_copy && g_flag_poll));    // small batches: no kernel-time events either
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
     if (zero_copy) {
@@ -1252,6 +1252,19 @@ extern "C" int ibo_posterior_batch(ibo_gp_t *g, int64_t M, const double *Q_host,
     IBO_TRY(use_device(g->device));
     if (!g->fitted) return fail(IBO_ERR_STATE, "posterior before a successful fit");
     return eval_host_points(g, M, Q_host, IBO_ACQ_NONE, 0.0, IBO_ERF_LIBM, clamp_lo, mu_host, s2_host, nullptr);
+}
+
+// host points in, host arrays out (any of mu / s2 / acq may be NULL): what EI(GP).negf(x), PI, UCB and their vectorised
+// forms ask for -- small batches cost no allocation and no copy launch (pinned staging read and written by the kernels)
+extern "C" int ibo_acq_batch(ibo_gp_t *g, int64_t M, const double *Q_host, int acq, double parm, int erf_mode,
+                             double clamp_lo, double ymax, double *mu_host, double *s2_host, double *acq_host)
+{
+    if (!g || !Q_host || (!mu_host && !s2_host && !acq_host)) return fail(IBO_ERR_ARG, "NULL argument");
+    if (M < 1) return fail(IBO_ERR_ARG, "M=%lld", (long long)M);
+    if (acq < 0 || acq > 3) return fail(IBO_ERR_ARG, "unknown acquisition %d", acq);
+    IBO_TRY(use_device(g->device));
+    if (!g->fitted) return fail(IBO_ERR_STATE, "evaluation before a successful fit");
+    return eval_host_points(g, M, Q_host, acq, parm, erf_mode, clamp_lo, mu_host, s2_host, acq_host, ymax);
 }
 
 // ------------------------------------------------------------------------ DIRECT on the GPU objective

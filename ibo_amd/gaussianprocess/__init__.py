@@ -229,16 +229,14 @@ class GaussianProcess(object):
                 else:
                     val = yd * CDF(Z) + sig * PDF(Z)
             return {"mu": mu, "s2": s2, "acq": val, "best_val": float(np.max(val)), "best_idx": int(np.argmax(val))}
-        cand = _lib.DeviceArray.from_host(Q, self._dev.device)
-        outs = {k: _lib.DeviceArray((M,), self._dev.device) for k in want}
-        bv = ctypes.c_double(); bi = ctypes.c_int64()
-        _lib.check(_lib.lib.ibo_acq_sweep(
-            self._handle(), M, cand.ptr, acq, float(parm), erf_mode, clamp_lo,
-            float('nan') if ymax is None else float(ymax), 0, None, 0.0, 0,
-            outs["mu"].ptr if "mu" in outs else None, outs["s2"].ptr if "s2" in outs else None,
-            outs["acq"].ptr if "acq" in outs else None, ctypes.byref(bv), ctypes.byref(bi)))
-        res = {k: v.to_host() for k, v in outs.items()}
-        res["best_val"], res["best_idx"] = bv.value, bi.value
+        res = {k: np.empty(M) for k in want}
+        ptr = lambda k: _lib.dp(res[k]) if k in res else None
+        _lib.check(_lib.lib.ibo_acq_batch(self._handle(), M, _lib.dp(Q), acq, float(parm), erf_mode, clamp_lo,
+                                          float('nan') if ymax is None else float(ymax), ptr("mu"), ptr("s2"), ptr("acq")))
+        if "acq" in res:                             # first maximiser, NaNs never win: what the device arg-max does
+            score = np.where(np.isnan(res["acq"]), -np.inf, res["acq"])
+            k = int(np.argmax(score))
+            res["best_val"], res["best_idx"] = float(score[k]), k
         return res
 
     # ------------------------------------------------------------------ reference API

@@ -215,6 +215,15 @@ int ibo_posterior_batch(ibo_gp_t *gp, int64_t M, const double *Q_host, double cl
                         double *mu_host, double *s2_host);
 
 /*
+ * The same evaluation for points that live on the HOST (Q_host: M x D), results into host arrays (any of mu_host,
+ * s2_host, acq_host may be NULL): EI / PI / UCB.negf(x) and their vectorised forms (ego/acquisition/__init__.py:47-166).
+ * ymax NaN = max(Y).  Small batches cost no allocation and no copy launch; from 2^18 points on upload, sweep and download
+ * are pipelined in chunks.  ibo_posterior_batch is this with acq = IBO_ACQ_NONE.
+ */
+int ibo_acq_batch(ibo_gp_t *gp, int64_t M, const double *Q_host, int acq, double parm, int erf_mode,
+                  double clamp_lo, double ymax, double *mu_host, double *s2_host, double *acq_host);
+
+/*
  * Fused candidate sweep: the batched equivalent of M calls of
  * GP_Maximizer::negei/negpi/negucb (cpp/optimizeGP.cpp:57-236), i.e. what
  * maximizeEI/PI/UCB evaluate inside DIRECT and what fastUCBGallery's
