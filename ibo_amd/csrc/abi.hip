@@ -109,15 +109,55 @@ static void *pool_get(size_t bytes, size_t *got)
     return p;
 }
 
+static thread_local bool g_pool_quiet = false;       // the caller has synchronised the device already (ibo_gp_destroy: once for all its buffers)
 static void pool_put(void *p, size_t bytes)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    (void)hipDeviceSynchronize();                    // what hipFree would have waited for: nothing in flight uses p
+    if (!g_pool_quiet) (void)hipDeviceSynchronize(); // what hipFree would have waited for: nothing in flight uses p
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool_bytes[dev & 15] + bytes > g_pool_limit) { (void)hipFree(p); return; }
     g_pool[dev & 15].push_back({p, bytes});
     g_pool_bytes[dev & 15] += bytes;
+}
+
+// A handle's stream, events and pinned staging are recycled the same way: creating them costs 1.5-2 ms and destroying
+// them 1.2 ms -- several times the 0.4 ms fit of the model the handle is created for.
+struct ExecSet {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, fit0 = nullptr, fit1 = nullptr;
+    double *pin = nullptr; size_t pin_cap = 0;
+    unsigned long long *done_flag = nullptr;
+};
+static std::vector<ExecSet> g_exec_pool[16];
+static void exec_set_free(ExecSet &x)
+{
+    if (x.ev0) (void)hipEventDestroy(x.ev0);
+    if (x.ev1) (void)hipEventDestroy(x.ev1);
+    if (x.fit0) (void)hipEventDestroy(x.fit0);
+    if (x.fit1) (void)hipEventDestroy(x.fit1);
+    if (x.pin) (void)hipHostFree(x.pin);
+    if (x.done_flag) (void)hipHostFree(x.done_flag);
+    if (x.stream) (void)hipStreamDestroy(x.stream);
+    x = ExecSet();
+}
+static bool exec_set_get(int dev, ExecSet *x)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    std::vector<ExecSet> &v = g_exec_pool[dev & 15];
+    if (v.empty()) return false;
+    *x = v.back();
+    v.pop_back();
+    return true;
+}
+static void exec_set_put(int dev, ExecSet x)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        std::vector<ExecSet> &v = g_exec_pool[dev & 15];
+        if (v.size() < 8 && x.pin_cap * sizeof(double) <= ((size_t)64 << 20)) { v.push_back(x); return; }
+    }
+    exec_set_free(x);
 }
 
 static void pool_trim(int dev)
@@ -126,6 +166,8 @@ static void pool_trim(int dev)
     for (PoolBlock &b : g_pool[dev & 15]) (void)hipFree(b.p);
     g_pool[dev & 15].clear();
     g_pool_bytes[dev & 15] = 0;
+    for (ExecSet &x : g_exec_pool[dev & 15]) exec_set_free(x);
+    g_exec_pool[dev & 15].clear();
 }
 
 template <typename T>
@@ -308,6 +350,14 @@ extern "C" int ibo_gp_create(int device, ibo_gp_t **out)
     ibo_gp *g = new ibo_gp();
     g->device = device;
     memset(&g->kp, 0, sizeof(g->kp));
+    ExecSet x;
+    if (exec_set_get(device, &x)) {
+        g->stream = x.stream; g->ev0 = x.ev0; g->ev1 = x.ev1; g->fit0 = x.fit0; g->fit1 = x.fit1;
+        g->pin = x.pin; g->pin_cap = x.pin_cap; g->done_flag = x.done_flag;
+        if (g->done_flag) *g->done_flag = 0;
+        *out = g;
+        return IBO_OK;
+    }
     hipError_t e = hipStreamCreate(&g->stream);
     if (e == hipSuccess) e = hipEventCreate(&g->ev0);
     if (e == hipSuccess) e = hipEventCreate(&g->ev1);
@@ -330,24 +380,25 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
 {
     if (!g) return IBO_OK;
     (void)hipSetDevice(g->device);
-    (void)hipStreamSynchronize(g->stream);
+    (void)hipDeviceSynchronize();                    // once, for every buffer handed back below
+    g_pool_quiet = true;
     g->Xp.release(); g->Xs.release(); g->ak.release(); g->XA.release(); g->Y.release(); g->R.release(); g->A.release(); g->L.release(); g->W.release();
     g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release(); g->small_ws.release();
-    if (g->pin) (void)hipHostFree(g->pin);
-    if (g->done_flag) (void)hipHostFree(g->done_flag);
-    g->done_flag = nullptr; g->done_count.release();
+    g->done_count.release();
     g->pw.Rinv.release(); g->pw.A.release(); g->pw.Lh.release(); g->pw.E.release(); g->pw.Et.release(); g->pw.d64.release();
     g->pw.vec.release(); g->pw.tmp.release(); g->pw.val.release(); g->pw.lin.release(); g->pw.info.release();
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();
-    (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1);
-    (void)hipEventDestroy(g->fit0); (void)hipEventDestroy(g->fit1);
+    g_pool_quiet = false;
     if (g->h2d_stream) {
         for (int b = 0; b < 2; b++) { (void)hipEventDestroy(g->pe_in[b]); (void)hipEventDestroy(g->pe_k[b]); (void)hipEventDestroy(g->pe_out[b]); }
         (void)hipStreamDestroy(g->h2d_stream); (void)hipStreamDestroy(g->d2h_stream);
     }
-    (void)hipStreamDestroy(g->stream);
+    ExecSet x;
+    x.stream = g->stream; x.ev0 = g->ev0; x.ev1 = g->ev1; x.fit0 = g->fit0; x.fit1 = g->fit1;
+    x.pin = g->pin; x.pin_cap = g->pin_cap; x.done_flag = g->done_flag;
+    exec_set_put(g->device, x);
     delete g;
     return IBO_OK;
 }
@@ -1011,9 +1062,11 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         IBO_TRY(exp_table(g->device, &a.exp_tab));
         IBO_TRY(g->small_ws.ensure(small_sweep_workspace(g->Npad, M)));
         if (signal && !want_best) {                  // the caller will spin on a host-visible word the last kernel writes
-            if (!g->done_flag) {
+            if (!g->done_flag) {                     // (a recycled handle brings its flag along)
                 HIP_TRY(hipHostMalloc((void **)&g->done_flag, 64, hipHostMallocDefault));
                 *g->done_flag = 0;
+            }
+            if (!g->done_count.p) {
                 IBO_TRY(g->done_count.ensure(1));
                 HIP_TRY(hipMemsetAsync(g->done_count.p, 0, sizeof(unsigned), s));
             }
