@@ -239,6 +239,41 @@ __device__ __forceinline__ void tile64_mma_nt_tri(const double *As, const double
     if (wc) tile64_mma_nt_tri_body<LD, 1, 2>(As, Bs, acc, wr, lane);
     else tile64_mma_nt_tri_body<LD, 0, 3>(As, Bs, acc, wr, lane);
 }
+// two such products with the same triangular B (X_i = A_i V^T and X_k = A_k V^T of a fused step): the B fragments are read
+// once and the eight accumulators keep the MFMA pipe fed where one product's tail has only two
+template <int LD, int CB0, int CB1>
+__device__ __forceinline__ void tile64_mma_nt_tri2_body(const double *As1, const double *As2, const double *Bs, d4_t (&acc1)[2][2],
+                                                        d4_t (&acc2)[2][2], int wr, int lane)
+{
+    double a1[16][2], a2[16][2], b0[4 * (CB0 + 1)], b1[4 * (CB1 + 1)];
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            a1[k4][m] = As1[(wr * 32 + m * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+            a2[k4][m] = As2[(wr * 32 + m * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+        }
+        if (k4 < 4 * (CB0 + 1)) b0[k4] = Bs[(CB0 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+        b1[k4] = Bs[(CB1 * 16 + (lane & 15)) * LD + k4 * 4 + (lane >> 4)];
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+        if (k4 < 4 * (CB0 + 1)) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) { acc1[m][0] = mfma_f64(a1[k4][m], b0[k4], acc1[m][0]); acc2[m][0] = mfma_f64(a2[k4][m], b0[k4], acc2[m][0]); }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) { acc1[m][1] = mfma_f64(a1[k4][m], b1[k4], acc1[m][1]); acc2[m][1] = mfma_f64(a2[k4][m], b1[k4], acc2[m][1]); }
+    }
+}
+template <int LD = T64_LD>
+__device__ __forceinline__ void tile64_mma_nt_tri2(const double *As1, const double *As2, const double *Bs, d4_t (&acc1)[2][2],
+                                                   d4_t (&acc2)[2][2])
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
+    if (wc) tile64_mma_nt_tri2_body<LD, 1, 2>(As1, As2, Bs, acc1, acc2, wr, lane);
+    else tile64_mma_nt_tri2_body<LD, 0, 3>(As1, As2, Bs, acc1, acc2, wr, lane);
+}
 #define TILE_COL_TRI(n) (TRI_CB(n) * 16 + (lane & 15))
 
 // C[row][col] for accumulator element (m, n, r) of this lane
@@ -472,8 +507,7 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
         __syncthreads();
         SSTAMP(4);
         d4_t xi[2][2] = {}, xk[2][2] = {};
-        tile64_mma_nt_tri<SD>(S, V, xi);
-        tile64_mma_nt_tri<SD>(T, V, xk);
+        tile64_mma_nt_tri2<SD>(S, T, V, xi, xk);
         SSTAMP(5);
         __syncthreads();
         SSTAMP(6);
