@@ -374,7 +374,7 @@ def worker(args):
                            "n_obs": C5_N, "dim": C5_D, "theta_points_per_gpu": C5_T,
                            "parallelism": "theta-sharded x%d, 1 RCCL all-reduce/step" % world},
                 "best": {"value": float(np.nanmin(outs[-1][0])), "index": int(outs[-1][1])},
-                "roofline": roofline_mfma(f_nlml(C5_N, C5_D), per_theta, kernel="chol_update_kernel (dominant)",
+                "roofline": roofline_mfma(f_nlml(C5_N, C5_D), per_theta, kernel="chol_update2_kernel (dominant)",
                                           ms_per_theta=per_theta * 1e3, flops_per_theta=f_nlml(C5_N, C5_D),
                                           note="whole grid step incl. K assembly, factorisation chain, reductions and the "
                                                "gather; per-kernel times are in profiles/"),

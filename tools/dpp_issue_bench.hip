@@ -8,7 +8,7 @@ __global__ void bench(double *p, unsigned long long *out)
 {
     double a0 = p[threadIdx.x], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     double x = a0 * 0.5, y = a0 * 0.25;
-    unsigned long long t[8];
+    unsigned long long t[11];
     auto T = [&](int i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory"); t[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     T(0);   // 128 independent plain fmac (8 accumulators round robin)
     REP16(asm volatile("v_fmac_f64 %0, %8, %9\n\tv_fmac_f64 %1, %8, %9\n\tv_fmac_f64 %2, %8, %9\n\tv_fmac_f64 %3, %8, %9\n\tv_fmac_f64 %4, %8, %9\n\tv_fmac_f64 %5, %8, %9\n\tv_fmac_f64 %6, %8, %9\n\tv_fmac_f64 %7, %8, %9"
@@ -41,20 +41,30 @@ __global__ void bench(double *p, unsigned long long *out)
     T(6);   // 128 independent plain v_mul_f64 (VOP3)
     REP16(asm volatile("v_mul_f64 %0, %8, %9\n\tv_mul_f64 %1, %8, %9\n\tv_mul_f64 %2, %8, %9\n\tv_mul_f64 %3, %8, %9\n\tv_mul_f64 %4, %8, %9\n\tv_mul_f64 %5, %8, %9\n\tv_mul_f64 %6, %8, %9\n\tv_mul_f64 %7, %8, %9"
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));)
-    T(7);
+    T(7);   // 128 x (s_nop 0 + dependent fmac)
+    REP16(asm volatile("s_nop 0\n\tv_fmac_f64 %0, %1, %2\n\ts_nop 0\n\tv_fmac_f64 %0, %1, %2\n\ts_nop 0\n\tv_fmac_f64 %0, %1, %2\n\ts_nop 0\n\tv_fmac_f64 %0, %1, %2\n\ts_nop 0\n\tv_fmac_f64 %0, %1, %2\n\ts_nop 0\n\tv_fmac_f64 %0, %1, %2\n\ts_nop 0\n\tv_fmac_f64 %0, %1, %2\n\ts_nop 0\n\tv_fmac_f64 %0, %1, %2"
+        : "+v"(a0) : "v"(x), "v"(y));)
+    T(8);   // 128 x (s_setprio 0 + dependent fmac)
+    REP16(asm volatile("s_setprio 0\n\tv_fmac_f64 %0, %1, %2\n\ts_setprio 0\n\tv_fmac_f64 %0, %1, %2\n\ts_setprio 0\n\tv_fmac_f64 %0, %1, %2\n\ts_setprio 0\n\tv_fmac_f64 %0, %1, %2\n\ts_setprio 0\n\tv_fmac_f64 %0, %1, %2\n\ts_setprio 0\n\tv_fmac_f64 %0, %1, %2\n\ts_setprio 0\n\tv_fmac_f64 %0, %1, %2\n\ts_setprio 0\n\tv_fmac_f64 %0, %1, %2"
+        : "+v"(a0) : "v"(x), "v"(y));)
+    T(9);   // 128 x (s_mov_b32 + dependent fmac)
+    REP16(asm volatile("s_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2\n\ts_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2\n\ts_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2\n\ts_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2\n\ts_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2\n\ts_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2\n\ts_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2\n\ts_mov_b32 s20, 0\n\tv_fmac_f64 %0, %1, %2"
+        : "+v"(a0) : "v"(x), "v"(y) : "s20");)
+    T(10);
     p[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
-    if (threadIdx.x == 0) for (int i = 0; i < 8; i++) out[i] = t[i];
+    if (threadIdx.x == 0) for (int i = 0; i < 11; i++) out[i] = t[i];
 }
 int main()
 {
-    double *p; unsigned long long *o, h[8];
-    hipMalloc(&p, 64 * 8); hipMalloc(&o, 64); hipMemset(p, 0, 64 * 8);
+    double *p; unsigned long long *o, h[11];
+    hipMalloc(&p, 64 * 8); hipMalloc(&o, 88); hipMemset(p, 0, 64 * 8);
     for (int rep = 0; rep < 2; rep++) {
         hipLaunchKernelGGL(bench, dim3(1), dim3(64), 0, 0, p, o);
-        hipMemcpy(h, o, 64, hipMemcpyDeviceToHost);
+        hipMemcpy(h, o, 88, hipMemcpyDeviceToHost);
     }
-    const char *nm[7] = {"128 independent v_fmac_f64", "128 dependent v_fmac_f64", "128 independent v_fmac_f64_dpp", "128 independent s_nop 1 + v_fmac_f64_dpp",
-                         "128 x (2 v_readlane + v_fma_f64 sgpr)", "128 dependent s_nop 1 + v_fmac_f64_dpp", "128 independent v_mul_f64"};
-    for (int i = 0; i < 7; i++) printf("%-45s %6llu ticks  = %.1f per group\n", nm[i], h[i + 1] - h[i], (h[i + 1] - h[i]) / 128.0);
+    const char *nm[10] = {"128 independent v_fmac_f64", "128 dependent v_fmac_f64", "128 independent v_fmac_f64_dpp", "128 independent s_nop 1 + v_fmac_f64_dpp",
+                         "128 x (2 v_readlane + v_fma_f64 sgpr)", "128 dependent s_nop 1 + v_fmac_f64_dpp", "128 independent v_mul_f64",
+                          "128 x (s_nop 0 + dependent v_fmac_f64)", "128 x (s_setprio 0 + dependent v_fmac_f64)", "128 x (s_mov_b32 + dependent v_fmac_f64)"};
+    for (int i = 0; i < 10; i++) printf("%-45s %6llu ticks  = %.1f per group\n", nm[i], h[i + 1] - h[i], (h[i + 1] - h[i]) / 128.0);
     return 0;
 }
