@@ -1091,7 +1091,8 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
             // the state of this candidate array is kept on the handle; if the model has only grown by a few rows
             // (ibo_gp_extend) since it was formed, those rows are folded in -- O(N) per candidate, not O(N^2)
             const bool usable = g->st_cand == cand_dev && g->st_M == M && g->st_epoch == g->fit_epoch && g->st_sf2 == g->kp.sf2 &&
-                                g->st_N >= 1 && g->st_N <= g->N && g->N - g->st_N <= 8 && g->state.cap >= 3 * (size_t)M;
+                                g->st_N >= 1 && g->st_N <= g->N && g->N - g->st_N <= 8 && g->state.cap >= 3 * (size_t)M &&
+                                sweep2_rank1_fits(a.Npad);
             IBO_TRY(g->state.ensure(3 * (size_t)M));
             a.qpart = g->state.p;
             if (usable) {

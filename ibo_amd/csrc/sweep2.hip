@@ -32,11 +32,12 @@
 #define S2_NW 16
 #define S2_KCH 128                     // k* rows per LDS stage
 #define S2_PANEL 1024                  // rows of W per pass: 16 waves x 4 row-blocks x 16
+#define S2_AWIN 4096                   // rows of the alpha vectors held in LDS at a time
 
 #include "sweep2_dev.h"
 
 // KA4 = ceil((D + 2) / 4): k4-steps of the exponent GEMM
-template <int FAM, int KA4>
+template <int FAM, int KA4, bool BIGN>          // BIGN: more than S2_AWIN rows -- the alpha vectors' window moves
 __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 {
     constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4;
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     __shared__ double lds_q[S2_NW][TCAND];
     __shared__ double lds_m[2][S2_NW][16];
     __shared__ double lds_tab[2048];                // 2^(j/2048)
-    extern __shared__ __attribute__((aligned(16))) double lds_alpha[];   // alphaY[NA128], alpha1[NA128] (NA128 = rows padded to 128)
+    // alphaY[AW], alpha1[AW]: a window of AW = min(rows padded to 128, S2_AWIN) rows of both vectors -- all of them up to
+    // 4096 observations; beyond, the last panel (the one that forms the mean) moves the window as its stages advance
+    extern __shared__ __attribute__((aligned(16))) double lds_alpha[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,9 +60,10 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     const int NA128 = (a.Npad + 127) & ~127;
     lds_tab[tid] = a.exp_tab[tid];
     lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
-    for (int e = tid; e < NA128; e += S2_NW * 64) {                 // both vectors are zero beyond N (abi.hip pads them)
+    const int AW = BIGN ? S2_AWIN : NA128;
+    for (int e = tid; e < AW; e += S2_NW * 64) {                    // both vectors are zero beyond N (abi.hip pads them)
         lds_alpha[e] = a.alphaY[e];
-        lds_alpha[NA128 + e] = a.alpha1[e];
+        lds_alpha[AW + e] = a.alpha1[e];
     }
     for (int e = tid; e < TCAND * KA; e += S2_NW * 64) {
         const int c = e / KA, col = e - c * KA;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     const unsigned lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t rXA = s2_rsrc(a.XA, (size_t)(NA128 / 16) * KA4 * 64 * sizeof(double));
     const unsigned lane8 = lane * 8;
-    const double *aY_quad = lds_alpha + (lane >> 4), *a1_quad = lds_alpha + NA128 + (lane >> 4);
+    const double *aY_quad = lds_alpha + (lane >> 4), *a1_quad = lds_alpha + AW + (lane >> 4);
     // SIMD balance: a stage's eight partly active row-blocks (2, 4, .., 16 active steps) belong to eight
     // consecutive waves; waves w and w+4 share a SIMD, so blocks k and 7-k of each group of eight go to waves
     // that do -- every SIMD then carries the same MFMA count in every stage
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             double ay = 0.0, a1v = 0.0;
-            if (LAST) { ay = aY_quad[tile * 16 + 4 * r]; a1v = a1_quad[tile * 16 + 4 * r]; }
+            if (LAST) { const int kw = tile * 16 + 4 * r - (BIGN ? (k0 / S2_AWIN) * S2_AWIN : 0); ay = aY_quad[kw]; a1v = a1_quad[kw]; }
             double kv;
             if (FAM == FAM_SE) kv = s2_exp(y[r], lds_tab);
             else {                                                  // z = |x~ - c~|^2 = -2y
@@ -234,6 +238,16 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
             };
             range(0, n[0], std::integral_constant<int, 4>{});
             if (!XA_EARLY && more) load_xa((t + 1) * S2_KCH, xa);
+            if (BIGN && LAST && more && ((t + 1) * S2_KCH) % S2_AWIN == 0) {
+                // the next stage's rows start a new window of the alpha vectors (nobody reads the old one any more: the
+                // stage that used it was generated before the last barrier)
+                const int wb = (t + 1) * S2_KCH;
+                for (int e = tid; e < S2_AWIN; e += S2_NW * 64) {
+                    lds_alpha[e] = wb + e < NA128 ? a.alphaY[wb + e] : 0.0;
+                    lds_alpha[AW + e] = wb + e < NA128 ? a.alpha1[wb + e] : 0.0;
+                }
+                __syncthreads();
+            }
             if (more) gen((t + 1) * S2_KCH, (t + 1) & 1, xa, muY, mu1, last_tag);
             range(n[0], n[1], std::integral_constant<int, 3>{});
             range(n[1], n[2], std::integral_constant<int, 2>{});
@@ -425,26 +439,30 @@ int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, 
     return (int)hipGetLastError();
 }
 
-// dynamic LDS: the two alpha vectors (rows padded to 128); static: 64 KiB of k* stages, 16 KiB exp table, candidates
-// (32 x 21), q and mean partials (4 + 4 KiB): 95.5 KiB
-#define S2_STATIC_LDS (96 * 1024)
-bool sweep2_fits(int Npad)
-{
-    return (size_t)((Npad + 127) & ~127) * 16 + S2_STATIC_LDS <= 160 * 1024;      // (the refresh kernel's 24 B/row + 27 KiB fit whenever this does)
-}
+// dynamic LDS: a window of the two alpha vectors, at most S2_AWIN rows (64 KiB); static: 64 KiB of k* stages, 16 KiB exp
+// table, candidates (32 x 37), q and mean partials (4 + 4 KiB): 95.5 KiB.  Any N whose packed W the 2 GiB buffer
+// descriptor covers (16384 rows) fits; the refresh kernel keeps three whole vectors (24 B/row + 27 KiB).
+bool sweep2_fits(int Npad) { return Npad <= 16384; }
+bool sweep2_rank1_fits(int Npad) { return (size_t)((Npad + 127) & ~127) * 24 + 27 * 1024 <= 160 * 1024; }
 
-template <int FAM, int KA4>
-static int launch_s2_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+template <int FAM, int KA4, bool BIGN>
+static int launch_s2_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
-    const int dyn = ((a.Npad + 127) & ~127) * 16;
+    const int na128 = (a.Npad + 127) & ~127;
+    const int dyn = (BIGN ? S2_AWIN : na128) * 16;
     static int granted = 0;                          // per instantiation: largest dynamic size already allowed
     if (dyn > granted) {
-        hipError_t e = hipFuncSetAttribute((const void *)sweep2_kernel<FAM, KA4>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        hipError_t e = hipFuncSetAttribute((const void *)sweep2_kernel<FAM, KA4, BIGN>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
         if (e != hipSuccess) return (int)e;
         granted = dyn;
     }
-    hipLaunchKernelGGL((sweep2_kernel<FAM, KA4>), dim3((unsigned)ntiles), dim3(S2_NW * 64), dyn, s, a);
+    hipLaunchKernelGGL((sweep2_kernel<FAM, KA4, BIGN>), dim3((unsigned)ntiles), dim3(S2_NW * 64), dyn, s, a);
     return (int)hipGetLastError();
+}
+template <int FAM, int KA4>
+static int launch_s2_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    return ((a.Npad + 127) & ~127) > S2_AWIN ? launch_s2_var<FAM, KA4, true>(a, ntiles, s) : launch_s2_var<FAM, KA4, false>(a, ntiles, s);
 }
 
 template <int FAM, int KA4>

@@ -400,7 +400,9 @@ def test_sweep2_kernel_against_oracle_and_the_other_kernels(ibo, oracle):
              (64, 1, K.GaussianKernel_iso([.4]), ("iso", [.4]), 8300), (1000, 6, K.MaternKernel3([.6, 1.0]), ("m3", [.6, 1.0]), 8300),
              (2048, 8, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0]), 8300), (1500, 5, K.GaussianKernel_ard([.3] * 5), ("ard", [.3] * 5), 8300),
              (700, 10, K.GaussianKernel_ard([.5] * 10), ("ard", [.5] * 10), 8300), (600, 13, K.MaternKernel5([1.0, 1.0]), ("m5", [1.0, 1.0]), 8300),
-             (1100, 16, K.GaussianKernel_ard([.9] * 16), ("ard", [.9] * 16), 8300)]
+             (1100, 16, K.GaussianKernel_ard([.9] * 16), ("ard", [.9] * 16), 8300),
+             # more than 4096 observations: the alpha vectors' LDS window moves in the last panel (two panels short of a third)
+             (4500, 6, K.MaternKernel5([.8, 1.0]), ("m5", [.8, 1.0]), 8200)]
     try:
         for N, D, kern, (okind, ohyp), M in cases:
             X, Y = synth(N + D, N, D)
