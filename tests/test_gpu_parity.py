@@ -447,7 +447,8 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
                                              (1500, 5, K.GaussianKernel_ard([.3] * 5), ("ard", [.3] * 5), 4096), (1100, 16, K.GaussianKernel_ard([.9] * 16), ("ard", [.9] * 16), 333),
                                              # down to a single candidate (posterior(x), DIRECT's first rectangles): also small2.hip since round 2
                                              (1024, 4, K.GaussianKernel_ard([.3] * 4), ("ard", [.3] * 4), 1), (2048, 8, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0]), 3),
-                                             (200, 3, K.GaussianKernel_iso([.4]), ("iso", [.4]), 16), (64, 1, K.GaussianKernel_iso([.4]), ("iso", [.4]), 2)):
+                                             (200, 3, K.GaussianKernel_iso([.4]), ("iso", [.4]), 16), (64, 1, K.GaussianKernel_iso([.4]), ("iso", [.4]), 2),
+                                             (4400, 5, K.GaussianKernel_ard([.6] * 5), ("ard", [.6] * 5), 21)):        # beyond 4096 observations
             X, Y = synth(N + D, N, D)
             GP = GaussianProcess(kern, X, Y, noise=.1)
             cand = np.random.RandomState(N).rand(M, D); cand[min(M - 1, 7)] = X[5]
