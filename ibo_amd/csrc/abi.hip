@@ -288,6 +288,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "small2")) { g_small2 = value; return IBO_OK; }
     if (key && !strcmp(key, "gemv_max")) { g_gemv_max = value; return IBO_OK; }
     if (key && !strcmp(key, "flag_poll")) { g_flag_poll = value; return IBO_OK; }
+    if (key && !strcmp(key, "small_inline")) { set_small_inline(value); return IBO_OK; }
     if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
@@ -1016,7 +1017,8 @@ static int exp_table(int device, const double **out)
 static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, double parm, int erf_mode,
                      double clamp_lo, double ymax, int n_excl, const double *excl_host, double excl_radius,
                      int64_t index_base, double *mu_dev, double *s2_dev, double *acq_dev,
-                     double *best_val, int64_t *best_idx, bool incremental = false, bool timed = true, bool signal = false)
+                     double *best_val, int64_t *best_idx, bool incremental = false, bool timed = true, bool signal = false,
+                     const double *cand_host = nullptr)
 {
     if (!g->fitted) return fail(IBO_ERR_STATE, "sweep before a successful fit");
     if (M < 1 || !cand_dev) return fail(IBO_ERR_ARG, "empty candidate set");
@@ -1027,7 +1029,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     a.kp = g->kp; a.N = g->N; a.Npad = g->Npad; a.DP = g->DP; a.M = M;
     a.Xs = g->Xs.p; a.ak = g->ak.p; a.XA = g->XA.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = g_dot_override >= 0 ? g_dot_override : g->dot_form;
     a.Xp = g->Xp.p; a.W = g->W.p; a.Wp = g->Wp.p; a.alphaY = g->alphaY.p; a.alpha1 = g->alpha1.p;
-    a.cand = cand_dev;
+    a.cand = cand_dev; a.cand_host = cand_host;
     a.prior.nb = g->nb; a.prior.theta = g->ptheta; a.prior.means = g->pmeans.p; a.prior.beta = g->pbeta.p;
     a.prior.lowerb = g->plowerb.p; a.prior.width = g->pwidth.p;
     a.noise = g->noise; a.clamp_lo = clamp_lo; a.ymax = (ymax == ymax) ? ymax : g->maxY; a.parm = parm;
@@ -1268,7 +1270,7 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     if (acq_host) dacq = obase + (size_t)M * nout++;
     g->signal_pending = false;
     IBO_TRY(run_sweep(g, M, zero_copy ? pin_in : g->cand.p, acq, parm, erf_mode, clamp_lo, ymax, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
-                      nullptr, nullptr, false, !zero_copy, zero_copy && g_flag_poll));    // small batches: no kernel-time events either
+                      nullptr, nullptr, false, !zero_copy, zero_copy && g_flag_poll, zero_copy ? pin_in : nullptr));    // small batches: no kernel-time events either
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
     if (zero_copy) {
         // a batch of this size is back in tens of microseconds: spin for a moment before handing the thread to the runtime's

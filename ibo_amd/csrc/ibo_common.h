@@ -193,6 +193,7 @@ struct SweepArgs {
     // small2.hip: when set, the last workgroup of the last kernel stores done_seq there (host-visible memory) after all
     // results are out -- the host spins on that word instead of going through an event
     unsigned long long *done_flag; unsigned long long done_seq; unsigned *done_count;
+    const double *cand_host;                   // the same candidates where the HOST can read them (pinned staging), or NULL
 };
 
 int launch_sweep_mfma(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
@@ -201,7 +202,8 @@ int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
 int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int launch_sweep2_refresh(const SweepArgs &a, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool sweep2_fits(int Npad);
-bool sweep2_rank1_fits(int Npad);        // the gallery's refresh kernel keeps whole vectors in LDS (N <= ~5500)
+bool sweep2_rank1_fits(int Npad);
+void set_small_inline(int v);        // the gallery's refresh kernel keeps whole vectors in LDS (N <= ~5500)
 // small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
 int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 size_t small_sweep_workspace(int Npad, int64_t M);      // its LDS budget holds both alpha vectors (N <= ~5000)

@@ -16,13 +16,24 @@
 // and results written to, wherever the caller's pointers lead -- abi.hip passes pinned host memory, so a batch costs
 // no copy launches.
 #include "sweep2_dev.h"
+#include <cstring>
+
+static int g_small_inline = 1;                       // ibo_set_option("small_inline", 0/1)
+void set_small_inline(int v) { g_small_inline = v; }
 
 #define SM_TC 32                 // candidates per tile
 #define SM_NW 16
 
 // grid (ctiles, NA128 / 128); Kf[((ctile nk4 + s) 2 + cb) 64 + lane], nk4 = NA128 / 4; mupart[(stage 2 + which) Mp + c]
+// A batch of at most SM_INLINE coordinates (DIRECT's: a few dozen points) travels in the kernel arguments: the candidates
+// the caller hands over sit in pinned HOST memory, and reading them from there is a PCIe round trip at the head of the
+// chain.  `ic` is the FIRST parameter and is never named in the body (indexing a by-value aggregate makes hipcc copy all
+// of it to scratch in every thread): the kernel reads it through the kernarg segment pointer.
+#define SM_INLINE 320
+struct InlineCand { double v[SM_INLINE]; };
 template <int FAM, int KA4>
-__global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(SweepArgs a, double *__restrict__ Kf, double *__restrict__ mupart, int Mp)
+__global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, SweepArgs a, double *__restrict__ Kf, double *__restrict__ mupart, int Mp,
+                                                                 int inlined)
 {
     constexpr int KA = 4 * KA4;
     __shared__ double lds_c[SM_TC * (KA + 1)];
@@ -36,7 +47,8 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(SweepArgs a, do
     lds_tab[tid] = a.exp_tab[tid];
     lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
     if (tid < 128) { lds_al[0][tid] = a.alphaY[t * 128 + tid]; lds_al[1][tid] = a.alpha1[t * 128 + tid]; }
-    s2_stage_candidates<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)ctile * SM_TC, lds_c);
+    s2_stage_candidates<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)ctile * SM_TC, lds_c,
+                                                    inlined ? (const double *)__builtin_amdgcn_kernarg_segment_ptr() : nullptr);
     const int rt = wave >> 1, gcb = wave & 1;
     const int tile = t * 8 + rt;
     const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * (KA + 1) + (lane >> 4)];
@@ -179,12 +191,18 @@ __global__ __launch_bounds__(64) void small_finish_kernel(SweepArgs a, const dou
 template <int FAM>
 static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, int Mp, dim3 grid, hipStream_t s)
 {
+    InlineCand ic;
+    int inl = 0;
+    if (a.cand_host && a.M * a.kp.D <= SM_INLINE && g_small_inline) {
+        memcpy(ic.v, a.cand_host, sizeof(double) * (size_t)(a.M * a.kp.D));
+        inl = 1;
+    }
     switch ((a.kp.D + 2 + 3) / 4) {
-    case 1: hipLaunchKernelGGL((kstar_small_kernel<FAM, 1>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
-    case 2: hipLaunchKernelGGL((kstar_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
-    case 3: hipLaunchKernelGGL((kstar_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
-    case 4: hipLaunchKernelGGL((kstar_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
-    default: hipLaunchKernelGGL((kstar_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, a, Kf, mupart, Mp); break;
+    case 1: hipLaunchKernelGGL((kstar_small_kernel<FAM, 1>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    case 2: hipLaunchKernelGGL((kstar_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    case 3: hipLaunchKernelGGL((kstar_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    case 4: hipLaunchKernelGGL((kstar_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    default: hipLaunchKernelGGL((kstar_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
     }
     return (int)hipGetLastError();
 }

@@ -96,14 +96,15 @@ __device__ __forceinline__ double s2_kstar(double y, double sf2, const double *t
 // exactly; it is pulled in to that radius, where k* is still 0, so that the exponent stays within what s2_exp's integer
 // arithmetic covers (|y| < 7e5).  Called by the whole workgroup; ends with a barrier.
 template <int FAM, int TCAND, int KA, int NT>
-__device__ __forceinline__ void s2_stage_candidates(const SweepArgs &a, int64_t tile0, double *lds_c)
+__device__ __forceinline__ void s2_stage_candidates(const SweepArgs &a, int64_t tile0, double *lds_c, const double *cand = nullptr)
 {
     const int tid = threadIdx.x, D = a.kp.D;
+    if (!cand) cand = a.cand;
     for (int e = tid; e < TCAND * KA; e += NT) {
         const int c = e / KA, col = e - c * KA;
         int64_t gi = tile0 + c;
         if (gi > a.M - 1) gi = a.M - 1;
-        lds_c[c * (KA + 1) + col] = (col < D) ? a.cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
+        lds_c[c * (KA + 1) + col] = (col < D) ? cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
     }
     __syncthreads();
     if (tid < TCAND) {
