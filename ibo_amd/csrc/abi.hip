@@ -1116,6 +1116,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         IBO_TRY(g->mupart.ensure((size_t)ntiles * 16 + 16));
         a.mupart = g->mupart.p;
 #endif
+        a.dot_form = 0;                              // the first-generation tile kernel is kept in its difference form only
         KERNEL_TRY(launch_sweep_mfma(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_mfma_kernel";
 #ifdef IBO_STAMPS

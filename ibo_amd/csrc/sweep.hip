@@ -535,7 +535,8 @@ static int launch_mfma_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
         if (a.dot_form) return launch_mfma_split<FAM, true>(a, ntiles, s);
         return launch_mfma_split<FAM, false>(a, ntiles, s);
     }
-    if (a.dot_form) return launch_mfma_var<FAM, true>(a, ntiles, s);
+    // large batches reach this kernel only in the difference form: data that admit the dot form go to sweep2.hip
+    // (abi.hip: run_sweep clears dot_form on this route, also when a test forces it)
     return launch_mfma_var<FAM, false>(a, ntiles, s);
 }
 
