@@ -450,7 +450,7 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
 {
     if (N < 1) return fail(IBO_ERR_ARG, "N=%d", N);
     if (!X || !Y) return fail(IBO_ERR_ARG, "X/Y is NULL");
-    g->N = N; g->D = D; g->Npad = round_up(N + (reverse ? 0 : g->reserve), 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
+    g->N = N; g->D = D; g->Npad = round_up(N + (reverse ? 0 : g->reserve), 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
     g->reversed = reverse;
     const int Np = g->Npad, DP = g->DP;
     size_t nn = (size_t)Np * Np;
@@ -1094,7 +1094,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
             // (ibo_gp_extend) since it was formed, those rows are folded in -- O(N) per candidate, not O(N^2)
             const bool usable = g->st_cand == cand_dev && g->st_M == M && g->st_epoch == g->fit_epoch && g->st_sf2 == g->kp.sf2 &&
                                 g->st_N >= 1 && g->st_N <= g->N && g->N - g->st_N <= 8 && g->state.cap >= 3 * (size_t)M &&
-                                sweep2_rank1_fits(a.Npad);
+                                sweep2_rank1_fits(a.Npad, a.kp.D);
             IBO_TRY(g->state.ensure(3 * (size_t)M));
             a.qpart = g->state.p;
             if (usable) {

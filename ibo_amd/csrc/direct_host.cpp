@@ -145,14 +145,23 @@ struct Search {
             double f1 = dv.probe_vals[2 * q], f2 = dv.probe_vals[2 * q + 1];
             best[q] = (f1 < f2) ? f1 : f2;
         }
-        // ascending, stable (libstdc++ sorts <= 16 elements by insertion; cpp/direct.cpp:194)
+        // ascending by value as cpp/direct.cpp:194 orders them: std::sort with a value-only comparison.  libstdc++ sorts
+        // <= 16 elements by (stable) insertion; beyond that -- more than 16 longest sides, i.e. 17..32 dimensions -- the
+        // order among EQUAL values is whatever its introsort leaves, so the library routine itself is called
         std::vector<int> &order = sc_order;
         order.assign(dv.dims.begin(), dv.dims.end());
-        for (size_t a = 1; a < m; a++) {
-            int da = order[a]; double va = best[a];
-            size_t b = a;
-            while (b > 0 && va < best[b - 1]) { order[b] = order[b - 1]; best[b] = best[b - 1]; b--; }
-            order[b] = da; best[b] = va;
+        if (m > 16) {
+            std::vector<std::pair<unsigned, double>> iv(m);
+            for (size_t a = 0; a < m; a++) iv[a] = std::make_pair((unsigned)order[a], best[a]);
+            std::sort(iv.begin(), iv.end(), [](const std::pair<unsigned, double> &a, const std::pair<unsigned, double> &b) { return a.second < b.second; });
+            for (size_t a = 0; a < m; a++) { order[a] = (int)iv[a].first; best[a] = iv[a].second; }
+        } else {
+            for (size_t a = 1; a < m; a++) {
+                int da = order[a]; double va = best[a];
+                size_t b = a;
+                while (b > 0 && va < best[b - 1]) { order[b] = order[b - 1]; best[b] = best[b - 1]; b--; }
+                order[b] = da; best[b] = va;
+            }
         }
         std::vector<double> &l = sc_l, &u = sc_u, &cl = sc_cl, &cu = sc_cu, &cc = sc_cc;
         l.assign(dv.lb.begin(), dv.lb.end()); u.assign(dv.ub.begin(), dv.ub.end()); cl.resize(D); cu.resize(D); cc.resize(D);

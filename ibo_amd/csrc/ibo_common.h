@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include <math.h>
 
-#define IBO_DMAX 16            // largest input dimensionality handled on device
+#define IBO_DMAX 32            // largest input dimensionality handled on device (rows of X are padded to DP = 4, 8, 16 or 32)
 
 // covariance families after normalising the reference's four kernel types to
 // "weighted squared distance z = sum_d w_d (x_d - c_d)^2, then a scalar map":
@@ -96,7 +96,7 @@ __device__ __forceinline__ double cov_from_z_rt(int fam, double z, double sf2)
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // which derivative each hyper-parameter index asks for (nlml_grad_kernel)
-#define IBO_GRAD_MAX 17
+#define IBO_GRAD_MAX 33          // D length scales + the signal magnitude
 struct GradSpec {
     int nh;
     int mode[IBO_GRAD_MAX];     // 0 SE-ARD length scale of dimension dim[h]; 1 SE-iso length scale; 2 signal
@@ -202,7 +202,7 @@ int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
 int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int launch_sweep2_refresh(const SweepArgs &a, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 bool sweep2_fits(int Npad);
-bool sweep2_rank1_fits(int Npad);
+bool sweep2_rank1_fits(int Npad, int D);
 void set_small_inline(int v);        // the gallery's refresh kernel keeps whole vectors in LDS (N <= ~5500)
 // small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
 int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);

@@ -23,7 +23,7 @@
 // 4096 x 4096 matrix in 16 dimensions against 25 now).  A thread's columns are 16 apart: a row's store instruction
 // covers whole 128-byte segments.
 // (z is accumulated in the reference's order: sum_d w_d (a_d - b_d)^2.)
-#define COV_LD 17
+#define COV_LD 33          // row stride of the staged points: odd (conflict-free column reads), >= IBO_DMAX
 __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
                                                          const double *__restrict__ A2, int ldp, int square,
                                                          int diag_rule, double noise, double *__restrict__ K, int ldk,
@@ -1082,12 +1082,13 @@ int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, 
 // through LDS once per hyper-parameter -- 128 barriers for 256 pairs: 181 us at N = 2048, D = 8; now 25).
 // Per-workgroup partial sums, reduced in a fixed order by grad_reduce_kernel.
 // ------------------------------------------------------------------------
+template <int GM>          // GM >= gs.nh: accumulators held per thread (17 covers D <= 16 without the registers of 33)
 __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs, int N, const double *__restrict__ X,
                                                         int ldx, const double *__restrict__ Kinv, int ldk,
                                                         const double *__restrict__ alpha, double *__restrict__ partial)
 {
     __shared__ double As[64 * COV_LD], Bs[64 * COV_LD], ala[64], alb[64];
-    __shared__ double red[IBO_GRAD_MAX][4];
+    __shared__ double red[GM][4];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4, D = kp.D;
     const int b0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
     for (int e = t; e < 64 * D; e += 256) {
@@ -1098,9 +1099,9 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs,
     if (t < 64) ala[t] = (a0 + t < N) ? alpha[a0 + t] : 0.0;
     else if (t < 128) alb[t - 64] = (b0 + t - 64 < N) ? alpha[b0 + t - 64] : 0.0;
     __syncthreads();
-    double acc[IBO_GRAD_MAX];
+    double acc[GM];
 #pragma unroll
-    for (int h = 0; h < IBO_GRAD_MAX; h++) acc[h] = 0.0;
+    for (int h = 0; h < GM; h++) acc[h] = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int la = ty * 4 + r, a = a0 + la;
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs,
             const double kab = cov_from_z_rt(kp.family, z, kp.sf2);
             const double wm = Kinv[(size_t)(a > b ? a : b) * ldk + (a > b ? b : a)] - ala[la] * alb[lb];     // lower triangle only is formed
 #pragma unroll
-            for (int h = 0; h < IBO_GRAD_MAX; h++) {
+            for (int h = 0; h < GM; h++) {
                 if (h >= gs.nh) continue;                  // (no break: the unrolled copies keep acc[] in registers)
                 double dk;
                 switch (gs.mode[h]) {
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs,
     }
     const int lane = t & 63, wave = t >> 6;
 #pragma unroll
-    for (int h = 0; h < IBO_GRAD_MAX; h++) {
+    for (int h = 0; h < GM; h++) {
         if (h >= gs.nh) continue;
         double v = acc[h];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1157,7 +1158,8 @@ int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double 
                      const double *alpha, double *partial, double *out, hipStream_t s)
 {
     dim3 grid((N + 63) / 64, (N + 63) / 64);
-    hipLaunchKernelGGL(nlml_grad_kernel, grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
+    if (gs.nh <= 17) hipLaunchKernelGGL(nlml_grad_kernel<17>, grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
+    else hipLaunchKernelGGL(nlml_grad_kernel<IBO_GRAD_MAX>, grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(gs.nh), dim3(256), 0, s, partial, (int)(grid.x * grid.y), out);
     return (int)hipGetLastError();
 }

@@ -31,6 +31,7 @@ void set_small_inline(int v) { g_small_inline = v; }
 // of it to scratch in every thread): the kernel reads it through the kernarg segment pointer.
 #define SM_INLINE 320
 struct InlineCand { double v[SM_INLINE]; };
+static_assert(sizeof(InlineCand) + sizeof(SweepArgs) + 32 <= 4096, "kernel arguments of kstar_small_kernel: 4 KiB at most");
 template <int FAM, int KA4>
 __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, SweepArgs a, double *__restrict__ Kf, double *__restrict__ mupart, int Mp,
                                                                  int inlined)
@@ -202,7 +203,11 @@ static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, in
     case 2: hipLaunchKernelGGL((kstar_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
     case 3: hipLaunchKernelGGL((kstar_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
     case 4: hipLaunchKernelGGL((kstar_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
-    default: hipLaunchKernelGGL((kstar_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    case 5: hipLaunchKernelGGL((kstar_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    case 6: hipLaunchKernelGGL((kstar_small_kernel<FAM, 6>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    case 7: hipLaunchKernelGGL((kstar_small_kernel<FAM, 7>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    case 8: hipLaunchKernelGGL((kstar_small_kernel<FAM, 8>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
+    default: hipLaunchKernelGGL((kstar_small_kernel<FAM, 9>), grid, dim3(SM_NW * 64), 0, s, ic, a, Kf, mupart, Mp, inl); break;
     }
     return (int)hipGetLastError();
 }

@@ -159,29 +159,37 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
     // produce K* rows [k0, k0+KCH) into stage b (LAST: also accumulate the mean)
     auto gen = [&](int k0, int b, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        if constexpr (DP > 8 && FAM != FAM_SE) {
+        if constexpr ((DP > 8 && FAM != FAM_SE) || DP > 16) {
             // Matern kernels in 9..16 dimensions: the candidate's coordinates come from LDS and one row's 16
             // scaled observation coordinates fill 32 SGPRs; with the KPW rows unrolled side by side hipcc
             // spills ~470 registers (SGPRs into VGPR lanes, then VGPRs to scratch) and the kernel runs at 40 %
             // of the MFMA rate; taking the rows one at a time gives 53 %.  (For the squared exponential the
-            // unrolled form is the better one: 64 % against 55 %.)
+            // unrolled form is the better one: 64 % against 55 %.)  DP = 32 (17..32 dimensions) takes this form for
+            // every family: 64 SGPRs of coordinates per row.
 #pragma unroll 1
             for (int kk = 0; kk < KPW; kk++) {
                 const int k = k0 + kl0 + kk;
                 const double *xr = a.Xs + (size_t)k * DP;
                 double kv;
+                constexpr int DCH = 8;                     // coordinates in SGPRs at a time
                 if (DOT) {
                     double y = a.ak[k] + bc;
+#pragma unroll 1
+                    for (int d0 = 0; d0 < DP; d0 += DCH) {
 #pragma unroll
-                    for (int d = 0; d < DP; d++) y = fma(xr[d], lds_c[d * TC + lane], y);
+                        for (int d = d0; d < d0 + DCH; d++) y = fma(xr[d], lds_c[d * TC + lane], y);
+                    }
                     if (FAM == FAM_SE) kv = exp_fast(y);
                     else kv = cov_from_z_fast<FAM>(fmax(-2.0 * y, 0.0), a.log_sf2, a.kp.sf2);
                 } else {
                     double z = 0.0;
+#pragma unroll 1
+                    for (int d0 = 0; d0 < DP; d0 += DCH) {
 #pragma unroll
-                    for (int d = 0; d < DP; d++) {
-                        double t = xr[d] - lds_c[d * TC + lane];
-                        z = fma(t, t, z);
+                        for (int d = d0; d < d0 + DCH; d++) {
+                            double t = xr[d] - lds_c[d * TC + lane];
+                            z = fma(t, t, z);
+                        }
                     }
                     kv = cov_from_z_fast<FAM>(z, a.log_sf2, a.kp.sf2);
                 }
@@ -373,14 +381,8 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
             }
             return;
         }
-        double xq[DP];
-        {
-            int64_t gi = valid ? li : a.M - 1;
-#pragma unroll
-            for (int d = 0; d < DP; d++) xq[d] = (d < D) ? a.cand[gi * D + d] : 0.0;
-        }
         bool excl;
-        double val = finish_candidate(a, xq, q, my, m1, li, valid, excl);
+        double val = finish_candidate(a, a.cand + (valid ? li : a.M - 1) * D, q, my, m1, li, valid, excl);
         int64_t idx = a.index_base + li;
         if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
         wave_argmax(val, idx);
@@ -461,10 +463,8 @@ __global__ __launch_bounds__(64) void sweep_gemv_finish_kernel(SweepArgs a, int 
 #pragma unroll
         for (int u = 0; u < 8; u++) if (r0 + u < nrc) q += v[u];
     }
-    double xq[IBO_DMAX];
-    for (int d = 0; d < a.kp.D; d++) xq[d] = a.cand[ci * a.kp.D + d];
     bool excl;
-    double val = finish_candidate(a, xq, q, a.mupart[ci], a.mupart[a.M + ci], li, valid, excl);
+    double val = finish_candidate(a, a.cand + ci * a.kp.D, q, a.mupart[ci], a.mupart[a.M + ci], li, valid, excl);
     int64_t idx = a.index_base + li;
     if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
     wave_argmax(val, idx);
@@ -504,7 +504,8 @@ static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     dim3 grid((unsigned)ntiles), block(NW * 64);
     if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
     else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
+    else if (a.DP == 16) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 32, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -524,7 +525,8 @@ static int launch_mfma_split(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     dim3 grid((unsigned)ntiles, (a.Npad + IBO_SPLIT_PANEL - 1) / IBO_SPLIT_PANEL), block(1024);
     if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
     else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
+    else if (a.DP == 16) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 32, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
     return (int)hipGetLastError();
 }
 

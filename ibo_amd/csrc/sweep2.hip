@@ -32,22 +32,24 @@
 #define S2_NW 16
 #define S2_KCH 128                     // k* rows per LDS stage
 #define S2_PANEL 1024                  // rows of W per pass: 16 waves x 4 row-blocks x 16
-#define S2_AWIN 4096                   // rows of the alpha vectors held in LDS at a time
+// rows of the alpha vectors held in LDS at a time: 64 KiB of the 160, or 48 KiB where the candidate tile is wide
+// (17..32 dimensions: 32 x 37 doubles instead of 32 x 21)
+__host__ __device__ constexpr int s2_awin(int ka4) { return ka4 <= 5 ? 4096 : 3072; }
 
 #include "sweep2_dev.h"
 
 // KA4 = ceil((D + 2) / 4): k4-steps of the exponent GEMM
-template <int FAM, int KA4, bool BIGN>          // BIGN: more than S2_AWIN rows -- the alpha vectors' window moves
+template <int FAM, int KA4, bool BIGN>          // BIGN: more than s2_awin(KA4) rows -- the alpha vectors' window moves
 __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 {
-    constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4;
+    constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4, S2_AWIN = s2_awin(KA4);
     static_assert(CBW == 2 && S2_NW * RBW * 16 == S2_PANEL && (S2_KCH / 16) * CBW == S2_NW, "tile geometry");
     __shared__ double lds_k[2][S2_KCH * TCAND];    // K* stages in B-fragment order: [k4-step][cand-block][lane]
     __shared__ double lds_c[TCAND * (KA + 1)];            // augmented, scaled candidates [cand][KA]
     __shared__ double lds_q[S2_NW][TCAND];
     __shared__ double lds_m[2][S2_NW][16];
     __shared__ double lds_tab[2048];                // 2^(j/2048)
-    // alphaY[AW], alpha1[AW]: a window of AW = min(rows padded to 128, S2_AWIN) rows of both vectors -- all of them up to
+    // alphaY[AW], alpha1[AW]: a window of AW = min(rows padded to 128, s2_awin) rows of both vectors -- all of them up to
     // 4096 observations; beyond, the last panel (the one that forms the mean) moves the window as its stages advance
     extern __shared__ __attribute__((aligned(16))) double lds_alpha[];
 
@@ -439,17 +441,18 @@ int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, 
     return (int)hipGetLastError();
 }
 
-// dynamic LDS: a window of the two alpha vectors, at most S2_AWIN rows (64 KiB); static: 64 KiB of k* stages, 16 KiB exp
-// table, candidates (32 x 37), q and mean partials (4 + 4 KiB): 95.5 KiB.  Any N whose packed W the 2 GiB buffer
-// descriptor covers (16384 rows) fits; the refresh kernel keeps three whole vectors (24 B/row + 27 KiB).
+// dynamic LDS: a window of the two alpha vectors, at most s2_awin rows (64 or 48 KiB); static: 64 KiB of k* stages,
+// 16 KiB exp table, candidates (32 x 21 doubles up to 16 dimensions, 32 x 37 up to 32), q and mean partials (4 + 4 KiB):
+// 93.3 / 97.3 KiB.  Any N whose packed W the 2 GiB buffer descriptor covers (16384 rows) fits; the refresh kernel keeps
+// three whole vectors (24 B/row + 27.3 / 31.3 KiB).
 bool sweep2_fits(int Npad) { return Npad <= 16384; }
-bool sweep2_rank1_fits(int Npad) { return (size_t)((Npad + 127) & ~127) * 24 + 27 * 1024 <= 160 * 1024; }
+bool sweep2_rank1_fits(int Npad, int D) { return (size_t)((Npad + 127) & ~127) * 24 + (D <= 18 ? 28 : 32) * 1024 <= 160 * 1024; }
 
 template <int FAM, int KA4, bool BIGN>
 static int launch_s2_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     const int na128 = (a.Npad + 127) & ~127;
-    const int dyn = (BIGN ? S2_AWIN : na128) * 16;
+    const int dyn = (BIGN ? s2_awin(KA4) : na128) * 16;
     static int granted = 0;                          // per instantiation: largest dynamic size already allowed
     if (dyn > granted) {
         hipError_t e = hipFuncSetAttribute((const void *)sweep2_kernel<FAM, KA4, BIGN>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
@@ -462,7 +465,7 @@ static int launch_s2_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 template <int FAM, int KA4>
 static int launch_s2_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
-    return ((a.Npad + 127) & ~127) > S2_AWIN ? launch_s2_var<FAM, KA4, true>(a, ntiles, s) : launch_s2_var<FAM, KA4, false>(a, ntiles, s);
+    return ((a.Npad + 127) & ~127) > s2_awin(KA4) ? launch_s2_var<FAM, KA4, true>(a, ntiles, s) : launch_s2_var<FAM, KA4, false>(a, ntiles, s);
 }
 
 template <int FAM, int KA4>
@@ -487,7 +490,11 @@ static int launch_s2_rank1_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s
     case 2: return launch_s2_rank1_one<FAM, 2>(a, ntiles, s);
     case 3: return launch_s2_rank1_one<FAM, 3>(a, ntiles, s);
     case 4: return launch_s2_rank1_one<FAM, 4>(a, ntiles, s);
-    default: return launch_s2_rank1_one<FAM, 5>(a, ntiles, s);
+    case 5: return launch_s2_rank1_one<FAM, 5>(a, ntiles, s);
+    case 6: return launch_s2_rank1_one<FAM, 6>(a, ntiles, s);
+    case 7: return launch_s2_rank1_one<FAM, 7>(a, ntiles, s);
+    case 8: return launch_s2_rank1_one<FAM, 8>(a, ntiles, s);
+    default: return launch_s2_rank1_one<FAM, 9>(a, ntiles, s);
     }
 }
 
@@ -499,7 +506,11 @@ static int launch_s2_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     case 2: return launch_s2_one<FAM, 2>(a, ntiles, s);
     case 3: return launch_s2_one<FAM, 3>(a, ntiles, s);
     case 4: return launch_s2_one<FAM, 4>(a, ntiles, s);
-    default: return launch_s2_one<FAM, 5>(a, ntiles, s);
+    case 5: return launch_s2_one<FAM, 5>(a, ntiles, s);
+    case 6: return launch_s2_one<FAM, 6>(a, ntiles, s);
+    case 7: return launch_s2_one<FAM, 7>(a, ntiles, s);
+    case 8: return launch_s2_one<FAM, 8>(a, ntiles, s);
+    default: return launch_s2_one<FAM, 9>(a, ntiles, s);
     }
 }
 

@@ -508,6 +508,83 @@ static void rvec_push(rvec_t *a, rect_t r)
     a->v[a->len++] = r;
 }
 
+/* cpp/direct.cpp:194 sorts its (dimension, value) pairs with std::sort(.., sortByVal), and WHICH of several equal
+ * values comes first decides the order the rectangle is cut in, so the sort is restated as the reference's standard
+ * library performs it.  Dependency outside /root/reference: libstdc++ (GCC; bits/stl_algo.h, unchanged since 4.x):
+ *   std::sort = __introsort_loop(first, last, 2 floor(log2 n)) + __final_insertion_sort, threshold 16:
+ *   ranges longer than 16 are cut by __unguarded_partition_pivot (median of first+1 / middle / last-1 moved to the
+ *   front, then Hoare's unguarded partition around it), right part first by recursion, left part by iteration;
+ *   what is left (pieces of <= 16) is finished by one insertion sort over the first 16 elements and an unguarded
+ *   insertion sort over the rest.  Up to 16 elements this is a plain stable insertion sort.
+ * The depth-limit fallback (heap sort after 2 log2 n bad partitions) is not restated: it aborts loudly. */
+typedef struct { int d; double v; } iv_t;
+static void iv_swap(iv_t *a, iv_t *b) { iv_t t = *a; *a = *b; *b = t; }
+static void iv_linear_insert(iv_t *last)                      /* __unguarded_linear_insert */
+{
+    iv_t val = *last, *next = last - 1;
+    while (val.v < next->v) { *last = *next; last = next; next--; }
+    *last = val;
+}
+static void iv_insertion(iv_t *first, iv_t *last)             /* __insertion_sort */
+{
+    iv_t *i;
+    if (first == last) return;
+    for (i = first + 1; i != last; i++) {
+        if (i->v < first->v) {
+            iv_t val = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(iv_t));
+            *first = val;
+        } else iv_linear_insert(i);
+    }
+}
+static iv_t *iv_partition_pivot(iv_t *first, iv_t *last)      /* __unguarded_partition_pivot */
+{
+    iv_t *mid = first + (last - first) / 2, *a = first + 1, *b = mid, *c = last - 1, *lo, *hi;
+    if (a->v < b->v) {                                        /* __move_median_to_first(first, a, b, c) */
+        if (b->v < c->v) iv_swap(first, b);
+        else if (a->v < c->v) iv_swap(first, c);
+        else iv_swap(first, a);
+    } else if (a->v < c->v) iv_swap(first, a);
+    else if (b->v < c->v) iv_swap(first, c);
+    else iv_swap(first, b);
+    lo = first + 1; hi = last;                                /* __unguarded_partition(first + 1, last, first) */
+    for (;;) {
+        while (lo->v < first->v) lo++;
+        hi--;
+        while (first->v < hi->v) hi--;
+        if (!(lo < hi)) return lo;
+        iv_swap(lo, hi);
+        lo++;
+    }
+}
+static void iv_introsort_loop(iv_t *first, iv_t *last, int depth)
+{
+    while (last - first > 16) {
+        iv_t *cut;
+        if (depth == 0) { fprintf(stderr, "oracle: std::sort's heap-sort fallback is not restated\n"); abort(); }
+        depth--;
+        cut = iv_partition_pivot(first, last);
+        iv_introsort_loop(cut, last, depth);
+        last = cut;
+    }
+}
+static void iv_sort(int *dim, double *val, int m)
+{
+    iv_t *a;
+    int i, lg = 0;
+    if (m < 2) return;
+    a = (iv_t *)malloc(sizeof(iv_t) * (size_t)m);
+    for (i = 0; i < m; i++) { a[i].d = dim[i]; a[i].v = val[i]; }
+    while ((m >> (lg + 1)) > 0) lg++;
+    iv_introsort_loop(a, a + m, 2 * lg);
+    if (m > 16) {                                             /* __final_insertion_sort */
+        iv_insertion(a, a + 16);
+        for (i = 16; i < m; i++) iv_linear_insert(a + i);
+    } else iv_insertion(a, a + m);
+    for (i = 0; i < m; i++) { dim[i] = a[i].d; val[i] = a[i].v; }
+    free(a);
+}
+
 /* cpp/direct.cpp:146-235; appends the new rectangles to 'out' */
 static void d_divide(dstate_t *S, const rect_t *rec, rvec_t *out)
 {
@@ -531,14 +608,8 @@ static void d_divide(dstate_t *S, const rect_t *rec, rvec_t *out)
             dim[m] = i; val[m] = (f1 < f2) ? f1 : f2; m++;
         }
     }
-    /* ascending by value; libstdc++ std::sort on <=16 elements is a stable
-     * insertion sort, which is what this is (cpp/direct.cpp:194) */
-    for (i = 1; i < m; i++) {
-        int di = dim[i]; double vi = val[i];
-        k = i - 1;
-        while (k >= 0 && vi < val[k]) { dim[k + 1] = dim[k]; val[k + 1] = val[k]; k--; }
-        dim[k + 1] = di; val[k + 1] = vi;
-    }
+    /* ascending by value (cpp/direct.cpp:194, std::sort with sortByVal): see iv_sort */
+    iv_sort(dim, val, m);
     rect_copy(&old, rec, n);
     for (k = 0; k < m; k++) {
         int dd = dim[k];

@@ -131,6 +131,32 @@ def test_direct_grouped_selection_matches_the_all_pairs_reference(oracle):
         assert ns == ref[2] and fm == ref[0] and np.array_equal(xm, ref[1])
 
 
+def test_direct_beyond_sixteen_dimensions_orders_ties_as_the_reference_library(oracle):
+    """more than 16 longest sides: cpp/direct.cpp:194's std::sort is an introsort there, and with equal probe values the
+    cut order is whatever it leaves.  The host DIRECT calls std::sort, the oracle restates libstdc++'s algorithm; both
+    against the compiled reference on objectives made of ties (symmetric, plateaus, constants) in 17..32 dimensions"""
+    from ibo_amd.utils.optimize import cdirect
+    rs = np.random.RandomState(23)
+    cases = []
+    for D in (17, 20, 27, 32):
+        cases.append((lambda x: float(np.sum((x - .5) ** 2)), D))                       # every dimension ties
+        cases.append((lambda x: float(np.round(np.sum(np.abs(x - .3)), 0)), D))           # plateaus
+        lv = rs.randint(0, 3, D).astype(float)
+        cases.append((lambda x, lv=lv: float(np.sum(lv * np.round(3 * x))), D))           # a few distinct values, many repeats
+        c = rs.rand(D)
+        cases.append((lambda x, c=c: float(np.sum((x - c) ** 2)), D))                   # no ties
+    cases.append((lambda x: 0.0, 19))
+    have_ref = oracle.RefLib.available()
+    for f, D in cases:
+        b = [[0., 1.]] * D
+        fm, xm, ns = cdirect(f, b, maxiter=4, maxsample=4000, return_samples=True)
+        o = oracle.cdirect(f, b, maxiter=4, maxsample=4000)
+        assert ns == o[2] and fm == o[0] and np.array_equal(xm, o[1]), D
+        if have_ref:
+            ref = oracle.RefLib().direct(f, b, maxiter=4, maxsample=4000)
+            assert ns == ref[2] and fm == ref[0] and np.array_equal(xm, ref[1]), D
+
+
 def test_legacy_direct_symbol_against_compiled_reference(oracle):
     """`direct` with the reference's exact signature (cpp/direct.h:76), same answers as _ref/libego.so"""
     from ibo_amd import _lib

@@ -1206,3 +1206,97 @@ def test_sv_ard_kernel_and_ego_alias(ibo, oracle):
     close(opt, o, atol=ACQ_ATOL); close(optx, ox, rtol=1e-9, atol=1e-12)
     close(EI(GP).f(probe[0]), oracle.acq_value(oracle.ACQ_EI, oracle.ERF_NR, o_mu[0], np.sqrt(o_s2[0]), Y.max(), .01)[0],
           atol=ACQ_ATOL)
+
+
+def test_seventeen_to_thirty_two_dimensions(ibo, oracle):
+    """D = 17..32 (rows of X padded to 32 coordinates, six to nine k4-steps in the exponent GEMM, the 3072-row alpha window,
+    up to 33 gradient components): every sweep kernel, the fit, the block extension + refresh kernel, NLML with its
+    gradient and DIRECT against the CPU oracle; D = 33 is refused"""
+    import oracle.oracle as orc
+    from ibo_amd import _lib, DeviceArray
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+    from ibo_amd.acquisition import sweep, maximizeEI
+    opt = lambda k, v: _lib.check(_lib.lib.ibo_set_option(k, v))
+    cases = [(900, 17, K.GaussianKernel_ard([1.0 + .02 * d for d in range(17)]), ("ard", [1.0 + .02 * d for d in range(17)])),
+             (1100, 20, K.MaternKernel5([1.4, 1.0]), ("m5", [1.4, 1.0])),
+             (700, 23, K.GaussianKernel_iso([1.2]), ("iso", [1.2])),
+             (1300, 27, K.MaternKernel3([1.6, 1.0]), ("m3", [1.6, 1.0])),
+             (520, 32, K.GaussianKernel_ard([1.5] * 32), ("ard", [1.5] * 32)),
+             (3300, 19, K.GaussianKernel_ard([1.1] * 19), ("ard", [1.1] * 19))]       # more rows than the 3072-row alpha window
+    try:
+        for N, D, kern, (okind, ohyp) in cases:
+            X, Y = synth(N + D, N, D)
+            GP = GaussianProcess(kern, X, Y, noise=.1)
+            ogp = oracle.GP(oracle.Kern(okind, ohyp), X, Y, noise=.1)
+            if N <= 1300:
+                close(GP.R, ogp.R, rtol=1e-12); close(GP.L, ogp.L, rtol=1e-8, atol=1e-12)
+            M = 8300
+            cand = np.random.RandomState(N).rand(M, D); cand[77] = X[5]; cand[M - 1] = cand[0]
+            opt(b"sweep_variant", 4)
+            r = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            assert r["kernel"] == "sweep2_kernel"
+            idx = np.r_[np.arange(0, M, M // 40), 77, M - 1, r["best_idx"]]
+            o = oracle.sweep_native(ogp, cand[idx], oracle.ACQ_EI, .01)
+            close(r["mu"][idx], o["mu"], atol=1e-9); close(r["s2"][idx], o["s2"]); close(r["acq"][idx], o["acq"], atol=ACQ_ATOL)
+            assert r["best_idx"] == int(np.argmax(r["acq"]))
+            # the first-generation tile kernel (difference form), the GEMV kernel, the small-batch kernels and the split form
+            opt(b"sweep_variant", 2)
+            r1 = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            opt(b"sweep_variant", 4)
+            assert r1["kernel"] == "sweep_mfma_kernel" and r1["best_idx"] == r["best_idx"]
+            close(r1["mu"], r["mu"], rtol=1e-9, atol=1e-10); close(r1["s2"], r["s2"], rtol=1e-9)
+            opt(b"sweep_path", 1); rg = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
+            assert rg["kernel"] == "sweep_gemv_kernel"
+            rs = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            assert rs["kernel"] == "wk_small_kernel"
+            opt(b"small2", 0); rp = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq")); opt(b"small2", 1)
+            assert rp["kernel"] == "sweep_mfma_kernel<split>"
+            for k in ("mu", "s2", "acq"):
+                for other in (rg, rs, rp):
+                    close(other[k], r[k][:300], rtol=1e-9, atol=1e-11)
+            for form in (0, 1):                                   # the split kernel in both distance forms
+                opt(b"dot_form", form); opt(b"small2", 0)
+                rf = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2"))
+                opt(b"dot_form", -1); opt(b"small2", 1)
+                close(rf["mu"], r["mu"][:300], rtol=1e-9, atol=1e-10); close(rf["s2"], r["s2"][:300], rtol=1e-9)
+            # one point (posterior(x): inline candidates), Python-flavoured acquisition
+            mu1, s21 = GP.posterior(cand[3]); o1 = ogp.posteriors(cand[3:4])
+            close(mu1, o1[0][0], atol=1e-9); close(s21, o1[1][0])
+        # block extension + refresh kernel in 24 dimensions
+        N0, D = 600, 24
+        X, Y = synth(124, N0 + 4, D)
+        kern = K.GaussianKernel_ard([1.3] * D)
+        GP = GaussianProcess(kern, X[:N0], Y[:N0], noise=.1)
+        dc = DeviceArray.from_host(np.random.RandomState(125).rand(9001, D))
+        seen = []
+        for rnd in range(4):
+            r = sweep(GP, dc, acq='ei', xi=.4, native=False, incremental=True, outputs=("mu", "s2", "acq"))
+            seen.append(r["kernel"])
+            f = sweep(GaussianProcess(kern, GP.X, GP.Y, noise=.1), dc, acq='ei', xi=.4, native=False, outputs=("mu", "s2", "acq"))
+            close(r["mu"], f["mu"], rtol=1e-9, atol=1e-10); close(r["s2"], f["s2"], rtol=1e-9); assert r["best_idx"] == f["best_idx"]
+            GP.addData(X[len(GP.X)], Y[len(GP.X)])
+        assert seen == ["sweep2_kernel"] + ["sweep2_rank1_kernel"] * 3
+        ogp = oracle.GP(oracle.Kern("ard", [1.3] * D), np.asarray(GP.X), np.asarray(GP.Y), noise=.1)
+        probe = np.random.RandomState(126).rand(30, D)
+        close(GP.posteriors(probe), ogp.posteriors(probe), atol=1e-9)
+        # NLML and its 21 / 33 partial derivatives
+        for N, D, name, cls, hyp in ((300, 20, "svard", K.SVGaussianKernel_ard, [1.0 + .05 * d for d in range(20)] + [1.1]),
+                                     (200, 32, "svard", K.SVGaussianKernel_ard, [1.5] * 32 + [.9]),
+                                     (200, 32, "ard", K.GaussianKernel_ard, [1.2 + .01 * d for d in range(32)])):
+            X, Y = synth(N + D, N, D)
+            v, d = marginalLikelihood(cls(hyp), X, Y, len(hyp), True, noise=1e-3)
+            ov, od = orc.marginal_likelihood(orc.Kern(name, hyp), X, Y, len(hyp), True, 1e-3)
+            close(v, ov); close(d, od, atol=1e-9)
+        # DIRECT over a 20-dimensional box: same optimum as the oracle's search on its own objective
+        X, Y = synth(140, 150, 20)
+        GP = GaussianProcess(K.GaussianKernel_iso([1.5]), X, Y, noise=.1)
+        ogp = oracle.GP(oracle.Kern("iso", [1.5]), X, Y, noise=.1)
+        opt_v, opt_x = maximizeEI(GP, [[0., 1.]] * 20, maxiter=6)
+        o, ox, _ = oracle.acqmax_native(ogp, [[0., 1.]] * 20, oracle.ACQ_EI, .01, maxiter=6)
+        close(opt_v, o, atol=ACQ_ATOL); close(opt_x, ox, rtol=1e-9, atol=1e-12)
+        with pytest.raises(Exception):
+            GaussianProcess(K.GaussianKernel_iso([1.5]), np.random.rand(10, 33), np.random.rand(10), noise=.1).posterior(np.zeros(33))
+    finally:
+        opt(b"sweep_variant", 4); opt(b"sweep_path", 0); opt(b"small2", 1); opt(b"dot_form", -1)
