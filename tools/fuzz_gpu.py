@@ -17,12 +17,12 @@ worst = 0.0
 t0 = time.time()
 for case in range(ncases):
     N = int(special_N[case % len(special_N)] if case < 2 * len(special_N) else rs.randint(1, int(os.environ.get("FUZZ_NMAX", "1500"))))
-    D = int(rs.randint(1, 17))
+    D = int(rs.randint(1, int(os.environ.get("FUZZ_DMAX", "32")) + 1))
     kind = ["ard", "iso", "m3", "m5"][rs.randint(4)]
     M = int([1, 3, 16, 17, 64, 65, 1000, 8192, 8193, 20000][rs.randint(10)])
     noise = float([.1, .01, 1e-3][rs.randint(3)])
     X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
-    th = np.exp(rs.uniform(np.log(.2), np.log(1.5), size=D))
+    th = np.exp(rs.uniform(np.log(.2), np.log(1.5), size=D)) * max(1.0, np.sqrt(D / 8.))      # distances grow with sqrt(D)
     if kind == "ard": hyp = th; ours = K.GaussianKernel_ard(hyp)
     elif kind == "iso": hyp = th[:1]; ours = K.GaussianKernel_iso(hyp)
     elif kind == "m3": hyp = np.r_[th[0], 1.0]; ours = K.MaternKernel3(hyp)
