@@ -758,6 +758,8 @@ static int g_panel_rows = 1;                         // ibo_set_option("chol_pan
 void set_chol_panel_rows(int v) { g_panel_rows = v; }
 static int g_update2 = 1;                            // ibo_set_option("chol_update2", 0/1): packed-panel trailing update (update2.hip)
 void set_chol_update2(int v) { g_update2 = v; }
+static int g_update2_min_tiles = 1024;               // ibo_set_option("update2_min_tiles"): 128 x 128 tiles (over the batch) from which the packed-panel kernel takes the update
+void set_chol_update2_min_tiles(int v) { g_update2_min_tiles = v; }
 
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
                             int panel, hipStream_t s, double *ws, size_t wstride)
@@ -790,7 +792,7 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
         if (pend < nb) {
             // the big update (K = 64 P): packed-panel kernel when the caller lent a workspace, bit-identical to the other
             const int nI2 = (Npad - 64 * pend + 127) / 128;
-            if (ws && g_update2 && (size_t)nI2 * (nI2 + 1) / 2 * batch >= 1024) {      // enough 128 x 128 tiles to fill the chip twice
+            if (ws && g_update2 && (size_t)nI2 * (nI2 + 1) / 2 * batch >= (size_t)g_update2_min_tiles) {
                 int rc = launch_chol_update2(L, Npad, p0, pend, batch, lstride, ws, wstride, s);
                 if (rc) return rc;
             } else launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
@@ -969,7 +971,7 @@ void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W, 
     TILE_IDS;
     int o = blockIdx.y * 2 * s;
     int r = min(s, nb - o - s);
-    int ti = blockIdx.x / s, tj = blockIdx.x % s;
+    int tj = blockIdx.x / s, ti = blockIdx.x % s;       // longest K ranges (small tj) first: the short ones fill the tail
     if (ti >= r) return;
     const double *A = L + (size_t)(o + s + ti) * 64 * Npad + (size_t)o * 64;
     const double *B = W + (size_t)o * 64 * Npad + (size_t)(o + tj) * 64;
@@ -992,7 +994,7 @@ void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T, int Np
     TILE_IDS;
     int o = blockIdx.y * 2 * s;
     int r = min(s, nb - o - s);
-    int ti = blockIdx.x / s, tj = blockIdx.x % s;
+    int ti = s - 1 - blockIdx.x / s, tj = blockIdx.x % s;   // longest K ranges (large ti) first
     if (ti >= r) return;
     const double *A = W + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + s) * 64;
     const double *B = T + (size_t)(o + s) * 64 * Npad + (size_t)(o + tj) * 64;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
     __shared__ double lds_s[SM_TC][17];              // squared sums [cand][row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ctile = blockIdx.x, g = blockIdx.y;
+    const int ctile = blockIdx.x, g = gridDim.y - 1 - blockIdx.y;       // the longest rows of W first: the short ones fill the tail
     const int Npad = a.Npad, nk8 = Npad >> 3, NA128 = (Npad + 127) & ~127;
     const int nsteps = 2 * g + 2;                    // 8-column steps in which row-block g has non-zeros
     const double2 *Wp2 = (const double2 *)a.Wp + (size_t)g * nk8 * 64 + lane;

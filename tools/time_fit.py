@@ -7,7 +7,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from ibo_amd.gaussianprocess import GaussianProcess
 from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
 
-for N in [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 4096]:
+opts = [a for a in sys.argv[1:] if "=" in a]          # key=value: ibo_set_option before the runs
+if opts:
+    from ibo_amd import _lib
+    for o in opts:
+        k, v = o.split("="); _lib.check(_lib.lib.ibo_set_option(k.encode(), int(v)))
+for N in [int(a) for a in sys.argv[1:] if "=" not in a] or [256, 1024, 2048, 4096]:
     D = 4 if N <= 1024 else 8
     rs = np.random.RandomState(2)
     X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
