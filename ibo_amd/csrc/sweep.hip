@@ -159,13 +159,12 @@ __global__ __launch_bounds__(NW * 64) void sweep_mfma_kernel(SweepArgs a)
     // produce K* rows [k0, k0+KCH) into stage b (LAST: also accumulate the mean)
     auto gen = [&](int k0, int b, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        if constexpr ((DP > 8 && FAM != FAM_SE) || DP > 16) {
-            // Matern kernels in 9..16 dimensions: the candidate's coordinates come from LDS and one row's 16
-            // scaled observation coordinates fill 32 SGPRs; with the KPW rows unrolled side by side hipcc
-            // spills ~470 registers (SGPRs into VGPR lanes, then VGPRs to scratch) and the kernel runs at 40 %
-            // of the MFMA rate; taking the rows one at a time gives 53 %.  (For the squared exponential the
-            // unrolled form is the better one: 64 % against 55 %.)  DP = 32 (17..32 dimensions) takes this form for
-            // every family: 64 SGPRs of coordinates per row.
+        if constexpr (DP > 8) {
+            // 9..32 dimensions: the candidate's coordinates come from LDS and the row's scaled observation coordinates
+            // from SGPRs.  With the KPW rows unrolled side by side and all of a row's coordinates loaded at once (32 or
+            // 64 SGPRs) hipcc spilled up to ~470 registers (SGPRs into VGPR lanes, then VGPRs to scratch): 40 % of the
+            // MFMA rate for the Matern kernels at DP = 16.  Rows one at a time, coordinates eight at a time (16 SGPRs):
+            // 36 B of scratch per lane, 67-69 % for every family at DP = 16, 58-61 % at DP = 32.
 #pragma unroll 1
             for (int kk = 0; kk < KPW; kk++) {
                 const int k = k0 + kl0 + kk;
