@@ -929,40 +929,65 @@ __global__ __launch_bounds__(256) void trinv_place_diag_kernel(const double *__r
 // acc += sum over 64-blocks kb in [kb0, kb1) of A[:, kb] * B[kb, :]  (A, B row-major 64-row strips; the
 // 64x64 tiles of stage kb+1 are in flight while stage kb is on the MFMAs).  Bs is 64 x TNN_LD: with a row
 // stride of 80 doubles the four k-rows of a B fragment fall on disjoint bank halves.
+// NW = 4: 2 x 2 waves of 32 x 32 (acc[2][2]).  NW = 8: 4 x 2 waves of 16 x 32 (acc[1][2]) -- a wave issues an fp64 MFMA
+// every ~118 cycles at best, so a tile that has its CU to itself (the lower levels of the doubling: fewer tiles than
+// CUs, and the tile with the longest K range IS the launch) takes half the time per stage on eight waves.  Every output
+// element sees the same MFMAs in the same order either way: identical bits.
 #define TNN_LD 80
+template <int NW>
 __device__ __forceinline__ void tile64_gemm_nn(const double *__restrict__ A, int lda, const double *__restrict__ B,
-                                               int ldb, int kb0, int kb1, d4_t (&acc)[2][2], double *As, double *Bs)
+                                               int ldb, int kb0, int kb1, d4_t (&acc)[8 / NW][2], double *As, double *Bs)
 {
+    constexpr int MR = 8 / NW, NV = 32 / NW;            // row-blocks per wave; 16-byte loads per thread and tile
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr = wv >> 1, wc = wv & 1;
     if (kb0 >= kb1) return;
-    d2_t va[8], vb[8];
-    tile64_fetch(A + (size_t)kb0 * 64, lda, va);
-    tile64_fetch(B + (size_t)kb0 * 64 * ldb, ldb, vb);
+    d2_t va[NV], vb[NV];
+    auto fetch = [&](const double *P, int ld, d2_t (&v)[NV]) {
+#pragma unroll
+        for (int u = 0; u < NV; u++) v[u] = *(const d2_t *)(P + (size_t)(2 * NW * u + (t >> 5)) * ld + (t & 31) * 2);
+    };
+    auto stash_a = [&](const d2_t (&v)[NV]) {            // odd row stride: 8-byte stores
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            double *dst = As + (2 * NW * u + (t >> 5)) * T64_LD + (t & 31) * 2;
+            dst[0] = v[u].x; dst[1] = v[u].y;
+        }
+    };
+    auto stash_b = [&](const d2_t (&v)[NV]) {
+#pragma unroll
+        for (int u = 0; u < NV; u++) *(d2_t *)(Bs + (2 * NW * u + (t >> 5)) * TNN_LD + (t & 31) * 2) = v[u];
+    };
+    fetch(A + (size_t)kb0 * 64, lda, va);
+    fetch(B + (size_t)kb0 * 64 * ldb, ldb, vb);
     for (int kb = kb0; kb < kb1; kb++) {
-        tile64_stash(As, va);
-        tile64_stash<false, TNN_LD>(Bs, vb);
+        stash_a(va);
+        stash_b(vb);
         __syncthreads();
         if (kb + 1 < kb1) {
-            tile64_fetch(A + (size_t)(kb + 1) * 64, lda, va);
-            tile64_fetch(B + (size_t)(kb + 1) * 64 * ldb, ldb, vb);
+            fetch(A + (size_t)(kb + 1) * 64, lda, va);
+            fetch(B + (size_t)(kb + 1) * 64 * ldb, ldb, vb);
         }
 #pragma unroll
         for (int k4 = 0; k4 < 16; k4++) {
-            double a[2], b[2];
+            double a[MR], b[2];
 #pragma unroll
-            for (int m = 0; m < 2; m++) a[m] = As[(wr * 32 + m * 16 + (lane & 15)) * T64_LD + k4 * 4 + (lane >> 4)];
+            for (int m = 0; m < MR; m++) a[m] = As[(wr * 16 * MR + m * 16 + (lane & 15)) * T64_LD + k4 * 4 + (lane >> 4)];
 #pragma unroll
             for (int n = 0; n < 2; n++) b[n] = Bs[(k4 * 4 + (lane >> 4)) * TNN_LD + wc * 32 + n * 16 + (lane & 15)];
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int m = 0; m < MR; m++)
 #pragma unroll
                 for (int n = 0; n < 2; n++) acc[m][n] = mfma_f64(a[m], b[n], acc[m][n]);
         }
         if (kb + 1 < kb1) __syncthreads();
     }
 }
+// row of accumulator (m, q) / column of accumulator n in the 64 x 64 tile, NW-wave layout
+#define TNN_ROW(m, q) (wr * 16 * (8 / NW) + (m) * 16 + (lane >> 4) + 4 * (q))
+#define TNN_COL(n) (wc * 32 + (n) * 16 + (lane & 15))
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, NW == 4 ? 2 : 4)))
 void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W, double *__restrict__ T, int Npad,
                     int s, int nb)
 {
@@ -975,18 +1000,19 @@ void trinv_T_kernel(const double *__restrict__ L, const double *__restrict__ W, 
     if (ti >= r) return;
     const double *A = L + (size_t)(o + s + ti) * 64 * Npad + (size_t)o * 64;
     const double *B = W + (size_t)o * 64 * Npad + (size_t)(o + tj) * 64;
-    d4_t acc[2][2] = {};
-    tile64_gemm_nn(A, Npad, B, Npad, tj, s, acc, As, Bs);           // W11 is lower triangular: k-blocks >= tj
+    d4_t acc[8 / NW][2] = {};
+    tile64_gemm_nn<NW>(A, Npad, B, Npad, tj, s, acc, As, Bs);           // W11 is lower triangular: k-blocks >= tj
     double *C = T + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + tj) * 64;
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < 8 / NW; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
+            for (int q = 0; q < 4; q++) C[(size_t)TNN_ROW(m, q) * Npad + TNN_COL(n)] = acc[m][n][q];
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, NW == 4 ? 2 : 4)))
 void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T, int Npad, int s, int nb)
 {
     __shared__ double As[64 * T64_LD];
@@ -998,16 +1024,19 @@ void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T, int Np
     if (ti >= r) return;
     const double *A = W + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + s) * 64;
     const double *B = T + (size_t)(o + s) * 64 * Npad + (size_t)(o + tj) * 64;
-    d4_t acc[2][2] = {};
-    tile64_gemm_nn(A, Npad, B, Npad, 0, ti + 1, acc, As, Bs);       // W22 is lower triangular: k-blocks <= ti
+    d4_t acc[8 / NW][2] = {};
+    tile64_gemm_nn<NW>(A, Npad, B, Npad, 0, ti + 1, acc, As, Bs);       // W22 is lower triangular: k-blocks <= ti
     double *C = W + (size_t)(o + s + ti) * 64 * Npad + (size_t)(o + tj) * 64;
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < 8 / NW; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = -acc[m][n][q];
+            for (int q = 0; q < 4; q++) C[(size_t)TNN_ROW(m, q) * Npad + TNN_COL(n)] = -acc[m][n][q];
 }
+
+static int g_trinv_wide = 1;                          // ibo_set_option("trinv_wide", 0/1): eight-wave tiles where a level has at most 512 of them
+void set_trinv_wide(int v) { g_trinv_wide = v; }
 
 int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s, bool zero_fill)
 {
@@ -1019,8 +1048,13 @@ int launch_trinv(const double *L, int Npad, const double *diag64, double *W, dou
     for (int sz = 1; sz < nb; sz *= 2) {
         int nodes = (nb + 2 * sz - 1) / (2 * sz);
         dim3 grid(sz * sz, nodes);
-        hipLaunchKernelGGL(trinv_T_kernel, grid, dim3(256), 0, s, L, W, T, Npad, sz, nb);
-        hipLaunchKernelGGL(trinv_W_kernel, grid, dim3(256), 0, s, W, T, Npad, sz, nb);
+        if (g_trinv_wide && sz * sz * nodes <= 512) {
+            hipLaunchKernelGGL(trinv_T_kernel<8>, grid, dim3(512), 0, s, L, W, T, Npad, sz, nb);
+            hipLaunchKernelGGL(trinv_W_kernel<8>, grid, dim3(512), 0, s, W, T, Npad, sz, nb);
+        } else {
+            hipLaunchKernelGGL(trinv_T_kernel<4>, grid, dim3(256), 0, s, L, W, T, Npad, sz, nb);
+            hipLaunchKernelGGL(trinv_W_kernel<4>, grid, dim3(256), 0, s, W, T, Npad, sz, nb);
+        }
     }
     return (int)hipGetLastError();
 }
@@ -1055,7 +1089,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double *A = Wt + (size_t)ti * 64 * Npad;              // rows i of W^T, all k
     const double *B = W + (size_t)tj * 64;                      // columns j of W
     d4_t acc[2][2] = {};
-    tile64_gemm_nn(A, Npad, B, Npad, max(ti, tj), Npad / 64, acc, As, Bs);      // W is lower triangular: k >= max(i, j)
+    tile64_gemm_nn<4>(A, Npad, B, Npad, max(ti, tj), Npad / 64, acc, As, Bs);      // W is lower triangular: k >= max(i, j)
     double *Ct = C + (size_t)ti * 64 * Npad + (size_t)tj * 64;
 #pragma unroll
     for (int m = 0; m < 2; m++)

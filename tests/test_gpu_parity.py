@@ -976,6 +976,28 @@ def test_c5_nlml_full_size(ibo, oracle):
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[1:2], X, Y, noise=1e-3)[0], vals[1:2])   # deterministic
 
 
+def test_trinv_wave_layouts_agree(ibo):
+    """W = L^-1 by recursive doubling (fits beyond 2048 rows, the NLML gradient): levels with at most 512 tiles run
+    8-wave tiles, the others 4-wave tiles, tiles in longest-K-first order -- every element is the same chain of MFMAs, so
+    the two layouts give the same bits; and W L = I"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    for N in (2300, 3000):                                    # 36 / 47 blocks: ragged last nodes at every level
+        X, Y = synth(N, N, 6)
+        Ws = []
+        for wide in (1, 0):
+            _lib.check(_lib.lib.ibo_set_option(b"trinv_wide", wide))
+            try:
+                GP = GaussianProcess(GaussianKernel_ard([.5] * 6), X, Y, noise=.1)
+                W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+                Ws.append(W)
+            finally:
+                _lib.check(_lib.lib.ibo_set_option(b"trinv_wide", 1))
+        assert np.array_equal(Ws[0], Ws[1])
+        assert np.abs(Ws[0] @ GP.L - np.eye(N)).max() < 1e-10 and np.abs(np.triu(Ws[0], 1)).max() == 0.0
+
+
 def test_cholesky_panel_orders_agree(ibo):
     """the two-level (panel = 4 block columns, K = 256 updates) and the plain right-looking factorisation give
     the same factor to rounding; the batched NLML grid does not depend on what shares its launches"""
