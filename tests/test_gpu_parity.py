@@ -1318,6 +1318,18 @@ def test_seventeen_to_thirty_two_dimensions(ibo, oracle):
         opt_v, opt_x = maximizeEI(GP, [[0., 1.]] * 20, maxiter=6)
         o, ox, _ = oracle.acqmax_native(ogp, [[0., 1.]] * 20, oracle.ACQ_EI, .01, maxiter=6)
         close(opt_v, o, atol=ACQ_ATOL); close(opt_x, ox, rtol=1e-9, atol=1e-12)
+        # a preference GP in 20 dimensions: C, L = chol(R + C^-1) and the posterior against the oracle fed with the same MAP
+        from ibo_amd.gaussianprocess import PrefGaussianProcess
+        hyp = [1.2 + .03 * d for d in range(20)]
+        pts = np.random.RandomState(150).rand(48, 20)
+        score = lambda x: float(np.sum(np.sin(2 * x)))
+        prefs = [((a, b, 0) if score(a) > score(b) else (b, a, 0)) for a, b in zip(pts[0::2], pts[1::2])]
+        PG = PrefGaussianProcess(K.GaussianKernel_ard(hyp), prefs)
+        opg = oracle.pref_fit(oracle.Kern("ard", hyp), prefs, noise=.1, Y_map=PG.Y)
+        np.testing.assert_array_equal(PG.X, opg.X)
+        close(PG.R, opg.R, rtol=1e-12, atol=1e-14); close(PG.C, opg.C, atol=1e-9); close(PG.L, opg.L, atol=1e-9)
+        probe = np.random.RandomState(151).rand(40, 20)
+        close(PG.posteriors(probe), opg.posteriors(probe), atol=1e-9)
         with pytest.raises(Exception):
             GaussianProcess(K.GaussianKernel_iso([1.5]), np.random.rand(10, 33), np.random.rand(10), noise=.1).posterior(np.zeros(33))
     finally:
