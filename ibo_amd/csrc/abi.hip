@@ -51,6 +51,7 @@ void ibo_internal_set_error(const char *msg)
 extern int g_sweep_variant;     // sweep.hip
 static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
+static int g_chol_fused2 = 1;    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
 static int g_zero_copy = 1;      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
 static int g_flag_poll = 1;      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
 static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
@@ -282,6 +283,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
+    if (key && !strcmp(key, "chol_fused2")) { g_chol_fused2 = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_update2")) { set_chol_update2(value); return IBO_OK; }
     if (key && !strcmp(key, "update2_min_tiles")) { set_chol_update2_min_tiles(value); return IBO_OK; }
     if (key && !strcmp(key, "trinv_wide")) { set_trinv_wide(value); return IBO_OK; }
@@ -510,7 +512,8 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     HIP_TRY(hipEventRecord(g->fit0, s));
     // R, and in the same pass the identity-padded copy the factorisation works on
     const bool fused = Np / 64 <= 32 && g_chol_fused;
-    double *work = fused ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
+    const bool fused2 = Np / 64 > 32 && g_chol_fused && g_chol_fused2;      // the two-level order, out of place as well
+    double *work = (fused || fused2) ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
     // (with the working copy the same pass writes the identity the ride-along starts from and clears the info word)
     const bool ride = fused && g_chol_ride != 0;
     const bool one_pass = ride && !A_host;
@@ -532,6 +535,10 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
             std::swap(g->T, g->Wp);
             packed = true;
         } else KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
+    } else if (fused2) {
+        KERNEL_TRY(launch_cholesky_fused2(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, 4, s));
+        g->L_upper_dirty = true;
+        KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     } else {
         KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s, g->T.p));      // T: free until launch_trinv
         g->L_upper_dirty = true;

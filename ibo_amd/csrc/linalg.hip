@@ -844,6 +844,40 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
     return (int)hipGetLastError();
 }
 
+// The same out-of-place scheme in the TWO-LEVEL order (panels of P block columns; one matrix of more than 32 blocks):
+// inside a panel every block column is one chol_step_kernel launch over the tiles (i, k), jb < k < pend, k <= i < nb --
+// at most 3 x 63, one per CU -- instead of the diagonal / row-block / update launches (21.4 -> 18.5 us per column at
+// N = 4096); a panel's last column has nothing to update inside the panel and keeps its two launches; then the K = 64 P
+// update of the matrix right of the panel, its operands read from the finished columns in `out`.  The arithmetic and its
+// order are those of launch_cholesky_batched with the same P: identical bits (tested).
+int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s)
+{
+    const int nb = Npad / 64;
+    if (g_chol_panel > 0) P = g_chol_panel;
+    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    for (int p0 = 0; p0 < nb; p0 += P) {
+        const int pend = p0 + P < nb ? p0 + P : nb;
+        for (int jb = p0; jb < pend; jb++) {
+            int nt = 0;
+            for (int k = jb + 1; k < pend; k++) nt += nb - k;
+            if (nt > 0 && nt <= 512) {
+                hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                                   info_dev, nt, 0, (double *)nullptr, (double *)nullptr, nt);
+            } else {
+                hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
+                                   (size_t)0, (size_t)0, out);
+                if (jb + 1 < nb) {
+                    hipLaunchKernelGGL(chol_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, Npad, jb, diag64, (size_t)0,
+                                       (size_t)0, out, -1);
+                    if (jb + 1 < pend) launch_update(work, Npad, jb, jb + 1, jb + 1, pend, 1, 0, s, out);
+                }
+            }
+        }
+        if (pend < nb) launch_update(work, Npad, p0, pend, pend, nb, 1, 0, s, out);
+    }
+    return (int)hipGetLastError();
+}
+
 // W[r][c] = Et[c][r] for c <= r, 0 above the diagonal (Et = (L^-1)^T from the ride-along; its blocks below the
 // diagonal were never written)
 __global__ void transpose_lower_kernel(const double *__restrict__ Et, double *__restrict__ W, int Npad)

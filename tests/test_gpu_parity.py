@@ -998,6 +998,31 @@ def test_trinv_wave_layouts_agree(ibo):
         assert np.abs(Ws[0] @ GP.L - np.eye(N)).max() < 1e-10 and np.abs(np.triu(Ws[0], 1)).max() == 0.0
 
 
+def test_two_level_fused_fit_equals_the_unfused_order(ibo):
+    """fits of more than 2048 rows: panels of four block columns, inside a panel one fused launch per column (out of place),
+    against the diagonal / row-block / update launches in place -- the same arithmetic in the same order, so L and W agree
+    bit for bit; also ragged sizes (a last panel of one, two, three columns) and a matrix that is not positive definite"""
+    from ibo_amd import _lib, NotPositiveDefinite
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    for N in (2113, 2200, 2250, 3000):                        # 34, 35, 36, 47 blocks
+        X, Y = synth(N + 1, N, 5)
+        res = []
+        for fused2 in (1, 0):
+            _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", fused2))
+            try:
+                GP = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)
+                W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+                res.append((GP.L.copy(), W))
+            finally:
+                _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", 1))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert np.abs(res[0][0] - np.linalg.cholesky(GP.R)).max() < 1e-11 and np.abs(np.triu(res[0][0], 1)).max() == 0.0
+    Xd = np.vstack([X[:2199], X[77:78]])                      # a duplicate point and no noise
+    with pytest.raises(NotPositiveDefinite):
+        GaussianProcess(GaussianKernel_ard([.45] * 5), Xd, Y[:2200], noise=0.0)
+
+
 def test_cholesky_panel_orders_agree(ibo):
     """the two-level (panel = 4 block columns, K = 256 updates) and the plain right-looking factorisation give
     the same factor to rounding; the batched NLML grid does not depend on what shares its launches"""
