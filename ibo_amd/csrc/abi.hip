@@ -1512,6 +1512,10 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
         KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dKi.p, Np, s, dT.p, Np, 0,
                                      dW.p, dinfo.p));
         KERNEL_TRY(launch_cholesky_fused(dT.p, dL.p, Np, d64.p, dinfo.p, s, dW.p, dKi.p, true));
+    } else if (Np / 64 > 32 && g_chol_fused && g_chol_fused2) {
+        // beyond: the two-level order with fused in-panel columns, out of place (dKi receives the unpadded matrix, unused)
+        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dKi.p, Np, s, dT.p, Np));
+        KERNEL_TRY(launch_cholesky_fused2(dT.p, dL.p, Np, d64.p, dinfo.p, 4, s));
     } else {
         KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p, Np, 1.0, s));                     // identity pad
         KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p, Np, s));
