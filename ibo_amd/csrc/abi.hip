@@ -518,7 +518,7 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     const bool ride = fused && g_chol_ride != 0;
     const bool one_pass = ride && !A_host;
     KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, Np, s,
-                                 A_host ? nullptr : work, Np, 0, one_pass ? g->W.p : nullptr, one_pass ? g->info.p : nullptr));
+                                 A_host ? nullptr : work, Np, 0, one_pass ? g->W.p : nullptr, (one_pass || fused2) ? g->info.p : nullptr));
     if (A_host) KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
     bool packed = false;
     if (fused) {
@@ -536,7 +536,7 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
             packed = true;
         } else KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     } else if (fused2) {
-        KERNEL_TRY(launch_cholesky_fused2(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, 4, s));
+        KERNEL_TRY(launch_cholesky_fused2(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, 4, s, true));     // (the covariance pass cleared the info word)
         g->L_upper_dirty = true;
         KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     } else {
@@ -1509,12 +1509,12 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     // until the transpose) -- instead of the three-kernel columns and the recursive-doubling inversion
     const bool fused = Np / 64 <= 32 && g_chol_fused && g_chol_ride;
     if (fused) {
-        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dKi.p, Np, s, dT.p, Np, 0,
+        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np, 0,
                                      dW.p, dinfo.p));
         KERNEL_TRY(launch_cholesky_fused(dT.p, dL.p, Np, d64.p, dinfo.p, s, dW.p, dKi.p, true));
     } else if (Np / 64 > 32 && g_chol_fused && g_chol_fused2) {
-        // beyond: the two-level order with fused in-panel columns, out of place (dKi receives the unpadded matrix, unused)
-        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dKi.p, Np, s, dT.p, Np));
+        // beyond: the two-level order with fused in-panel columns, out of place
+        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np));
         KERNEL_TRY(launch_cholesky_fused2(dT.p, dL.p, Np, d64.p, dinfo.p, 4, s));
     } else {
         KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p, Np, 1.0, s));                     // identity pad

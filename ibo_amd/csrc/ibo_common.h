@@ -232,7 +232,8 @@ void set_chol_panel_rows(int v);
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s,
                           double *Ework = nullptr, double *Eout = nullptr, bool info_is_zero = false);
 // the two-level order (panels of P block columns) out of place, one fused launch per block column inside a panel
-int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s);
+int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s,
+                           bool info_is_zero = false);
 int launch_transpose_lower(const double *Et, double *W, int Npad, hipStream_t s);
 // W = Et^T (lower, rows >= N zero) and its MFMA-fragment-order copy Wp (another buffer than Et) in one pass
 int launch_transpose_pack(const double *Et, int N, int Npad, double *W, double *Wp, hipStream_t s);

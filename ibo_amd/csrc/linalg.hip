@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64, D = kp.D;
     if (zero_word && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) *zero_word = 0;
     if (lower_only && j0 > i0 + 63) return;          // a factorisation only reads the lower triangle
+    if (j0 > i0) K2 = nullptr;                       // ... so the working copy gets no blocks above the diagonal (67 MB less at N = 4096)
     if (Eye) {                                       // an np2 x np2 identity in the same pass (the fit's ride-along rows)
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
                     // hard-wires 1+noise (ego/gaussianprocess/__init__.py:138)
                     v = (diag_rule == 0) ? (1.0 + noise) : (v + noise);
                 }
-                K[(size_t)i * ldk + j] = v;
+                if (K) K[(size_t)i * ldk + j] = v;
                 if (K2) K2[(size_t)i * np2 + j] = v;
             } else if (K2 && i < np2 && j < np2) {
                 K2[(size_t)i * np2 + j] = (i == j) ? 1.0 : 0.0;     // identity pad of the np2 x np2 working copy
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
 }
 
 // K2 (optional, square case): a second, np2 x np2 copy of K padded with the identity -- the matrix the
-// factorisation works on, written by the same kernel instead of a separate pad-and-copy pass.
+// factorisation works on, written by the same kernel instead of a separate pad-and-copy pass: its blocks on and below
+// the diagonal only.  K may be NULL when only the working copy is wanted.
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
                       int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2, int lower_only,
                       double *Eye, int *zero_word)
@@ -548,6 +550,40 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
     }
 }
 
+// A panel's LAST block column in the two-level order (nothing to update inside the panel): every row block's workgroup
+// repeats the diagonal factorisation -- as chol_step_kernel does -- and multiplies its block by inv(L_jj)^T; workgroup 0
+// also stores the diagonal block and its inverse.  One launch for chol_diag_kernel + chol_trsm_kernel, same arithmetic.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void chol_diag_trsm_kernel(const double *__restrict__ A, double *__restrict__ Lout, int Npad, int jb, double *__restrict__ diag64, int *info)
+{
+    __shared__ double S[64 * SD];
+    __shared__ double V[64 * SD];
+    __shared__ double T[64 * SD];
+    TILE_IDS;
+    const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
+    const int ib = jb + 1 + blockIdx.x;
+    double vd[16];
+    diag64_fetch(A + doff, Npad, vd);
+    d2_t va[8];
+    tile64_fetch(A + (size_t)ib * 64 * Npad + jb * 64, Npad, va);
+    diag64_stash(vd, S, V, T);
+    __syncthreads();
+    diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
+    if (blockIdx.x == 0) diag64_store(Lout + doff, Npad, diag64 + (size_t)jb * 4096, S, V);
+    __syncthreads();
+    tile64_stash<false, SD>(S, va);
+    __syncthreads();
+    d4_t acc[2][2] = {};
+    tile64_mma_nt_tri<SD>(S, V, acc);
+    double *Ob = Lout + (size_t)ib * 64 * Npad + jb * 64;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(m, r) * Npad + TILE_COL_TRI(n)] = acc[m][n][r];
+}
+
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
 __global__ __launch_bounds__(256) void chol_trsm_kernel(double *L, int Npad, int jb,
                                                         const double *__restrict__ diag64,
@@ -850,11 +886,11 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
 // N = 4096); a panel's last column has nothing to update inside the panel and keeps its two launches; then the K = 64 P
 // update of the matrix right of the panel, its operands read from the finished columns in `out`.  The arithmetic and its
 // order are those of launch_cholesky_batched with the same P: identical bits (tested).
-int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s)
+int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s, bool info_is_zero)
 {
     const int nb = Npad / 64;
     if (g_chol_panel > 0) P = g_chol_panel;
-    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    if (!info_is_zero) HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     for (int p0 = 0; p0 < nb; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
         for (int jb = p0; jb < pend; jb++) {
@@ -863,6 +899,8 @@ int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, 
             if (nt > 0 && nt <= 512) {
                 hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, work, out, Npad, jb, diag64,
                                    info_dev, nt, 0, (double *)nullptr, (double *)nullptr, nt);
+            } else if (nt == 0 && jb + 1 < nb && nb - jb - 1 <= 256) {
+                hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev);
             } else {
                 hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
                                    (size_t)0, (size_t)0, out);
