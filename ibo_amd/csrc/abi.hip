@@ -51,6 +51,7 @@ void ibo_internal_set_error(const char *msg)
 extern int g_sweep_variant;     // sweep.hip
 static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
+static int g_fused2_min_nb = 33;  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
 static int g_chol_fused2 = 1;    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
 static int g_zero_copy = 1;      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
 static int g_flag_poll = 1;      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
@@ -284,6 +285,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_fused2")) { g_chol_fused2 = value; return IBO_OK; }
+    if (key && !strcmp(key, "fused2_min_nb")) { g_fused2_min_nb = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_update2")) { set_chol_update2(value); return IBO_OK; }
     if (key && !strcmp(key, "update2_min_tiles")) { set_chol_update2_min_tiles(value); return IBO_OK; }
     if (key && !strcmp(key, "trinv_wide")) { set_trinv_wide(value); return IBO_OK; }
@@ -511,8 +513,8 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     const double *A_host = have_A ? g->A.p : nullptr;      // (only tested for presence below)
     HIP_TRY(hipEventRecord(g->fit0, s));
     // R, and in the same pass the identity-padded copy the factorisation works on
-    const bool fused = Np / 64 <= 32 && g_chol_fused;
-    const bool fused2 = Np / 64 > 32 && g_chol_fused && g_chol_fused2;      // the two-level order, out of place as well
+    const bool fused2 = Np / 64 >= g_fused2_min_nb && g_chol_fused && g_chol_fused2;      // the two-level order, out of place as well
+    const bool fused = !fused2 && Np / 64 <= 32 && g_chol_fused;
     double *work = (fused || fused2) ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
     // (with the working copy the same pass writes the identity the ride-along starts from and clears the info word)
     const bool ride = fused && g_chol_ride != 0;
