@@ -550,22 +550,28 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
     }
 }
 
-// A panel's LAST block column in the two-level order (nothing to update inside the panel): every row block's workgroup
-// repeats the diagonal factorisation -- as chol_step_kernel does -- and multiplies its block by inv(L_jj)^T; workgroup 0
-// also stores the diagonal block and its inverse.  One launch for chol_diag_kernel + chol_trsm_kernel, same arithmetic.
+// Diagonal block + row blocks of one block column in ONE launch: every row block's workgroup repeats the diagonal
+// factorisation -- as chol_step_kernel does -- and multiplies its block by inv(L_jj)^T; workgroup 0 also stores the diagonal
+// block and its inverse.  chol_diag_kernel + chol_trsm_kernel, same arithmetic.  Workgroups [0, m) take the matrix's row
+// blocks jb + 1 .., workgroups m .. the row blocks 0 .. of the ride-along's E (chol_step_kernel's comment), if any.
+// Used where a block column has no tile to update (a panel's last column in the two-level order) and where it has too many
+// for one tile per workgroup (chol_update_step_kernel then does the updates).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void chol_diag_trsm_kernel(const double *__restrict__ A, double *__restrict__ Lout, int Npad, int jb, double *__restrict__ diag64, int *info)
+void chol_diag_trsm_kernel(const double *__restrict__ A, double *__restrict__ Lout, int Npad, int jb, double *__restrict__ diag64, int *info,
+                           int m, const double *__restrict__ Ework, double *__restrict__ Eout)
 {
     __shared__ double S[64 * SD];
     __shared__ double V[64 * SD];
     __shared__ double T[64 * SD];
     TILE_IDS;
     const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
-    const int ib = jb + 1 + blockIdx.x;
+    const bool erow = (int)blockIdx.x >= m;
+    const int ib = erow ? (int)blockIdx.x - m : jb + 1 + (int)blockIdx.x;
+    const size_t roff = (size_t)ib * 64 * Npad + jb * 64;
     double vd[16];
     diag64_fetch(A + doff, Npad, vd);
     d2_t va[8];
-    tile64_fetch(A + (size_t)ib * 64 * Npad + jb * 64, Npad, va);
+    tile64_fetch((erow ? Ework : A) + roff, Npad, va);
     diag64_stash(vd, S, V, T);
     __syncthreads();
     diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
@@ -575,13 +581,64 @@ void chol_diag_trsm_kernel(const double *__restrict__ A, double *__restrict__ Lo
     __syncthreads();
     d4_t acc[2][2] = {};
     tile64_mma_nt_tri<SD>(S, V, acc);
-    double *Ob = Lout + (size_t)ib * 64 * Npad + jb * 64;
+    double *Ob = (erow ? Eout : Lout) + roff;
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int mm = 0; mm < 2; mm++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(m, r) * Npad + TILE_COL_TRI(n)] = acc[m][n][r];
+            for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL_TRI(n)] = acc[mm][n][r];
+}
+
+// The updates of a fused step on their own: tile numbering as in chol_step_kernel (t < nchol: tile (i, k) of the matrix,
+// jb < k <= i; then tile (i, k) of E, i <= jb < k), C -= X_i X_k^T with the row blocks X = (row block) inv(L_jj)^T that
+// chol_diag_trsm_kernel has stored in Lout / Eout.  X_i is negated on its way into LDS and the accumulators start as C:
+// the arithmetic of chol_step_kernel's last product.  Two workgroups per CU.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void chol_update_step_kernel(double *__restrict__ A, const double *__restrict__ Lout, int Npad, int jb, int nchol,
+                             double *__restrict__ Ework, const double *__restrict__ Eout)
+{
+    __shared__ double As[64 * T64_LD];
+    __shared__ double Bs[64 * T64_LD];
+    TILE_IDS;
+    const int nb = Npad / 64, m = nb - jb - 1, t = blockIdx.x;
+    int i, k;
+    const double *Xi;
+    double *C;
+    if (t < nchol) {
+        k = jb + 1;
+        int rem = t;
+        while (rem >= nb - k) { rem -= nb - k; k++; }
+        i = k + rem;
+        Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
+        C = A + (size_t)i * 64 * Npad + k * 64;
+    } else {
+        const int e = t - nchol;
+        i = e / m; k = jb + 1 + e % m;
+        Xi = Eout + (size_t)i * 64 * Npad + jb * 64;
+        C = Ework + (size_t)i * 64 * Npad + k * 64;
+    }
+    const double *Xk = Lout + (size_t)k * 64 * Npad + jb * 64;
+    d2_t va[8], vb[8];
+    tile64_fetch(Xi, Npad, va);
+    tile64_fetch(Xk, Npad, vb);
+    d4_t acc[2][2];
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[mm][n][r] = C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)];
+    tile64_stash<true>(As, va);
+    tile64_stash(Bs, vb);
+    __syncthreads();
+    tile64_mma_nt(As, Bs, acc);
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] = acc[mm][n][r];
 }
 
 // rows below the diagonal block: A[ib][jb] <- A[ib][jb] * inv(L_jj)^T
@@ -840,6 +897,9 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // Plain right-looking order with one fused launch per block column (chol_step_kernel): `work` holds the matrix
 // and is destroyed, the factor (lower blocks; the strict upper blocks are not touched) goes to `out`.
 // Bit-identical to launch_cholesky with panel = 1.
+static int g_step_split = 256;      // ibo_set_option("step_split"): tiles of a block column from which rows and updates are separate launches
+void set_step_split(int v) { g_step_split = v; }
+
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s, double *Ework,
                           double *Eout, bool info_is_zero)
 {
@@ -850,7 +910,15 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
         const int m = nb - jb - 1, nchol = m * (m + 1) / 2;
         const int nextra = (Ework && m > 0) ? (jb + 1) * m : 0;       // tiles of the W = L^-1 ride-along (chol_step_kernel)
         int ridden = 0;
-        if (m > 0 && nchol <= MAXT) {
+        if (m > 0 && nchol + nextra > g_step_split) {
+            // more tiles than CUs: a fused step would give a workgroup two tiles -- six products, four of them the row blocks
+            // X = (block) inv(L_jj)^T that every tile of a row or column recomputes.  Row blocks once (with the chain,
+            // nb workgroups), then one product per tile, two workgroups per CU: 29 -> 19 us per step at N = 2048.
+            hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(m + (nextra ? jb + 1 : 0)), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                               info_dev, m, Ework, Eout);
+            hipLaunchKernelGGL(chol_update_step_kernel, dim3(nchol + nextra), dim3(256), 0, s, work, out, Npad, jb, nchol, Ework, Eout);
+            ridden = nextra;
+        } else if (m > 0 && nchol <= MAXT) {
             // the trailing tiles fit on the chip (two rounds at most): repeating the diagonal factorisation in each
             // workgroup costs nothing and two launches disappear; extra tiles come along
             ridden = nextra < MAXT - nchol ? nextra : MAXT - nchol;
@@ -900,7 +968,8 @@ int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, 
                 hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, work, out, Npad, jb, diag64,
                                    info_dev, nt, 0, (double *)nullptr, (double *)nullptr, nt);
             } else if (nt == 0 && jb + 1 < nb && nb - jb - 1 <= 256) {
-                hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev);
+                hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nb - jb - 1,
+                                   (const double *)nullptr, (double *)nullptr);
             } else {
                 hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
                                    (size_t)0, (size_t)0, out);

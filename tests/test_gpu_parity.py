@@ -1023,6 +1023,35 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
         GaussianProcess(GaussianKernel_ard([.45] * 5), Xd, Y[:2200], noise=0.0)
 
 
+def test_split_steps_equal_fused_steps(ibo):
+    """fits of up to 2048 rows: a block column with more tiles than CUs (ride-along included) runs as two launches -- row blocks
+    with the chain, then one product per tile -- instead of a fused step with two tiles per workgroup: same arithmetic, same
+    bits in L and W; and the same L as the three-kernel sequence in place"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    for N in (1500, 2048, 1985):
+        X, Y = synth(N + 2, N, 4)
+        res = []
+        for split in (256, 1 << 30, 64):
+            _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
+            try:
+                GP = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05)
+                W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+                res.append((GP.L.copy(), W))
+            finally:
+                _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
+        for L, W in res[1:]:
+            assert np.array_equal(L, res[0][0]) and np.array_equal(W, res[0][1])
+        _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 0))
+        try:
+            L0 = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05).L
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 1))
+        assert np.array_equal(L0, res[0][0])
+        assert np.abs(res[0][1] @ res[0][0] - np.eye(N)).max() < 1e-10
+
+
 def test_cholesky_panel_orders_agree(ibo):
     """the two-level (panel = 4 block columns, K = 256 updates) and the plain right-looking factorisation give
     the same factor to rounding; the batched NLML grid does not depend on what shares its launches"""
