@@ -964,20 +964,20 @@ int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, 
         for (int jb = p0; jb < pend; jb++) {
             int nt = 0;
             for (int k = jb + 1; k < pend; k++) nt += nb - k;
-            if (nt > 0 && nt <= 512) {
+            if (nt > 0 && nt <= g_step_split) {
                 hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, work, out, Npad, jb, diag64,
                                    info_dev, nt, 0, (double *)nullptr, (double *)nullptr, nt);
-            } else if (nt == 0 && jb + 1 < nb && nb - jb - 1 <= 256) {
+            } else if (nt > 0) {           // more in-panel tiles than CUs (beyond 5400 rows): row blocks first, then the updates
                 hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nb - jb - 1,
                                    (const double *)nullptr, (double *)nullptr);
-            } else {
+                hipLaunchKernelGGL(chol_update_step_kernel, dim3(nt), dim3(256), 0, s, work, out, Npad, jb, nt, (double *)nullptr,
+                                   (const double *)nullptr);
+            } else if (jb + 1 < nb) {
+                hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nb - jb - 1,
+                                   (const double *)nullptr, (double *)nullptr);
+            } else {                       // the matrix's last block column
                 hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
                                    (size_t)0, (size_t)0, out);
-                if (jb + 1 < nb) {
-                    hipLaunchKernelGGL(chol_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, Npad, jb, diag64, (size_t)0,
-                                       (size_t)0, out, -1);
-                    if (jb + 1 < pend) launch_update(work, Npad, jb, jb + 1, jb + 1, pend, 1, 0, s, out);
-                }
             }
         }
         if (pend < nb) launch_update(work, Npad, p0, pend, pend, nb, 1, 0, s, out);

@@ -1008,15 +1008,16 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
     for N in (2113, 2200, 2250, 3000):                        # 34, 35, 36, 47 blocks
         X, Y = synth(N + 1, N, 5)
         res = []
-        for fused2 in (1, 0):
-            _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", fused2))
+        for fused2, split in ((1, 256), (0, 256), (1, 40)):      # split 40: in-panel columns as row blocks + updates (as beyond 5400 rows)
+            _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", fused2)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
             try:
                 GP = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)
                 W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
                 res.append((GP.L.copy(), W))
             finally:
-                _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", 1))
-        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+                _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", 1)); _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
+        for L, W in res[1:]:
+            assert np.array_equal(res[0][0], L) and np.array_equal(res[0][1], W)
         assert np.abs(res[0][0] - np.linalg.cholesky(GP.R)).max() < 1e-11 and np.abs(np.triu(res[0][0], 1)).max() == 0.0
     Xd = np.vstack([X[:2199], X[77:78]])                      # a duplicate point and no noise
     with pytest.raises(NotPositiveDefinite):
