@@ -30,11 +30,16 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
                                                          double *__restrict__ K2, int np2, int lower_only,
                                                          double *__restrict__ Eye, int *__restrict__ zero_word)
 {
-    __shared__ double As[64 * COV_LD], Bs[64 * COV_LD];
+    __shared__ double AB[2 * 64 * COV_LD];           // the two tiles' points; afterwards the tile itself, transposed (64 x 65)
+    double *As = AB, *Bs = AB + 64 * COV_LD;
+    static_assert(2 * 64 * COV_LD >= 64 * 65, "the transposed tile reuses the staging buffers");
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64, D = kp.D;
     if (zero_word && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) *zero_word = 0;
-    if (lower_only && j0 > i0 + 63) return;          // a factorisation only reads the lower triangle
+    // K(X, X) is symmetric bit for bit ((a - b)^2 = (b - a)^2): a tile below the diagonal also writes its mirror image,
+    // the tiles above the diagonal compute nothing (half the fp64 exps; at N = 4096 the pass is then bound by its 200 MB of writes: 46 us)
+    const bool mirror = square && !lower_only && K && j0 < i0;
+    const bool skip = square && j0 > i0;             // (lower_only: a factorisation only reads the lower triangle)
     if (j0 > i0) K2 = nullptr;                       // ... so the working copy gets no blocks above the diagonal (67 MB less at N = 4096)
     if (Eye) {                                       // an np2 x np2 identity in the same pass (the fit's ride-along rows)
 #pragma unroll
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
                 if (i < np2 && j < np2) Eye[(size_t)i * np2 + j] = (i == j) ? 1.0 : 0.0;
             }
     }
+    if (skip) return;
     for (int e = t; e < 64 * D; e += 256) {
         const int r = e / D, d = e - r * D;
         As[r * COV_LD + d] = (i0 + r < n1) ? A1[(size_t)(i0 + r) * ldp + d] : 0.0;
@@ -82,9 +88,22 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
                 }
                 if (K) K[(size_t)i * ldk + j] = v;
                 if (K2) K2[(size_t)i * np2 + j] = v;
+                z[r][c] = v;
             } else if (K2 && i < np2 && j < np2) {
                 K2[(size_t)i * np2 + j] = (i == j) ? 1.0 : 0.0;     // identity pad of the np2 x np2 working copy
             }
+        }
+    }
+    if (mirror) {                                    // K[j][i] = K[i][j], written row by row from the transposed tile
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) AB[(tx + 16 * c) * 65 + ty * 4 + r] = z[r][c];
+        __syncthreads();
+        for (int e = t; e < 4096; e += 256) {
+            const int rr = e >> 6, cc = e & 63;
+            if (j0 + rr < n2 && i0 + cc < n1) K[(size_t)(j0 + rr) * ldk + i0 + cc] = AB[rr * 65 + cc];
         }
     }
 }
