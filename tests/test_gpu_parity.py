@@ -1051,6 +1051,20 @@ def test_split_steps_equal_fused_steps(ibo):
             _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 1))
         assert np.array_equal(L0, res[0][0])
         assert np.abs(res[0][1] @ res[0][0] - np.eye(N)).max() < 1e-10
+    # the NLML gradient takes the same route (K^-1 = W^T W from the ride-along): same value and gradient either way, and the oracle's
+    import oracle.oracle as orc
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+    X, Y = synth(1603, 1600, 3)
+    out = []
+    for split in (256, 1 << 30):
+        _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
+        try:
+            out.append(marginalLikelihood(GaussianKernel_ard([.3, .4, .5]), X, Y, 3, True, noise=1e-2))
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    ov, od = orc.marginal_likelihood(orc.Kern("ard", [.3, .4, .5]), X, Y, 3, True, 1e-2)
+    close(out[0][0], ov); close(out[0][1], od, atol=1e-8)
 
 
 def test_cholesky_panel_orders_agree(ibo):
