@@ -522,6 +522,22 @@ def worker(args):
                                      "addPreferences_ms": pms, "addPreferences_first_call_ms": pref_ms[0],
                                      "gallery8_ms": (time.perf_counter() - t0) * 1e3}
                 del PG, cand4
+                # the sweep kernel against the input dimension (N = 1024, 2^18 candidates: a quarter of the headline batch, so the
+                # tail of the tile rounds weighs more): D = 17..32 take a 32-coordinate row layout and 6..9 k4-steps of the exponent GEMM
+                from ibo_amd.acquisition import sweep as _sweep
+                dims = {}
+                for d in (8, 16, 24, 32):
+                    Xd, Yd = synth(11, 1024, d)
+                    cd = DeviceArray.from_host(np.random.RandomState(111).rand(1 << 18, d), local_rank)
+                    for name, kern in (("se_ard", GaussianKernel_ard([.3 * np.sqrt(d / 4.)] * d)), ("matern52", MaternKernel5([.5 * np.sqrt(d / 4.), 1.0]))):
+                        g = GaussianProcess(kern, Xd, Yd, noise=.1, device=local_rank)
+                        for _ in range(2):
+                            _sweep(g, cd)
+                        ms = float(np.mean([_sweep(g, cd)["kernel_ms"] for _ in range(5)]))
+                        dims["D%d_%s" % (d, name)] = {"kernel_ms": ms, "frac": f_eval(1024, d) * float(1 << 18) / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+                        del g
+                    del cd
+                cfgs["sweep_by_dimension"] = {"workload": "N=1024, EI over 2^18 candidates, kernel time (HIP events)", "results": dims}
             if rank == 0:
                 out["configs"] = cfgs
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
