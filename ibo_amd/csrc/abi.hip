@@ -539,7 +539,7 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
             packed = true;
         } else KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     } else if (fused2) {
-        KERNEL_TRY(launch_cholesky_fused2(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, 4, s, true));     // (the covariance pass cleared the info word)
+        KERNEL_TRY(launch_cholesky_fused2(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, 4, s, true, g->W.p));    // W: free until launch_trinv     // (the covariance pass cleared the info word)
         g->L_upper_dirty = true;
         KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
     } else {

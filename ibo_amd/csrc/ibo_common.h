@@ -221,7 +221,7 @@ int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStrea
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
                             int panel, hipStream_t s, double *ws = nullptr, size_t wstride = 0);
 int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t lstride, double *ws, size_t wstride,
-                        hipStream_t s);
+                        hipStream_t s, const double *Lpanel = nullptr);
 void set_chol_panel(int p);
 void set_chol_update2(int v);
 void set_chol_update2_min_tiles(int v);
@@ -234,7 +234,7 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
                           double *Ework = nullptr, double *Eout = nullptr, bool info_is_zero = false);
 // the two-level order (panels of P block columns) out of place, one fused launch per block column inside a panel
 int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s,
-                           bool info_is_zero = false);
+                           bool info_is_zero = false, double *ws = nullptr);
 int launch_transpose_lower(const double *Et, double *W, int Npad, hipStream_t s);
 // W = Et^T (lower, rows >= N zero) and its MFMA-fragment-order copy Wp (another buffer than Et) in one pass
 int launch_transpose_pack(const double *Et, int N, int Npad, double *W, double *Wp, hipStream_t s);

@@ -973,7 +973,7 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
 // N = 4096); a panel's last column has nothing to update inside the panel and keeps its two launches; then the K = 64 P
 // update of the matrix right of the panel, its operands read from the finished columns in `out`.  The arithmetic and its
 // order are those of launch_cholesky_batched with the same P: identical bits (tested).
-int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s, bool info_is_zero)
+int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s, bool info_is_zero, double *ws)
 {
     const int nb = Npad / 64;
     if (g_chol_panel > 0) P = g_chol_panel;
@@ -999,7 +999,13 @@ int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, 
                                    (size_t)0, (size_t)0, out);
             }
         }
-        if (pend < nb) launch_update(work, Npad, p0, pend, pend, nb, 1, 0, s, out);
+        if (pend < nb) {
+            const int nI2 = (Npad - 64 * pend + 127) / 128;
+            if (ws && g_update2 && nI2 * (nI2 + 1) / 2 >= g_update2_min_tiles) {
+                int rc = launch_chol_update2(work, Npad, p0, pend, 1, 0, ws, 0, s, out);
+                if (rc) return rc;
+            } else launch_update(work, Npad, p0, pend, pend, nb, 1, 0, s, out);
+        }
     }
     return (int)hipGetLastError();
 }

@@ -158,13 +158,14 @@ __global__ __launch_bounds__(U2_NW * 64, 4) void chol_update2_kernel(double *L, 
 
 // ws: 2 T K doubles per matrix (T = Npad - 64 pend), `wstride` doubles apart
 int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t lstride, double *ws, size_t wstride,
-                        hipStream_t s)
+                        hipStream_t s, const double *Lpanel)
 {
+    if (!Lpanel) Lpanel = L;                 // out-of-place factorisations keep the finished block columns in another matrix
     const int r0 = 64 * pend, c0 = 64 * p0, K = 64 * (pend - p0), T = Npad - r0;
     if (T <= 0) return 0;
     double *PA = ws, *PB = ws + (size_t)T * K;
     const size_t total = (size_t)T * K;
-    hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, L, Npad, r0, c0, K, PA, PB,
+    hipLaunchKernelGGL(pack_panel_kernel, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, Lpanel, Npad, r0, c0, K, PA, PB,
                        lstride, wstride);
     const int nI = (T + U2_TM - 1) / U2_TM;
     const int tiles = nI * (nI + 1) / 2;
