@@ -944,6 +944,10 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
             const int nt = nchol + ridden;
             hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < CU ? nt : CU), dim3(256), 0, s, work, out, Npad, jb, diag64,
                                info_dev, nchol, 0, Ework, Eout, nt);
+        } else if (m == 0 && Ework) {
+            // last block column with the ride-along: nothing trails it, E's row blocks only need the multiplication by inv(L_jj)^T
+            hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, 0, Ework, Eout);
+            continue;
         } else {
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, work, Npad, jb, diag64, info_dev,
                                (size_t)0, (size_t)0, out);
@@ -959,10 +963,6 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
             hipLaunchKernelGGL(chol_step_kernel<true>, dim3(nt < CU ? nt : CU), dim3(256), 0, s, work, out, Npad, jb,
                                diag64, info_dev, 0, ridden, Ework, Eout, nt);
         }
-        // last block column of E: nothing trails it, its row blocks only need the multiplication by inv(L_jj)^T
-        if (Ework && m == 0)
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3(nb), dim3(256), 0, s, Ework, Npad, jb, diag64, (size_t)0, (size_t)0,
-                               Eout, 0);
     }
     return (int)hipGetLastError();
 }
