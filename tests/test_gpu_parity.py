@@ -1065,6 +1065,12 @@ def test_split_steps_equal_fused_steps(ibo):
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
     ov, od = orc.marginal_likelihood(orc.Kern("ard", [.3, .4, .5]), X, Y, 3, True, 1e-2)
     close(out[0][0], ov); close(out[0][1], od, atol=1e-8)
+    # a failed pivot in a split step (an early and a late block column) is reported like anywhere else
+    from ibo_amd import NotPositiveDefinite
+    for dup in (40, 1590):
+        Xd = X.copy(); Xd[dup + 5] = Xd[dup]
+        with pytest.raises(NotPositiveDefinite):
+            GaussianProcess(GaussianKernel_ard([.3, .4, .5]), Xd, Y, noise=0.0)
 
 
 def test_cholesky_panel_orders_agree(ibo):
