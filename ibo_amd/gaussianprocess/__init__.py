@@ -436,23 +436,22 @@ class PrefGaussianProcess(GaussianProcess):
         """distinct points of all (preferred, unpreferred, degree) triples in order of first appearance
         (preferred before unpreferred within a triple; the reference's numbering, :395-406, which callers
         see through GP.X) -> (points (n, D), [(i_preferred, i_unpreferred, degree)], was-ever-preferred mask)"""
-        slot = {}
-        pts = []
-        pairs = []
-        fav = []
-        for better, worse, degree in prefs:
-            ij = []
-            for x in (better, worse):
-                key = cls._point_key(x)
-                k = slot.get(key)
-                if k is None:
-                    k = slot[key] = len(pts)
-                    pts.append(np.asarray(x, dtype=float))
-                    fav.append(False)
-                ij.append(k)
-            fav[ij[0]] = True
-            pairs.append((ij[0], ij[1], degree))
-        return np.array(pts, dtype=float), pairs, fav
+        if len(prefs) == 0:
+            return np.zeros((0, 0)), [], []
+        # all 2P points at once: identity of a point = its fp64 bytes (+0.0 folds -0.0 into 0.0, as == would)
+        A = np.array([np.asarray(x, dtype=np.float64) for tr in prefs for x in (tr[0], tr[1])], dtype=np.float64)
+        A = A.reshape(len(A), -1)
+        K = np.ascontiguousarray(A + 0.0)
+        keys = K.view(np.dtype((np.void, K.dtype.itemsize * K.shape[1]))).ravel()
+        _, first, inv = np.unique(keys, return_index=True, return_inverse=True)
+        order = np.argsort(first, kind="stable")               # distinct points by first appearance
+        number = np.empty(len(order), dtype=np.int64)
+        number[order] = np.arange(len(order))
+        k = number[np.asarray(inv).ravel()]
+        fav = np.zeros(len(order), dtype=bool)
+        fav[k[0::2]] = True
+        pairs = [(int(i), int(j), tr[2]) for i, j, tr in zip(k[0::2], k[1::2], prefs)]
+        return A[first[order]], pairs, fav.tolist()
 
     def addPreferences(self, prefs, useC=True, showPrefLikelihood=False):
         """add (x_preferred, x_unpreferred, degree) triples and refit from ALL preferences (:347-498)"""
@@ -460,9 +459,12 @@ class PrefGaussianProcess(GaussianProcess):
         newX, prefinds, preferred = self._index_preferences(self.preferences)
         # warm start of the MAP (:408-427): a point keeps the latent value it had; a new point starts at the
         # top of the current range if it was ever preferred, at the bottom otherwise
-        had = dict((self._point_key(x), y) for x, y in zip(self.X, self.Y))
         top, bottom = (max(self.Y), min(self.Y)) if len(self.Y) > 0 else (.5, -.5)
-        start = [had.get(self._point_key(x), top if fav else bottom) for x, fav in zip(newX, preferred)]
+        if len(self.Y) > 0:
+            had = dict((self._point_key(x), y) for x, y in zip(self.X, self.Y))
+            start = [had.get(self._point_key(x), top if fav else bottom) for x, fav in zip(newX, preferred)]
+        else:
+            start = [top if fav else bottom for fav in preferred]
 
         # K(X,X), Cholesky and L^-1 on the GPU (:432-438)
         self.X = newX
@@ -476,9 +478,10 @@ class PrefGaussianProcess(GaussianProcess):
         # MAP (:442).  The reference runs fmin_bfgs with numerical gradients (gtol 1e-5) on this
         # convex functional; Newton with the analytic Hessian reaches the same optimum in ~10 solves.
         Y = self._map_newton(start, prefinds)
+        unpreferred = set(c for _, c, _ in prefinds)
         for r, c, _ in prefinds:                      # order fix-up (:445-457)
             if Y[r] <= Y[c]:
-                if not any(c1 == r for _, c1, _ in prefinds):
+                if r not in unpreferred:
                     Y[r] = Y[c] + .1
         self._set_map(Y, prefinds, plain_fitted=True)
 
