@@ -1070,7 +1070,10 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16 && (!small2_ok || M <= g_gemv_max));
     // small batches: spread the IBO_SPLIT_PANEL-row panels over the grid too (one tile per 64 candidates alone
     // would leave most of the 256 CUs idle); above ~128 tiles the plain kernel fills the chip
-    bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256));
+    // (4097 .. 8192 candidates are at most 256 tiles of the large-batch kernel -- one round of the chip, 134 us at N = 1024 and
+    // 495 us at N = 2048 whatever their number, where the panel-split kernel takes 142 .. 221 and 478 .. 842 us)
+    const bool sweep2_ok = a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad);
+    bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256 && !(sweep2_ok && M > 4096)));
     const bool small2 = split && small2_ok;
     if (small2) {
         IBO_TRY(exp_table(g->device, &a.exp_tab));

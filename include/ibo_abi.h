@@ -81,8 +81,8 @@ int         ibo_device_name(int device, char *buf, size_t buflen);
 /* self-test of the fp64 MFMA fragment layout on the device (returns IBO_OK or
  * IBO_ERR_HIP with a message); cheap, used by smoke() */
 int         ibo_selftest_mfma(int device, double *max_abs_err);
-/* tuning/testing knobs: "sweep_path" = 0 auto (GEMV kernel for M <= 16, panel-split MFMA
- * kernel up to 8192 candidates, MFMA tile kernel above), 1 force GEMV, 2 force MFMA tile,
+/* tuning/testing knobs: "sweep_path" = 0 auto (the three small-batch kernels up to 4096 candidates, the MFMA tile kernel
+ * above; GEMV / panel-split kernels where the dot form is not admissible), 1 force GEMV, 2 force MFMA tile,
  * 3 force panel-split; "sweep_variant" picks the tile shape; "dot_form" -1 auto / 0 / 1;
  * "chol_panel" P forces the Cholesky panel width in 64-blocks (0 = choose: 1 plain right-looking,
  * 4 two-level); "nlml_batch" B forces the matrices per batched factorisation in ibo_nlml_grid.
