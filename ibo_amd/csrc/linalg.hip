@@ -904,7 +904,9 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
         if (pend < nb) {
             // the big update (K = 64 P): packed-panel kernel when the caller lent a workspace, bit-identical to the other
             const int nI2 = (Npad - 64 * pend + 127) / 128;
-            if (ws && g_update2 && (size_t)nI2 * (nI2 + 1) / 2 * batch >= (size_t)g_update2_min_tiles) {
+            // (a batch keeps the packed-panel kernel down to a quarter of the tiles one matrix needs: its late, small updates are many
+            // short launches of the 64 x 64 kernel otherwise -- C5 0.626 -> 0.60 ms per theta)
+            if (ws && g_update2 && (size_t)nI2 * (nI2 + 1) / 2 * batch >= (size_t)(batch >= 8 ? g_update2_min_tiles / 4 : g_update2_min_tiles)) {
                 int rc = launch_chol_update2(L, Npad, p0, pend, batch, lstride, ws, wstride, s);
                 if (rc) return rc;
             } else launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
