@@ -1459,10 +1459,10 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
             KParams kp;
             IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
             KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, s, nullptr, 0, 1));
-            KERNEL_TRY(launch_nlml_aug(dL.p + nn * k, Np, N, dY.p, s));
         }
+        KERNEL_TRY(launch_nlml_aug(dL.p, Np, N, dY.p, s, nb, nn));
         KERNEL_TRY(launch_cholesky_batched(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s, ws.dP.p, pws));
-        for (int k = 0; k < nb; k++) KERNEL_TRY(launch_nlml_reduce(dL.p + nn * k, Np, N, dout.p + 2 * (t0 + k), s));
+        KERNEL_TRY(launch_nlml_reduce(dL.p, Np, N, dout.p + 2 * t0, s, nb, nn));
     }
     HIP_TRY(hipStreamSynchronize(s));
     std::vector<double> out(2 * (size_t)n_theta);

@@ -261,9 +261,9 @@ int launch_extend_kvec(const KParams &kp, const double *Xp, int ldp, int N, int 
 // d = sqrt(1 + noise - |z|^2); L[N][:N] = z, L[N][N] = d; W[N][:N] = -u/d, W[N][N] = 1/d; row-block N/16 of Wp repacked
 int launch_extend_rows(int N, int Npad, double noise, const double *z, const double *u, double *L, double *W, double *Wp,
                        int *info, hipStream_t s);
-int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s);
+int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s, int batch = 1, size_t lstride = 0);
 int launch_nlml_scalars(const double *L, int Npad, int N, const double *y, const double *alpha, double *out2, hipStream_t s);
-int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s);
+int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s, int batch = 1, size_t lstride = 0);
 int launch_pad_copy(const double *src, int N, int lds, double *dst, int Npad, double pad_diag, hipStream_t s);
 // preference GP: out = base (or 0) + diag I + sparse entries (lin = row * N + col, distinct), identity pad;  A = R + Cinv
 int launch_pref_build(const double *base, int N, int Npad, double diag, int nnz, const long long *lin, const double *val,

@@ -1611,10 +1611,11 @@ int launch_pref_sum(const double *R, const double *Cinv, int N, int Npad, double
 // ------------------------------------------------------------------------
 // The pad rows below the y row are rewritten as identity rows every time: a factorisation that failed (not positive
 // definite) leaves NaNs in them, and the matrix slot is used again.
-__global__ void aug_row_kernel(double *__restrict__ L, int Npad, int N, const double *__restrict__ y)
+__global__ void aug_row_kernel(double *__restrict__ L, int Npad, int N, const double *__restrict__ y, size_t lstride)
 {
     const int k = blockIdx.x * 256 + threadIdx.x, r = N + blockIdx.y;
     if (k >= Npad) return;
+    L += blockIdx.z * lstride;
     if (blockIdx.y == 0) {
         if (k < N) L[(size_t)N * Npad + k] = y[k];
         else if (k == N) L[(size_t)N * Npad + N] = 1e300;
@@ -1624,10 +1625,11 @@ __global__ void aug_row_kernel(double *__restrict__ L, int Npad, int N, const do
 }
 
 __global__ __launch_bounds__(256) void nlml_reduce_kernel(const double *__restrict__ L, int Npad, int N,
-                                                          double *__restrict__ out2)
+                                                          double *__restrict__ out2, size_t lstride)
 {
     __shared__ double rq[256], rl[256];
     const int t = threadIdx.x;
+    L += blockIdx.x * lstride; out2 += 2 * blockIdx.x;       // one workgroup per matrix of the batch
     double q = 0.0, ld = 0.0;
     for (int k0 = t; k0 < N; k0 += 8 * 256) {         // same order of the sums; eight diagonal entries' loads in flight
         double z[8], dg[8];
@@ -1684,15 +1686,15 @@ int launch_nlml_scalars(const double *L, int Npad, int N, const double *y, const
     return (int)hipGetLastError();
 }
 
-int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s)
+int launch_nlml_aug(double *L, int Npad, int N, const double *y, hipStream_t s, int batch, size_t lstride)
 {
-    hipLaunchKernelGGL(aug_row_kernel, dim3((Npad + 255) / 256, Npad - N), dim3(256), 0, s, L, Npad, N, y);
+    hipLaunchKernelGGL(aug_row_kernel, dim3((Npad + 255) / 256, Npad - N, batch), dim3(256), 0, s, L, Npad, N, y, lstride);
     return (int)hipGetLastError();
 }
 
-int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s)
+int launch_nlml_reduce(const double *L, int Npad, int N, double *out2, hipStream_t s, int batch, size_t lstride)
 {
-    hipLaunchKernelGGL(nlml_reduce_kernel, dim3(1), dim3(256), 0, s, L, Npad, N, out2);
+    hipLaunchKernelGGL(nlml_reduce_kernel, dim3(batch), dim3(256), 0, s, L, Npad, N, out2, lstride);
     return (int)hipGetLastError();
 }
 
