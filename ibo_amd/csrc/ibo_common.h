@@ -227,6 +227,7 @@ void set_chol_update2(int v);
 void set_chol_update2_min_tiles(int v);
 void set_trinv_wide(int v);
 void set_step_split(int v);
+void set_chol_pipe(int v);
 void set_chol_panel_rows(int v);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
 // Ework (identity on entry) / Eout, optional: W = L^-1 rides along -- Eout receives (L^-1)^T, blocks on and above the diagonal

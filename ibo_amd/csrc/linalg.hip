@@ -918,6 +918,137 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // Plain right-looking order with one fused launch per block column (chol_step_kernel): `work` holds the matrix
 // and is destroyed, the factor (lower blocks; the strict upper blocks are not touched) goes to `out`.
 // Bit-identical to launch_cholesky with panel = 1.
+// SOFTWARE-PIPELINED block columns (the fit path up to 2048 rows).  Launch jb holds
+//   * the ROW workgroups of block column jb -- the matrix's row blocks jb + 1 .. and, with the ride-along, E's row blocks
+//     0 .. jb: each first applies step jb - 1 to the two tiles it needs (its own block of column jb and the diagonal block:
+//     C - X_i X_jb^T and C - X_jb X_jb^T with the row blocks X(jb - 1) the previous launch stored), then runs the chain on the
+//     diagonal block and multiplies its block by inv(L_jj)^T -- chol_diag_trsm_kernel behind two products;
+//   * the TILE workgroups with the rest of step jb - 1: tiles (i, k), k > jb, of the matrix and of E, one product each,
+//     chol_update_step_kernel's body.  They touch nothing the row workgroups read or write in this launch.
+// So the trailing update of a step runs BESIDE the next step's chain instead of before it: a step costs max(chain + three
+// products, tiles) instead of their sum (25 -> 17 us at N = 2048).  With 133 KB of LDS every workgroup has a CU to itself, so
+// no tile's MFMAs share a SIMD with a chain (which would slow the chain several times over, DESIGN s9).  Each tile still
+// receives the updates of steps 0, 1, .. in that order with the same operands: identical bits (tested).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npad, int jb, double *__restrict__ diag64, int *info,
+                      int nrow, double *__restrict__ Ework, double *__restrict__ Eout)
+{
+    __shared__ double S[64 * SD];
+    __shared__ double V[64 * SD];
+    __shared__ double T[64 * SD];
+    __shared__ double U[64 * SD];
+    TILE_IDS;
+    const int nb = Npad / 64, m = nb - jb - 1, jp = jb - 1;
+    if ((int)blockIdx.x >= nrow) {
+        // ---- a tile of step jp right of column jb
+        const int t = blockIdx.x - nrow, nchol = m * (m + 1) / 2;
+        int i, k;
+        const double *Xi;
+        double *C;
+        if (t < nchol) {
+            k = jb + 1;
+            int rem = t;
+            while (rem >= nb - k) { rem -= nb - k; k++; }
+            i = k + rem;
+            Xi = Lout + (size_t)i * 64 * Npad + jp * 64;
+            C = A + (size_t)i * 64 * Npad + k * 64;
+        } else {
+            const int e = t - nchol;
+            i = e / m; k = jb + 1 + e % m;
+            Xi = Eout + (size_t)i * 64 * Npad + jp * 64;
+            C = Ework + (size_t)i * 64 * Npad + k * 64;
+        }
+        const double *Xk = Lout + (size_t)k * 64 * Npad + jp * 64;
+        d2_t va[8], vb[8];
+        tile64_fetch(Xi, Npad, va);
+        tile64_fetch(Xk, Npad, vb);
+        d4_t acc[2][2];
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[mm][n][r] = C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)];
+        tile64_stash<true, SD>(S, va);
+        tile64_stash<false, SD>(V, vb);
+        __syncthreads();
+        tile64_mma_nt<SD>(S, V, acc);
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) C[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] = acc[mm][n][r];
+        return;
+    }
+    // ---- a row block of block column jb
+    const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
+    const int nE = Ework ? jb + 1 : 0;
+    const bool has_row = (int)blockIdx.x < m + nE;              // (a last column without ride-along: the diagonal block alone)
+    const bool erow = (int)blockIdx.x >= m;
+    const int ib = erow ? (int)blockIdx.x - m : jb + 1 + (int)blockIdx.x;
+    const size_t roff = (size_t)ib * 64 * Npad + jb * 64;
+    const bool upd_d = jb > 0, upd_a = jb > 0 && has_row && !(erow && ib == jb);     // E's block (jb, jb) is still the identity
+    d4_t ad[2][2], aa[2][2];
+    d2_t vxd[8], vxi[8];
+    {
+        const double *Dp = A + doff, *Ap = (erow ? Ework : A) + roff;
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    ad[mm][n][r] = Dp[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)];
+                    aa[mm][n][r] = has_row ? Ap[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL(n)] : 0.0;
+                }
+    }
+    if (upd_d) {
+        tile64_fetch(Lout + (size_t)jb * 64 * Npad + jp * 64, Npad, vxd);
+        if (upd_a) tile64_fetch((erow ? Eout : Lout) + (size_t)ib * 64 * Npad + jp * 64, Npad, vxi);
+        tile64_stash<false, SD>(V, vxd);
+        tile64_stash<true, SD>(T, vxd);
+        if (upd_a) tile64_stash<true, SD>(U, vxi);
+        __syncthreads();
+        tile64_mma_nt<SD>(T, V, ad);
+        if (upd_a) tile64_mma_nt<SD>(U, V, aa);
+        __syncthreads();
+    }
+    // the diagonal block into the chain's layout (diag64_stash), this workgroup's block into U
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                S[TILE_ROW(mm, r) * SD + TILE_COL(n)] = ad[mm][n][r];
+                V[TILE_ROW(mm, r) * SD + TILE_COL(n)] = 0.0;
+                U[TILE_ROW(mm, r) * SD + TILE_COL(n)] = aa[mm][n][r];
+            }
+    __syncthreads();                                            // T's old contents (-X_jb) are done with
+    {
+        const int t = threadIdx.x;
+        T[(t >> 4) * SD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
+    if (blockIdx.x == 0) diag64_store(Lout + doff, Npad, diag64 + (size_t)jb * 4096, S, V);
+    __syncthreads();
+    if (!has_row) return;
+    d4_t acc[2][2] = {};
+    tile64_mma_nt_tri<SD>(U, V, acc);
+    double *Ob = (erow ? Eout : Lout) + roff;
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL_TRI(n)] = acc[mm][n][r];
+}
+
+static int g_chol_pipe = 1;         // ibo_set_option("chol_pipe", 0/1)
+void set_chol_pipe(int v) { g_chol_pipe = v; }
+
 static int g_step_split = 256;      // ibo_set_option("step_split"): tiles of a block column from which rows and updates are separate launches
 void set_step_split(int v) { g_step_split = v; }
 
@@ -927,6 +1058,17 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
     const int nb = Npad / 64;
     const int CU = 256, MAXT = 2 * CU;                  // tiles one fused launch takes: two per workgroup
     if (!info_is_zero) HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    // (from ~1300 rows: below, a step has so few tiles that the fused step's shorter critical path wins by 1-2 %)
+    if (g_chol_pipe && (nb >= 20 || g_chol_pipe > 1)) {
+        for (int jb = 0; jb < nb; jb++) {
+            const int m = nb - jb - 1, nE = Ework ? jb + 1 : 0;
+            const int nrow = m + nE > 0 ? m + nE : 1;
+            const int ntile = jb > 0 ? m * (m + 1) / 2 + (Ework ? jb * m : 0) : 0;        // step jb - 1 right of column jb
+            hipLaunchKernelGGL(chol_pipe_kernel, dim3(nrow + ntile), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
+                               Ework, Eout);
+        }
+        return (int)hipGetLastError();
+    }
     for (int jb = 0; jb < nb; jb++) {
         const int m = nb - jb - 1, nchol = m * (m + 1) / 2;
         const int nextra = (Ework && m > 0) ? (jb + 1) * m : 0;       // tiles of the W = L^-1 ride-along (chol_step_kernel)

@@ -88,7 +88,8 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * 4 two-level); "nlml_batch" B forces the matrices per batched factorisation in ibo_nlml_grid.
  * A/B switches of the fit path, every setting giving the same bits: "chol_fused" (one launch per block column up to
  * 2048 rows), "chol_fused2" (the same inside the panels of the two-level order beyond), "chol_ride" (W = L^-1 formed during
- * the factorisation), "step_split" T (block columns with more than T tiles: row blocks and updates as two launches; 256),
+ * the factorisation), "chol_pipe" (software-pipelined block columns from ~1300 rows), "step_split" T (without it: block columns with more
+ * than T tiles as two launches, row blocks then updates; 256),
  * "trinv_wide" (eight-wave tiles in the small levels of the triangular inversion), "update2_min_tiles", "fused2_min_nb".
  * Env IBO_SWEEP_IMPL=gemv|mfma too. */
 int         ibo_set_option(const char *key, int value);

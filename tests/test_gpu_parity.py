@@ -1025,23 +1025,24 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
 
 
 def test_split_steps_equal_fused_steps(ibo):
-    """fits of up to 2048 rows: a block column with more tiles than CUs (ride-along included) runs as two launches -- row blocks
-    with the chain, then one product per tile -- instead of a fused step with two tiles per workgroup: same arithmetic, same
-    bits in L and W; and the same L as the three-kernel sequence in place"""
+    """fits of up to 2048 rows: software-pipelined block columns (a launch holds column j's row blocks and the rest of step
+    j - 1's tiles), block columns as two launches (row blocks with the chain, then one product per tile), fused steps with two
+    tiles per workgroup: same arithmetic, same bits in L and W; and the same L as the three-kernel sequence in place; a
+    failed pivot is reported from each"""
     from ibo_amd import _lib
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
     for N in (1500, 2048, 1985):
         X, Y = synth(N + 2, N, 4)
         res = []
-        for split in (256, 1 << 30, 64):
-            _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
+        for pipe, split in ((1, 256), (0, 256), (0, 1 << 30), (0, 64)):      # software-pipelined columns (the default from ~1300 rows); split / fused steps
+            _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
             try:
                 GP = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05)
                 W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
                 res.append((GP.L.copy(), W))
             finally:
-                _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
+                _lib.check(_lib.lib.ibo_set_option(b"step_split", 256)); _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
         for L, W in res[1:]:
             assert np.array_equal(L, res[0][0]) and np.array_equal(W, res[0][1])
         _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 0))
@@ -1056,21 +1057,27 @@ def test_split_steps_equal_fused_steps(ibo):
     from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
     X, Y = synth(1603, 1600, 3)
     out = []
-    for split in (256, 1 << 30):
-        _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
+    for pipe, split in ((1, 256), (0, 256), (0, 1 << 30)):
+        _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
         try:
             out.append(marginalLikelihood(GaussianKernel_ard([.3, .4, .5]), X, Y, 3, True, noise=1e-2))
         finally:
-            _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
-    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+            _lib.check(_lib.lib.ibo_set_option(b"step_split", 256)); _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
+    for o in out[1:]:
+        assert out[0][0] == o[0] and np.array_equal(out[0][1], o[1])
     ov, od = orc.marginal_likelihood(orc.Kern("ard", [.3, .4, .5]), X, Y, 3, True, 1e-2)
     close(out[0][0], ov); close(out[0][1], od, atol=1e-8)
     # a failed pivot in a split step (an early and a late block column) is reported like anywhere else
     from ibo_amd import NotPositiveDefinite
-    for dup in (40, 1590):
-        Xd = X.copy(); Xd[dup + 5] = Xd[dup]
-        with pytest.raises(NotPositiveDefinite):
-            GaussianProcess(GaussianKernel_ard([.3, .4, .5]), Xd, Y, noise=0.0)
+    for pipe in (1, 0):
+        _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe))
+        try:
+            for dup in (40, 1590):
+                Xd = X.copy(); Xd[dup + 5] = Xd[dup]
+                with pytest.raises(NotPositiveDefinite):
+                    GaussianProcess(GaussianKernel_ard([.3, .4, .5]), Xd, Y, noise=0.0)
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
 
 
 def test_cholesky_panel_orders_agree(ibo):
