@@ -1011,7 +1011,7 @@ void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npa
         if (upd_a) tile64_stash<true, SD>(U, vxi);
         __syncthreads();
         tile64_mma_nt<SD>(T, V, ad);
-        if (upd_a) tile64_mma_nt<SD>(U, V, aa);
+        if (upd_a) tile64_mma_nt<SD>(U, V, aa);             // (the two interleaved, B fragments shared: 1 % slower)
         __syncthreads();
     }
     // the diagonal block into the chain's layout (diag64_stash), this workgroup's block into U
