@@ -931,8 +931,9 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // receives the updates of steps 0, 1, .. in that order with the same operands: identical bits (tested).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npad, int jb, double *__restrict__ diag64, int *info,
-                      int nrow, double *__restrict__ Ework, double *__restrict__ Eout)
-{
+                      int nrow, double *__restrict__ Ework, double *__restrict__ Eout, int kend, int pre)
+{   // kend: the matrix's tiles of step jb - 1 stop before block column kend (the two-level order's panel end; nb otherwise);
+    // pre = 0: column jb is up to date already (first column of the matrix or of a panel): no step jb - 1 to apply
     __shared__ double S[64 * SD];
     __shared__ double V[64 * SD];
     __shared__ double T[64 * SD];
@@ -941,7 +942,9 @@ void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npa
     const int nb = Npad / 64, m = nb - jb - 1, jp = jb - 1;
     if ((int)blockIdx.x >= nrow) {
         // ---- a tile of step jp right of column jb
-        const int t = blockIdx.x - nrow, nchol = m * (m + 1) / 2;
+        int nchol = 0;
+        for (int kk = jb + 1; kk < kend; kk++) nchol += nb - kk;
+        const int t = blockIdx.x - nrow;
         int i, k;
         const double *Xi;
         double *C;
@@ -988,7 +991,7 @@ void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npa
     const bool erow = (int)blockIdx.x >= m;
     const int ib = erow ? (int)blockIdx.x - m : jb + 1 + (int)blockIdx.x;
     const size_t roff = (size_t)ib * 64 * Npad + jb * 64;
-    const bool upd_d = jb > 0, upd_a = jb > 0 && has_row && !(erow && ib == jb);     // E's block (jb, jb) is still the identity
+    const bool upd_d = pre != 0, upd_a = pre != 0 && has_row && !(erow && ib == jb);     // E's block (jb, jb) is still the identity
     d4_t ad[2][2], aa[2][2];
     d2_t vxd[8], vxi[8];
     {
@@ -1065,7 +1068,7 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
             const int nrow = m + nE > 0 ? m + nE : 1;
             const int ntile = jb > 0 ? m * (m + 1) / 2 + (Ework ? jb * m : 0) : 0;        // step jb - 1 right of column jb
             hipLaunchKernelGGL(chol_pipe_kernel, dim3(nrow + ntile), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
-                               Ework, Eout);
+                               Ework, Eout, nb, jb > 0 ? 1 : 0);
         }
         return (int)hipGetLastError();
     }
@@ -1124,6 +1127,8 @@ int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, 
     if (!info_is_zero) HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     for (int p0 = 0; p0 < nb; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
+        // (the in-panel columns pipelined like the fused route's -- chol_pipe_kernel with kend = pend -- measured 2 % slower:
+        // <= 189 tiles per column, where the fused step's shorter critical path wins, as below 1300 rows)
         for (int jb = p0; jb < pend; jb++) {
             int nt = 0;
             for (int k = jb + 1; k < pend; k++) nt += nb - k;
