@@ -165,7 +165,9 @@ def self_launch(ngpus, argv, timeout_s=3000.0, script=None):
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=port, IBO_COMM_ID_FILE=os.path.join(rdv, "rccl_id"),
                        IBO_BENCH_CHILD="1")
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            out = subprocess.PIPE if r == 0 else sys.stderr      # only rank 0 owns the JSON line
+            # only rank 0 owns the JSON line; it goes to a file in the private directory, not a pipe: a line longer than the
+            # pipe buffer would block rank 0 in write() while the launcher waits for it to exit
+            out = open(os.path.join(rdv, "rank0.out"), "wb") if r == 0 else sys.stderr
             procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env, stdout=out))
         t0 = time.time()
         status = 0
@@ -194,7 +196,8 @@ def self_launch(ngpus, argv, timeout_s=3000.0, script=None):
                 break
             if pending:
                 time.sleep(0.05)
-        line = procs[0].stdout.read().decode("utf-8", "replace") if procs[0].stdout else ""
+        with open(os.path.join(rdv, "rank0.out"), "rb") as f:
+            line = f.read().decode("utf-8", "replace")
         if status == 0:
             sys.stdout.write(line)
             sys.stdout.flush()
@@ -396,7 +399,7 @@ def worker(args):
         def step():
             r = sweep(GP, cand, acq='ei', xi=.01, native=True, index_base=start)
             if comm is not None:
-                x = cand_host[r["best_idx"] - start]
+                x = cand_host[r["best_idx"] - start] if r["best_idx"] >= 0 else np.zeros(DIM)
                 v, i, _, _ = comm.argmax(r["best_val"], r["best_idx"], x)
                 return v, i, r["kernel_ms"], r["kernel"]
             return r["best_val"], r["best_idx"], r["kernel_ms"], r["kernel"]

@@ -64,6 +64,7 @@ _sig("ibo_dev_free", c_int, c_int, c_void_p)
 _sig("ibo_memcpy_h2d", c_int, c_int, c_void_p, c_void_p, c_size_t)
 _sig("ibo_memcpy_d2h", c_int, c_int, c_void_p, c_void_p, c_size_t)
 _sig("ibo_device_synchronize", c_int, c_int)
+_sig("ibo_dev_generation", c_int, c_int, c_void_p, POINTER(ctypes.c_uint64))
 _sig("ibo_gp_create", c_int, c_int, POINTER(c_void_p))
 _sig("ibo_gp_destroy", c_int, c_void_p)
 _sig("ibo_gp_fit", c_int, c_void_p, c_int, c_int, c_int, _DP, _DP, _DP, c_int, c_double, c_double, POINTER(c_int))
@@ -114,7 +115,7 @@ _sig("logCDFs", c_double, c_int, POINTER(c_int), _DP)
 
 EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device_name", "ibo_selftest_mfma",
             "ibo_set_option", "ibo_trim", "ibo_dev_alloc", "ibo_dev_free", "ibo_memcpy_h2d", "ibo_memcpy_d2h",
-            "ibo_device_synchronize", "ibo_gp_create", "ibo_gp_destroy", "ibo_gp_fit", "ibo_gp_fit_with_matrix",
+            "ibo_device_synchronize", "ibo_dev_generation", "ibo_gp_create", "ibo_gp_destroy", "ibo_gp_fit", "ibo_gp_fit_with_matrix",
             "ibo_gp_extend", "ibo_gp_reserve", "ibo_pref_begin", "ibo_pref_rinv_mul", "ibo_pref_newton_step", "ibo_pref_finish", "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
             "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_spd_solve", "ibo_spd_inverse", "ibo_posterior_batch",
             "ibo_acq_sweep", "ibo_acq_batch", "ibo_acq_sweep_incremental", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_host", "ibo_nlml_grid", "ibo_nlml_grad",
@@ -171,6 +172,21 @@ class DeviceArray(object):
         d = cls(a.shape, device)
         check(lib.ibo_memcpy_h2d(d.device, d.ptr, a.ctypes.data_as(c_void_p), d.nbytes))
         return d
+
+    def generation(self):
+        """the library's generation of this allocation (changes with every upload into it; 0 once freed)"""
+        if self.ptr is None:
+            return 0
+        g = ctypes.c_uint64()
+        check(lib.ibo_dev_generation(self.device, self.ptr, ctypes.byref(g)))
+        return g.value
+
+    def upload(self, a):
+        """overwrite the array's contents from host memory (a new generation: kept sweep state is dropped)"""
+        a = f64(a)
+        if a.size * 8 != self.nbytes:
+            raise ValueError("shape mismatch")
+        check(lib.ibo_memcpy_h2d(self.device, self.ptr, a.ctypes.data_as(c_void_p), self.nbytes))
 
     def to_host(self):
         out = np.empty(self.shape, dtype=np.float64)

@@ -178,13 +178,16 @@ def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None,
     outputs      any of 'mu', 's2', 'acq': per-candidate arrays to return (host ndarrays)
     incremental  keep the per-candidate state of THIS DeviceArray on the model's handle and, when the model has only
                  grown through addData since the last such call, fold the new rows in instead of sweeping again
-                 (fastUCBGallery's rounds); the array's contents must not change between calls
+                 (fastUCBGallery's rounds).  Honoured for a caller-owned DeviceArray only (an ndarray is uploaded to a
+                 temporary and swept in full); the state is keyed on the array's generation (_lib.DeviceArray.generation),
+                 so a freed-and-reallocated or re-uploaded array is swept in full again
     Returns dict(best_val, best_idx, kernel_ms, [mu], [s2], [acq]); first maximiser wins ties.
     """
     if isinstance(candidates, _lib.DeviceArray):
         cand = candidates
     else:
         cand = _lib.DeviceArray.from_host(np.atleast_2d(candidates), model._dev.device)
+        incremental = False
     M = cand.shape[0]
     code = _ACQ[acq]
     if parm is None:

@@ -231,7 +231,7 @@ struct ibo_gp {
     // kept sweep state (ibo_acq_sweep_incremental): (q, aY.k*, a1.k*) per candidate of ONE device candidate array
     DevBuf<double> state;
     DevBuf<double> small_ws;        // small2.hip: k* in fragment order + partial sums of a small batch
-    const double *st_cand = nullptr; int64_t st_M = 0; int st_N = 0; double st_sf2 = 0.0; unsigned st_epoch = 0;
+    uint64_t st_gen = 0; size_t st_off = 0; int64_t st_M = 0; int st_N = 0; double st_sf2 = 0.0; unsigned st_epoch = 0;   // st_gen: generation of the candidate array's allocation (0: no state)
     unsigned fit_epoch = 0;         // bumped by every full fit: a kept state never survives one
     int reserve = 0;                // rows of head-room the next fit leaves for ibo_gp_extend (ibo_gp_reserve)
     DevBuf<int> info;
@@ -319,23 +319,67 @@ extern "C" int ibo_selftest_mfma(int device, double *max_abs_err)
 }
 
 // ------------------------------------------------------------------------ device memory
+// Every allocation handed out by ibo_dev_alloc carries a GENERATION: a process-wide counter value taken when it is
+// allocated and again whenever ibo_memcpy_h2d writes into it.  hipFree / hipMalloc routinely hand the same address to
+// the next array of the same size, so state that is kept "per candidate array" (ibo_acq_sweep_incremental) is keyed
+// on the generation, never on the raw pointer: a freed-and-reallocated or overwritten array can not be mistaken for
+// the one the state was formed from.  Memory the library did not allocate has no generation (0) and never qualifies.
+struct DevAlloc { char *base; size_t bytes; int device; uint64_t gen; };
+static std::vector<DevAlloc> g_allocs;
+static uint64_t g_gen_counter = 0;
+static std::mutex g_alloc_mu;
+
+// generation of the allocation that contains [p, p + bytes) on `device`, 0 if none; *offset = p - base
+static uint64_t alloc_generation(int device, const void *p, size_t bytes, size_t *offset)
+{
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    const char *c = (const char *)p;
+    for (const DevAlloc &a : g_allocs)
+        if (a.device == device && c >= a.base && c + bytes <= a.base + a.bytes) {
+            if (offset) *offset = (size_t)(c - a.base);
+            return a.gen;
+        }
+    return 0;
+}
+
 extern "C" int ibo_dev_alloc(int device, size_t bytes, void **dev_ptr)
 {
     if (!dev_ptr) return fail(IBO_ERR_ARG, "dev_ptr is NULL");
     IBO_TRY(use_device(device));
     HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 8));
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_allocs.push_back({(char *)*dev_ptr, bytes ? bytes : 8, device, ++g_gen_counter});
     return IBO_OK;
 }
 extern "C" int ibo_dev_free(int device, void *dev_ptr)
 {
     IBO_TRY(use_device(device));
-    if (dev_ptr) HIP_TRY(hipFree(dev_ptr));
+    if (dev_ptr) {
+        {
+            std::lock_guard<std::mutex> lk(g_alloc_mu);
+            for (size_t i = 0; i < g_allocs.size(); i++)
+                if (g_allocs[i].base == (char *)dev_ptr && g_allocs[i].device == device) { g_allocs.erase(g_allocs.begin() + i); break; }
+        }
+        HIP_TRY(hipFree(dev_ptr));
+    }
     return IBO_OK;
 }
 extern "C" int ibo_memcpy_h2d(int device, void *dev_dst, const void *host_src, size_t bytes)
 {
     IBO_TRY(use_device(device));
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);       // new contents: a new generation for the allocation written into
+        const char *c = (const char *)dev_dst;
+        for (DevAlloc &a : g_allocs)
+            if (a.device == device && c < a.base + a.bytes && c + bytes > a.base) a.gen = ++g_gen_counter;
+    }
     HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return IBO_OK;
+}
+extern "C" int ibo_dev_generation(int device, const void *dev_ptr, uint64_t *generation)
+{
+    if (!generation) return fail(IBO_ERR_ARG, "generation is NULL");
+    *generation = alloc_generation(device, dev_ptr, 1, nullptr);
     return IBO_OK;
 }
 extern "C" int ibo_memcpy_d2h(int device, void *host_dst, const void *dev_src, size_t bytes)
@@ -601,6 +645,9 @@ extern "C" int ibo_gp_extend(ibo_gp_t *g, int n, const double *Xnew, const doubl
     HIP_TRY(hipMemcpyAsync(g->Xp.p + (size_t)N0 * DP, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(g->info.p, 0, sizeof(int), s));
     HIP_TRY(hipEventRecord(g->fit0, s));
+    // from here on the handle's rows are being rewritten: any early return (a HIP or launch error) must leave it marked
+    // unfitted -- the caller then refits -- rather than "fitted" with rows N0.. of L / W / Wp half-written
+    g->fitted = false;
     for (int i = 0; i < n; i++) {
         const int N = N0 + i;                       // rows present before this point
         // k = K(X, x_new) (also the new row / column of R), z = W k and u = W^T z, then the new rows of L and W
@@ -638,6 +685,7 @@ extern "C" int ibo_gp_extend(ibo_gp_t *g, int n, const double *Xnew, const doubl
     g->N = N1; g->maxY = my;
     g->Yhost.assign(Yall, Yall + N1);
     g->L_upper_dirty = true;
+    g->fitted = true;
     return IBO_OK;
 }
 
@@ -708,6 +756,7 @@ extern "C" int ibo_gp_set_y(ibo_gp_t *g, const double *Y_host)
         if (Y_host[i] > my) my = Y_host[i];
     }
     g->maxY = my;
+    g->st_gen = 0;                                  // the kept per-candidate means were formed with the old alpha vectors
     HIP_TRY(hipMemcpyAsync(g->Y.p, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
     KERNEL_TRY(launch_alpha(g->W.p, g->N, g->Npad, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1108,7 +1157,11 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         if (incremental) {
             // the state of this candidate array is kept on the handle; if the model has only grown by a few rows
             // (ibo_gp_extend) since it was formed, those rows are folded in -- O(N) per candidate, not O(N^2)
-            const bool usable = g->st_cand == cand_dev && g->st_M == M && g->st_epoch == g->fit_epoch && g->st_sf2 == g->kp.sf2 &&
+            // (keyed on the array's GENERATION, not its address: see ibo_dev_alloc.  An array the library did not allocate
+            // has none, and is swept in full every time)
+            size_t off = 0;
+            const uint64_t gen = alloc_generation(g->device, cand_dev, sizeof(double) * (size_t)M * g->D, &off);
+            const bool usable = gen != 0 && g->st_gen == gen && g->st_off == off && g->st_M == M && g->st_epoch == g->fit_epoch && g->st_sf2 == g->kp.sf2 &&
                                 g->st_N >= 1 && g->st_N <= g->N && g->N - g->st_N <= 8 && g->state.cap >= 3 * (size_t)M &&
                                 sweep2_rank1_fits(a.Npad, a.kp.D);
             IBO_TRY(g->state.ensure(3 * (size_t)M));
@@ -1120,7 +1173,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
                 KERNEL_TRY(launch_sweep2(a, s, g->ev0, g->ev1));
                 g->sweep_kernel = "sweep2_kernel";
             }
-            g->st_cand = cand_dev; g->st_M = M; g->st_N = g->N; g->st_sf2 = g->kp.sf2; g->st_epoch = g->fit_epoch;
+            g->st_gen = gen; g->st_off = off; g->st_M = M; g->st_N = g->N; g->st_sf2 = g->kp.sf2; g->st_epoch = g->fit_epoch;
         } else {
             IBO_TRY(g->qpart.ensure(3 * (size_t)M));    // (q, aY.k*, a1.k*) per candidate, finished by acq_finish_kernel
             a.qpart = g->qpart.p;

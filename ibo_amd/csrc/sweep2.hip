@@ -453,11 +453,13 @@ static int launch_s2_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     const int na128 = (a.Npad + 127) & ~127;
     const int dyn = (BIGN ? s2_awin(KA4) : na128) * 16;
-    static int granted = 0;                          // per instantiation: largest dynamic size already allowed
-    if (dyn > granted) {
+    static int granted[16];                          // per instantiation AND device (the attribute is per device): largest dynamic size already allowed
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dyn > granted[dev & 15]) {
         hipError_t e = hipFuncSetAttribute((const void *)sweep2_kernel<FAM, KA4, BIGN>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
         if (e != hipSuccess) return (int)e;
-        granted = dyn;
+        granted[dev & 15] = dyn;
     }
     hipLaunchKernelGGL((sweep2_kernel<FAM, KA4, BIGN>), dim3((unsigned)ntiles), dim3(S2_NW * 64), dyn, s, a);
     return (int)hipGetLastError();
@@ -472,11 +474,13 @@ template <int FAM, int KA4>
 static int launch_s2_rank1_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     const int dyn = ((a.Npad + 127) & ~127) * 24;
-    static int granted = 0;
-    if (dyn > granted) {
+    static int granted[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dyn > granted[dev & 15]) {
         hipError_t e = hipFuncSetAttribute((const void *)sweep2_rank1_kernel<FAM, KA4>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
         if (e != hipSuccess) return (int)e;
-        granted = dyn;
+        granted[dev & 15] = dyn;
     }
     hipLaunchKernelGGL((sweep2_rank1_kernel<FAM, KA4>), dim3((unsigned)ntiles), dim3(S2_NW * 64), dyn, s, a);
     return (int)hipGetLastError();

@@ -50,6 +50,52 @@ def _box(lo, hi, d):
     return np.array([[lo, hi]] * d, dtype=float)
 
 
+# --------------------------------------------------------------------------- one-dimensional curves (testfunctions.py:74-124)
+class _Curve(TestFunction):
+    """a function of the first coordinate only"""
+    hp = None
+
+    def __init__(self, name, minimum, argmin, lo, hi, **kwargs):
+        super(_Curve, self).__init__(name, minimum, argmin, _box(lo, hi, 1), **kwargs)
+        self.defaultHP = {GaussianKernel_iso: [self.hp[0], 1], GaussianKernel_ard: [self.hp[1], 1], MaternKernel3: [self.hp[2], 1]}
+
+
+class Poly4(_Curve):
+    """|x^3 + x^2 + x| / 100 on [-10, 10] (named "4th-order" in the reference; the cubic is what it evaluates)"""
+    hp = (1.620, 1.628, 4.635)
+
+    def __init__(self, **kwargs):
+        super(Poly4, self).__init__("4th-order poly", 0, [0], -10., 10., **kwargs)
+
+    def _cost(self, X):
+        t = X[:, 0]
+        return np.abs(t ** 3 + t ** 2 + t) / 100.0
+
+
+class Poly6(_Curve):
+    """Goldstein's sixth-order polynomial ((x^2 - 15) x^2 + 27) x^2 + 250, over 100, on [-4, 4]"""
+    hp = (0.285, 0.287, 0.678)
+
+    def __init__(self, **kwargs):
+        super(Poly6, self).__init__("Goldstein 6th-order", 0.07, [0], -4., 4., **kwargs)
+
+    def _cost(self, X):
+        q = X[:, 0] ** 2
+        return (((q - 15) * q + 27) * q + 250) / 100
+
+
+class Schubert1(_Curve):
+    """sum_{i=1..5} i cos((i + 1) x + i) on [-1, 1]"""
+    hp = (0.192, 0.192, 0.279)
+
+    def __init__(self, **kwargs):
+        super(Schubert1, self).__init__("Schubert", -8.5178, [-0.195], -1., 1., **kwargs)
+
+    def _cost(self, X):
+        i = np.arange(1, 6)
+        return np.sum(i * np.cos((i + 1) * X[:, :1] + i), axis=1)
+
+
 # --------------------------------------------------------------------------- Shekel family (testfunctions.py:150-207)
 _SHEKEL_A = np.array([[4, 4, 4, 4], [1, 1, 1, 1], [8, 8, 8, 8], [6, 6, 6, 6], [3, 7, 3, 7], [2, 9, 2, 9],
                       [5, 5, 3, 3], [8, 1, 8, 1], [6, 2, 6, 2], [7, 3.6, 7, 3.6]], dtype=float)
@@ -177,13 +223,85 @@ class Sphere(TestFunction):
         return np.sum(X * X, axis=1)
 
 
-class SumSquares(TestFunction):
+class _IsoOnly(TestFunction):
+    """d-dimensional functions whose only tuned hyper-parameter is an isotropic length scale per dimension count"""
+    iso_by_d = {}
+
+    def createKernel(self, Kernel):
+        if Kernel == GaussianKernel_iso and self.d in self.iso_by_d:
+            return Kernel(np.array([self.iso_by_d[self.d]]))
+        raise ValueError('test function %s has no default values for kernel %s' % (self.name, Kernel.__name__))
+
+
+class SumSquares(_IsoOnly):
+    """sum_i i x_i^2 on [-10, 10]^d (:399-420)"""
+    iso_by_d = {2: 2.42, 4: 5.3, 8: 0.5}
+
     def __init__(self, d=4, **kwargs):
-        super(SumSquares, self).__init__("Sum Squares %d" % d, 0, np.zeros(d), _box(-10., 10., d), **kwargs)
+        super(SumSquares, self).__init__("SumSquares %d" % d, 0, np.zeros(d), _box(-10., 10., d), **kwargs)
         self.d = d
 
     def _cost(self, X):
         return np.sum(np.arange(1, X.shape[1] + 1) * X * X, axis=1)
+
+
+class Levy(_IsoOnly):
+    """d-dimensional Levy function as the reference writes it (:308-334; with z = 1 + (x - 1) / 4:
+    sin^2(pi z_1) + sum_{i<d} (z_i - 1)^2 (1 + 10 sin^2(pi z_i + 1)) + (z_d - 1)^2 (1 + sin^2(2 pi z_d))).
+    The reference's constructor reads an undefined name and cannot run (:314); this one stores d as it meant to."""
+    iso_by_d = {2: 0.9, 4: 2.8}
+
+    def __init__(self, d=2, **kwargs):
+        super(Levy, self).__init__("Levy %d" % d, 0, np.ones(d), _box(-10., 10., d), **kwargs)
+        self.d = d
+
+    def _cost(self, X):
+        z = 1 + (X - 1) / 4.0
+        head, last = z[:, :-1], z[:, -1]
+        s = np.sin(np.pi * z[:, 0]) ** 2 + np.sum((head - 1) ** 2 * (1 + 10 * np.sin(np.pi * head + 1) ** 2), axis=1)
+        return s + (last - 1) ** 2 * (1 + np.sin(2 * np.pi * last) ** 2)
+
+
+class Michalewics(_IsoOnly):
+    """-sum_i sin(x_i) sin(i x_i^2 / pi)^20 on [0, pi]^d, d in {2, 5, 10} (:337-362)"""
+    iso_by_d = {2: 0.28, 5: 0.68, 10: 1.36}
+    _known = {2: (-1.8014, np.array([2.2029, 1.5708])), 5: (-4.687658, None), 10: (-9.66015, None)}
+
+    def __init__(self, d=2, **kwargs):
+        assert d in self._known
+        self.d = d
+        super(Michalewics, self).__init__("Michalewics %d" % d, self._known[d][0], self._known[d][1], _box(0., np.pi, d), **kwargs)
+
+    def _cost(self, X):
+        return -np.sum(np.sin(X) * np.sin(np.arange(1, self.d + 1) * X ** 2 / np.pi) ** 20, axis=1)
+
+
+class Perm(TestFunction):
+    """sum_{k=1..d} (sum_j (j^k + beta) ((x_j / j)^k - 1))^2 on [-d-1, d+1]^d, minimum 0 at (1, .., d) (:365-381)"""
+
+    def __init__(self, d=4, beta=0.5, **kwargs):
+        super(Perm, self).__init__("Perm %d" % d, 0, np.arange(1, d + 1), _box(-d - 1., d + 1., d), **kwargs)
+        self.beta = beta
+        self.d = d
+
+    def _cost(self, X):
+        j = np.arange(1, self.d + 1, dtype=float)
+        k = j[:, None]                                               # (k, j) tables, one row per power
+        inner = np.sum((j[None, :] ** k + self.beta) * ((X[:, None, :] / j) ** k - 1), axis=2)
+        return np.sum(inner ** 2, axis=1)
+
+
+class Zakharov(TestFunction):
+    """|x|^2 + a^2 + a^4 with a = sum_i i x_i / 2 on [-5, 10]^d (:425-440)"""
+
+    def __init__(self, d=2, **kwargs):
+        super(Zakharov, self).__init__("Zakharov %d" % d, 0, np.zeros(d), _box(-5., 10., d), **kwargs)
+        self.d = d
+        self.defaultHP = {GaussianKernel_iso: [0.5]}
+
+    def _cost(self, X):
+        a = np.sum(0.5 * np.arange(1, self.d + 1) * X, axis=1)
+        return np.sum(X * X, axis=1) + a ** 2 + a ** 4
 
 
 # --------------------------------------------------------------------------- a random draw from a GP (:470-527)
@@ -240,3 +358,48 @@ def learnHyper(tf, Kernel, seed=None):
     Y = tf.values(X)
     loghyper = fmin_bfgs(nlml, np.log(np.ones(1) * .5), dnlml, args=(Kernel, X, Y), disp=False)
     return np.exp(loghyper)
+
+
+def checkMinimum(testfuncs, samples=100, seed=None):
+    """try to undercut each function's recorded minimum: BFGS from its recorded argmin and `samples` latin-hypercube
+    points (:543-555).  Prints the reference's report and returns [(name, best value found, where)]."""
+    from scipy.optimize import fmin_bfgs
+    found = []
+    for tf in testfuncs:
+        best, where = np.inf, None
+        if tf.argmin is not None:
+            x0 = np.asarray(tf.argmin, dtype=float)
+            x1 = fmin_bfgs(tf.f, x0, disp=False)
+            print('[%s] was told argmin = %s, min = %.2f' % (tf.name, tf.argmin, tf.minimum))
+            print('[%s] check argmin = %s, min = %.2f' % (tf.name, tf.argmin, tf.f(x0)))
+            print('[%s] found argmin = %s, min = %.2f' % (tf.name, x1, tf.f(x1)))
+            best, where = tf.f(x1), x1
+        P = np.array(lhcSample(tf.bounds, samples, seed=seed))
+        v = tf.values(P)
+        for x, y in zip(P, v):
+            if y < tf.minimum:
+                print('sample x = %s, y = %.4f is lower than minimum %.4f' % (x, y, tf.minimum))
+        if v.min() < best:
+            best, where = float(v.min()), P[int(np.argmin(v))]
+        found.append((tf.name, best, where))
+    return found
+
+
+def plot2D(tf, N=50):
+    """filled contour plot of a two-dimensional test function on an (N + 1)^2 grid (:558-577); needs matplotlib"""
+    import matplotlib.pyplot as plt
+    b = np.asarray(tf.bounds, dtype=float)
+    c0 = np.linspace(b[0, 0], b[0, 1], N + 1)
+    c1 = np.linspace(b[1, 0], b[1, 1], N + 1)
+    G0, G1 = np.meshgrid(c0, c1)
+    z = tf.values(np.column_stack([G0.ravel(), G1.ravel()])).reshape(G0.shape)
+    fig = plt.figure(1)
+    fig.clf()
+    ax = fig.add_subplot(111)
+    cs = ax.contourf(c0, c1, z, 50, alpha=0.9, cmap=plt.cm.jet)
+    fig.colorbar(cs)
+    if tf.argmin is not None:
+        ax.plot(tf.argmin[0], tf.argmin[1], 'wo')
+    ax.set_xbound(b[0, 0], b[0, 1])
+    ax.set_ybound(b[1, 0], b[1, 1])
+    return fig

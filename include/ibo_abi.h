@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IBO_ABI_VERSION 3   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_* */
+#define IBO_ABI_VERSION 4   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation */
 
 /* status codes */
 #define IBO_OK              0
@@ -100,6 +100,10 @@ int ibo_dev_free(int device, void *dev_ptr);
 int ibo_memcpy_h2d(int device, void *dev_dst, const void *host_src, size_t bytes);
 int ibo_memcpy_d2h(int device, void *host_dst, const void *dev_src, size_t bytes);
 int ibo_device_synchronize(int device);
+/* Every ibo_dev_alloc allocation carries a generation: a process-wide counter value taken at allocation and again by each
+ * ibo_memcpy_h2d into it (0 for memory this library did not allocate).  State kept per candidate array
+ * (ibo_acq_sweep_incremental) is keyed on it, never on the address, which hipFree / hipMalloc recycle. */
+int ibo_dev_generation(int device, const void *dev_ptr, uint64_t *generation);
 
 /* ---------------------------------------------------------------- model (fit) */
 int ibo_gp_create(int device, ibo_gp_t **out);
@@ -139,7 +143,7 @@ int ibo_gp_fit_with_matrix(ibo_gp_t *gp, int ktype, int N, int D,
  * are updated in place on the device.  Returns IBO_ERR_STATE -- and changes nothing -- when the handle cannot
  * be extended (never fitted, fitted from a caller-supplied matrix or from an inverse, or N + n exceeds the
  * row padding, a multiple of 64): the caller then calls ibo_gp_fit with all the data.  IBO_ERR_NOT_PD as
- * ibo_gp_fit (the handle then needs a refit).
+ * ibo_gp_fit, and any other error, leave the handle UNFITTED (every later call returns IBO_ERR_STATE until a refit).
  */
 int ibo_gp_extend(ibo_gp_t *gp, int n, const double *Xnew_host, const double *Y_all_host, int *info);
 /* head-room: later fits of this handle pad the matrices to a multiple of 64 that leaves at least `rows` free rows, so
@@ -264,8 +268,11 @@ int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
  * candidate on the handle, 24 bytes each.  A later call with the same array, after at most 8 rows were appended and
  * nothing else changed, folds the new rows of W into q -- (w_new . k*)^2, O(N) per candidate instead of O(N^2) --
  * re-forms the means from the current alpha vectors and evaluates the acquisition as usual.  Anything else (other
- * array or size, a refit, another k* variance, batches small enough for the other kernels) is a full sweep.
- * The caller must not change the candidate array's contents between calls.
+ * array or size, a refit, ibo_gp_set_y, another k* variance, batches small enough for the other kernels) is a full sweep.
+ * "The same array" means the same ibo_dev_alloc allocation at the same GENERATION (ibo_dev_generation) and offset: an
+ * array that was freed and reallocated at the same address, or overwritten through ibo_memcpy_h2d, is a different one,
+ * and memory the library did not allocate is swept in full every time.  Contents changed behind the library's back (the
+ * caller's own kernels or hipMemcpy) are the one thing it cannot see.
  */
 int ibo_acq_sweep_incremental(ibo_gp_t *gp, int64_t M, const double *cand_dev,
                               int acq, double parm, int erf_mode, double clamp_lo, double ymax,

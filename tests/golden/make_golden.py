@@ -365,9 +365,57 @@ def g9_lhc():
     save("g9_lhc", **out)
 
 
+# ---------------------------------------------------------------- G10 the analytic test-function zoo
+def g10_testfunctions():
+    """f(x) of every analytic class of ego/utils/testfunctions.py on seeded points inside its bounds, both signs.
+    Levy cannot be constructed in the reference (its __init__ reads an undefined name, testfunctions.py:314): its
+    values are taken from the class's own f with the attribute the constructor meant to set."""
+    import ego.utils.testfunctions as T
+    out = {}
+    names = []
+    cases = [("Poly4", T.Poly4, {}), ("Poly6", T.Poly6, {}), ("Schubert1", T.Schubert1, {}),
+             ("GoldsteinPrice", T.GoldsteinPrice, {}), ("Shekel5", T.Shekel5, {}), ("Shekel7", T.Shekel7, {}),
+             ("Shekel10", T.Shekel10, {}), ("Camelback", T.Camelback, {}), ("Branin", T.Branin, {}),
+             ("Hartman3", T.Hartman3, {}), ("Hartman6", T.Hartman6, {}),
+             ("Michalewics2", T.Michalewics, dict(d=2)), ("Michalewics5", T.Michalewics, dict(d=5)),
+             ("Michalewics10", T.Michalewics, dict(d=10)), ("Perm4", T.Perm, dict(d=4)), ("Perm3", T.Perm, dict(d=3)),
+             ("Sphere4", T.Sphere, dict(d=4)), ("SumSquares4", T.SumSquares, dict(d=4)), ("SumSquares8", T.SumSquares, dict(d=8)),
+             ("Zakharov2", T.Zakharov, dict(d=2)), ("Zakharov5", T.Zakharov, dict(d=5))]
+    rs = np.random.RandomState(1010)
+    for name, cls, kw in cases:
+        tf = cls(maximize=False, **kw)
+        b = np.array(tf.bounds, dtype=float)
+        P = b[:, 0] + (b[:, 1] - b[:, 0]) * rs.rand(24, len(b))
+        out[name + "_x"] = P
+        out[name + "_f"] = np.array([float(tf.f(x)) for x in P])
+        out[name + "_fmax"] = np.array([float(cls(maximize=True, **kw).f(x)) for x in P])
+        out[name + "_bounds"] = b
+        out[name + "_min"] = float(tf.minimum)
+        out[name + "_name"] = np.array(tf.name)
+        names.append(name)
+    for d in (2, 4):                                # Levy: bypass the broken constructor
+        tf = T.Levy.__new__(T.Levy)
+        T.TestFunction.__init__(tf, "Levy %d" % d, 0, np.ones(d), [[-10.0, 10.0]] * d, maximize=False)
+        tf.d = d
+        b = np.array(tf.bounds, dtype=float)
+        P = b[:, 0] + (b[:, 1] - b[:, 0]) * rs.rand(24, d)
+        name = "Levy%d" % d
+        out[name + "_x"] = P
+        out[name + "_f"] = np.array([float(tf.f(x)) for x in P])
+        tf.maximize = True
+        out[name + "_fmax"] = np.array([float(tf.f(x)) for x in P])
+        out[name + "_bounds"] = b
+        out[name + "_min"] = 0.0
+        out[name + "_name"] = np.array("Levy %d" % d)
+        names.append(name)
+    out["names"] = np.array(names)
+    save("g10_testfunctions", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9"]
-    fns = dict(g1=g1_demo, g2=g2_hyper, g3=g3_cases, g4=g4_direct, g6=g6_sweeps, g7=g7_prefs, g8=g8_nlml, g9=g9_lhc)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7", "g8", "g9", "g10"]
+    fns = dict(g1=g1_demo, g2=g2_hyper, g3=g3_cases, g4=g4_direct, g6=g6_sweeps, g7=g7_prefs, g8=g8_nlml, g9=g9_lhc,
+               g10=g10_testfunctions)
     for w in which:
         fns[w]()
     shutil.rmtree(TMP, ignore_errors=True)

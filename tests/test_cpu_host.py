@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), "libibo_hip.so does not export %s" % s
         assert s in _lib.EXPORTED, "%s is declared in ibo_abi.h but not bound in ibo_amd/_lib.py" % s
-    assert _lib.lib.ibo_abi_version() == 3
+    assert _lib.lib.ibo_abi_version() == 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -329,3 +329,44 @@ def test_test_function_zoo_known_minima():
     assert isinstance(tfs.Shekel5().createKernel(GaussianKernel_iso), GaussianKernel_iso)
     with pytest.raises(ValueError):
         tfs.Shekel5().createKernel(MaternKernel3)
+
+
+def test_every_analytic_test_function_against_the_reference_values():
+    """G10: f(x) of all nineteen analytic classes of ego/utils/testfunctions.py (21 + 2 instances) on seeded points,
+    both signs, names and recorded minima, generated from the reference's own classes (make_golden.py g10)"""
+    from ibo_amd.utils import testfunctions as tfs
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_iso, GaussianKernel_ard
+    g = load_golden("g10_testfunctions")
+    made = {"Michalewics2": (tfs.Michalewics, dict(d=2)), "Michalewics5": (tfs.Michalewics, dict(d=5)),
+            "Michalewics10": (tfs.Michalewics, dict(d=10)), "Perm4": (tfs.Perm, dict(d=4)), "Perm3": (tfs.Perm, dict(d=3)),
+            "Sphere4": (tfs.Sphere, dict(d=4)), "SumSquares4": (tfs.SumSquares, dict(d=4)), "SumSquares8": (tfs.SumSquares, dict(d=8)),
+            "Zakharov2": (tfs.Zakharov, dict(d=2)), "Zakharov5": (tfs.Zakharov, dict(d=5)), "Levy2": (tfs.Levy, dict(d=2)),
+            "Levy4": (tfs.Levy, dict(d=4))}
+    assert len(g["names"]) == 23
+    for name in g["names"]:
+        name = str(name)
+        cls, kw = made.get(name, (getattr(tfs, name, None), {}))
+        assert cls is not None, name
+        tf = cls(maximize=False, **kw)
+        X = g[name + "_x"]
+        np.testing.assert_allclose(tf.values(X), g[name + "_f"], rtol=1e-12, atol=1e-13, err_msg=name)
+        np.testing.assert_allclose(cls(**kw).values(X), g[name + "_fmax"], rtol=1e-12, atol=1e-13, err_msg=name)
+        assert abs(tf.f(X[5]) - g[name + "_f"][5]) <= 1e-12 * max(1.0, abs(g[name + "_f"][5]))
+        np.testing.assert_array_equal(np.array(tf.bounds, dtype=float), g[name + "_bounds"])
+        assert tf.name == str(g[name + "_name"]) and float(tf.minimum) == float(g[name + "_min"]), name
+    # the kernels the reference tunes for the new classes (testfunctions.py:78-80, 321-326, 350-355, 409-414, 432)
+    assert tfs.Poly4().createKernel(GaussianKernel_ard).hyperparams[0] == 1.628
+    assert tfs.Levy(4).createKernel(GaussianKernel_iso).hyperparams[0] == 2.8
+    assert tfs.Michalewics(10).createKernel(GaussianKernel_iso).hyperparams[0] == 1.36
+    assert tfs.SumSquares(8).createKernel(GaussianKernel_iso).hyperparams[0] == 0.5
+    assert tfs.Zakharov(3).createKernel(GaussianKernel_iso).hyperparams[0] == 0.5
+    with pytest.raises(ValueError):
+        tfs.Levy(3).createKernel(GaussianKernel_iso)
+    with pytest.raises(ValueError):
+        tfs.SumSquares(4).createKernel(GaussianKernel_ard)
+    # the documented minima
+    assert tfs.Perm(4, maximize=False).f(np.arange(1., 5.)) == 0.0 and tfs.Levy(3, maximize=False).f(np.ones(3)) < 1e-30
+    assert abs(tfs.Michalewics(2, maximize=False).f([2.2029, 1.5708]) + 1.8013) < 1e-3
+    assert abs(tfs.Schubert1(maximize=False).f([-0.195]) + 8.5178) < 2e-3
+    found = tfs.checkMinimum([tfs.Zakharov(2, maximize=False)], samples=20, seed=3)
+    assert found[0][0] == "Zakharov 2" and found[0][1] < 1e-8

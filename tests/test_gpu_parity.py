@@ -520,6 +520,66 @@ def test_incremental_sweep_state_equals_full_sweeps(ibo):
     np.testing.assert_array_equal(g_inc, g_full)
 
 
+def test_incremental_state_cannot_alias_another_array(ibo):
+    """the kept (q, alphaY.k*, alpha1.k*) state is keyed on the candidate array's GENERATION (ibo_dev_generation), not on its
+    address: an array freed and reallocated at the same address, one overwritten in place through ibo_memcpy_h2d,
+    another ndarray of the same shape, and ibo_gp_set_y all force the full sweep -- with the right values"""
+    from ibo_amd import _lib
+    from ibo_amd._lib import DeviceArray
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.acquisition import sweep
+    X, Y = synth(81, 400, 3)
+    kern = K.GaussianKernel_ard([.3, .35, .4])
+    GP = GaussianProcess(kern, X[:390], Y[:390], noise=.1)
+    A = np.random.RandomState(82).rand(9001, 3)
+    B = np.random.RandomState(83).rand(9001, 3)
+
+    def check(r, cand_host):
+        f = sweep(GaussianProcess(kern, GP.X, GP.Y, noise=.1), cand_host, acq='ei', xi=.2, outputs=("mu", "s2", "acq"))
+        close(r["mu"], f["mu"], rtol=1e-9, atol=1e-10); close(r["s2"], f["s2"], rtol=1e-9); close(r["acq"], f["acq"], rtol=1e-9, atol=ACQ_ATOL)
+        assert r["best_idx"] == f["best_idx"]
+
+    kw = dict(acq='ei', xi=.2, incremental=True, outputs=("mu", "s2", "acq"))
+    dA = DeviceArray.from_host(A)
+    genA, addrA = dA.generation(), dA.ptr.value
+    assert genA > 0
+    assert sweep(GP, dA, **kw)["kernel"] == "sweep2_kernel"
+    GP.addData(X[390], Y[390])
+    r = sweep(GP, dA, **kw); assert r["kernel"] == "sweep2_rank1_kernel"; check(r, A)
+    # (1) free, allocate another array of the same shape: whatever address it gets, it is a different array
+    dA.free()
+    dB = DeviceArray.from_host(B)
+    same_address = dB.ptr.value == addrA
+    assert dB.generation() not in (0, genA)
+    GP.addData(X[391], Y[391])
+    r = sweep(GP, dB, **kw); assert r["kernel"] == "sweep2_kernel", (r["kernel"], same_address); check(r, B)
+    GP.addData(X[392], Y[392])
+    r = sweep(GP, dB, **kw); assert r["kernel"] == "sweep2_rank1_kernel"; check(r, B)
+    # (2) overwritten in place: new generation, full sweep, values of the NEW contents
+    g0 = dB.generation()
+    dB.upload(A)
+    assert dB.generation() != g0
+    r = sweep(GP, dB, **kw); assert r["kernel"] == "sweep2_kernel"; check(r, A)
+    r = sweep(GP, dB, **kw); assert r["kernel"] == "acq_finish_kernel"; check(r, A)
+    # (3) ndarrays: uploaded to a temporary each time, never incremental, each with its own values
+    for arr in (A, B, A):
+        r = sweep(GP, arr, **kw); assert r["kernel"] == "sweep2_kernel"; check(r, arr)
+    # (4) new targets through ibo_gp_set_y: the kept means belong to the old alpha vectors
+    r = sweep(GP, dB, **kw); assert r["kernel"] == "sweep2_kernel"        # (3) replaced the state
+    Y2 = np.array(GP.Y) * 0.5 + 0.1
+    _lib.check(_lib.lib.ibo_gp_set_y(GP._handle(), _lib.dp(_lib.f64(Y2))))
+    r = sweep(GP, dB, **kw); assert r["kernel"] == "sweep2_kernel"
+    f = sweep(GaussianProcess(kern, GP.X, Y2, noise=.1), A, acq='ei', xi=.2, outputs=("mu",))
+    close(r["mu"], f["mu"], rtol=1e-9, atol=1e-10)
+    # (5) a view into the same allocation at another offset is another array; memory of unknown origin has no generation
+    v = dB.view_rows(1, 9001)
+    assert sweep(GP, v, **kw)["kernel"] == "sweep2_kernel"
+    gen = ctypes.c_uint64(7)
+    _lib.check(_lib.lib.ibo_dev_generation(0, ctypes.c_void_p(A.ctypes.data), ctypes.byref(gen)))        # (a host address)
+    assert gen.value == 0
+
+
 def test_sweep_index_base_beyond_32_bits(ibo):
     """global indices of a shard far into a huge candidate set: index_base > 2^31 (and > 2^32) is carried in
     64 bits through the kernel's partials, the final reduction and the ABI"""
