@@ -59,6 +59,7 @@ static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to
 static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
 static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
+static int g_chol_left = 1;      // ibo_set_option("chol_left", 0/1): ibo_nlml_grid factors in the left-looking outer order (update3.hip)
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
 
@@ -300,6 +301,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
+    if (key && !strcmp(key, "chol_left")) { g_chol_left = value; return IBO_OK; }
     if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
@@ -1496,7 +1498,10 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N));
     IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
     IBO_TRY(dL.ensure(nn * B)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096 * B));
-    const size_t pws = 2 * (size_t)Np * 256;        // per matrix: both packed copies of a 4-block panel
+    // packed operands of the trailing updates, per matrix: the whole factor in fragment order (left-looking order,
+    // update3.hip) or both packed copies of one 4-block panel (right-looking, update2.hip)
+    const bool left = g_chol_left != 0;
+    const size_t pws = left ? nn : 2 * (size_t)Np * 256;
     IBO_TRY(ws.dP.ensure(pws * B));
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
@@ -1515,7 +1520,10 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
             KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, s, nullptr, 0, 1));
         }
         KERNEL_TRY(launch_nlml_aug(dL.p, Np, N, dY.p, s, nb, nn));
-        KERNEL_TRY(launch_cholesky_batched(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s, ws.dP.p, pws));
+        // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
+        if (left) KERNEL_TRY(launch_cholesky_batched_left(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s, ws.dP.p, pws, N + 1,
+                                                          N % 64 == 0 ? Np / 64 - 1 : Np / 64));
+        else KERNEL_TRY(launch_cholesky_batched(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s, ws.dP.p, pws));
         KERNEL_TRY(launch_nlml_reduce(dL.p, Np, N, dout.p + 2 * t0, s, nb, nn));
     }
     HIP_TRY(hipStreamSynchronize(s));

@@ -873,34 +873,41 @@ void set_chol_update2(int v) { g_update2 = v; }
 static int g_update2_min_tiles = 1024;               // ibo_set_option("update2_min_tiles"): 128 x 128 tiles (over the batch) from which the packed-panel kernel takes the update
 void set_chol_update2_min_tiles(int v) { g_update2_min_tiles = v; }
 
+// the block columns [p0, pend) of a panel whose columns are up to date: diagonal blocks, row blocks, K = 64 updates inside the panel
+static void chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, int *info_dev, int batch, size_t lstride, hipStream_t s)
+{
+    const int nb = Npad / 64;
+    const size_t dstride = (size_t)nb * 4096;
+    // P <= 4: the per-column launches stay inside the panel's diagonal block, the rows below it take the whole panel
+    // in one launch (chol_panel_rows_kernel; the same arithmetic in the same order)
+    // (taken when the rows fill the chip: with few of them the short launches it replaces finish sooner; either way
+    // the bits are the same)
+    const bool rows_fused = g_panel_rows && pend - p0 <= 4 && (size_t)(nb - pend) * batch >= 256;
+    for (int jb = p0; jb < pend; jb++) {
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, info_dev,
+                           lstride, dstride, (double *)nullptr);
+        const int m = (rows_fused ? pend : nb) - jb - 1;
+        if (m > 0)
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, lstride,
+                               dstride, (double *)nullptr);
+        if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s, nullptr, rows_fused ? pend : 0);
+    }
+    if (rows_fused && pend < nb)
+        hipLaunchKernelGGL(chol_panel_rows_kernel, dim3(nb - pend, 1, batch), dim3(256), 0, s, L, Npad, p0, pend, diag64,
+                           lstride, dstride);
+}
+
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
                             int panel, hipStream_t s, double *ws, size_t wstride)
 {
     const int nb = Npad / 64;
-    const size_t dstride = (size_t)nb * 4096;
     // the panel width fixes the order of the floating-point sums, so it may depend on the matrix size and
     // on the entry point but never on how many matrices share the launches
     const int P = g_chol_panel > 0 ? g_chol_panel : panel;
     HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
     for (int p0 = 0; p0 < nb; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
-        // P <= 4: the per-column launches stay inside the panel's diagonal block, the rows below it take the whole panel
-        // in one launch (chol_panel_rows_kernel; the same arithmetic in the same order)
-        // (taken when the rows fill the chip: with few of them the short launches it replaces finish sooner; either way
-        // the bits are the same)
-        const bool rows_fused = g_panel_rows && pend - p0 <= 4 && (size_t)(nb - pend) * batch >= 256;
-        for (int jb = p0; jb < pend; jb++) {
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, info_dev,
-                               lstride, dstride, (double *)nullptr);
-            const int m = (rows_fused ? pend : nb) - jb - 1;
-            if (m > 0)
-                hipLaunchKernelGGL(chol_trsm_kernel, dim3(m, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, lstride,
-                                   dstride, (double *)nullptr);
-            if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s, nullptr, rows_fused ? pend : 0);
-        }
-        if (rows_fused && pend < nb)
-            hipLaunchKernelGGL(chol_panel_rows_kernel, dim3(nb - pend, 1, batch), dim3(256), 0, s, L, Npad, p0, pend, diag64,
-                               lstride, dstride);
+        chol_inpanel(L, Npad, p0, pend, diag64, info_dev, batch, lstride, s);
         if (pend < nb) {
             // the big update (K = 64 P): packed-panel kernel when the caller lent a workspace, bit-identical to the other
             const int nI2 = (Npad - 64 * pend + 127) / 128;
@@ -910,6 +917,34 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
                 int rc = launch_chol_update2(L, Npad, p0, pend, batch, lstride, ws, wstride, s);
                 if (rc) return rc;
             } else launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// The same factorisation in the LEFT-LOOKING outer order (update3.hip): a panel's block columns receive all their updates
+// -- from every finished column, K = 64 p0 -- in one launch just before the panel is factored, from a packed copy of the
+// finished columns (Pk: Npad^2 doubles per matrix, pstride apart) that grows by a panel per step.  Same sums in the same order
+// as launch_cholesky_batched with the same panel width: identical bits.  nlive: rows >= nlive are identity pad (they are not
+// touched); nfactor: block columns to factor (a caller that never reads the last block column -- the likelihood's y row
+// alone in it -- passes nb - 1).
+int launch_cholesky_batched_left(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride, int panel,
+                                 hipStream_t s, double *Pk, size_t pstride, int nlive, int nfactor)
+{
+    const int nb = Npad / 64;
+    const int P = g_chol_panel > 0 ? g_chol_panel : panel;
+    if (nfactor <= 0 || nfactor > nb) nfactor = nb;
+    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
+    for (int p0 = 0; p0 < nfactor; p0 += P) {
+        const int pend = p0 + P < nb ? p0 + P : nb;
+        if (p0 > 0) {
+            int rc = launch_chol_update3(L, Npad, 64 * p0, 64 * (pend - p0), nlive, batch, lstride, Pk, pstride, s);
+            if (rc) return rc;
+        }
+        chol_inpanel(L, Npad, p0, pend, diag64, info_dev, batch, lstride, s);
+        if (pend < nfactor) {
+            int rc = launch_chol_pack3(L, Npad, 64 * pend, 64 * p0, 64 * (pend - p0), batch, lstride, Pk, pstride, s);
+            if (rc) return rc;
         }
     }
     return (int)hipGetLastError();

@@ -1,0 +1,223 @@
+// update3.hip -- LEFT-LOOKING trailing update of the batched two-level Cholesky (the marginal-likelihood grid,
+// BASELINE config 5; linalg.hip: launch_cholesky_batched_left).
+//
+// update2.hip is right-looking: after every panel of 256 columns the whole trailing matrix takes one K = 256 update.
+// Every 128 x 128 tile of C is then read and written once per panel -- 46 GB of the 108 GB a 64-theta grid at N = 4096
+// moved through the fabric -- and each visit is a short K loop with a prologue (the tile from HBM) and an epilogue.
+// Here the block columns [c0, c0 + width) of the NEXT panel are brought up to date in one go, just before they are
+// factored:   C <- C - L[rows, 0 : c0] L[panel rows, 0 : c0]^T,   K = c0 (256 .. N - 256) columns deep.
+// A tile of C is read once and written once per factorisation (8 GB per grid instead of 46), the K loop is 8 x longer
+// on average, and both operands come from ONE packed copy of the finished block columns (chol_pack3_kernel) that
+// grows by a panel per outer step:
+//   Pk[((g NK8 + j) 64 + lane) 2 + h] = L[16 g + (lane & 15)][8 j + 4 h + (lane >> 4)],   NK8 = Npad / 8,
+// a row-block's K range is contiguous (one aligned 16-byte load per lane and k8-step, scalar offsets only).
+//
+// Arithmetic: an element of C receives the terms -L_ik L_jk in ascending k, in the same groups of four (the k4-steps
+// of v_mfma_f64_16x16x4) as in the right-looking order, where it received them panel by panel; storing and reloading
+// the fp64 accumulator in between changes nothing.  There is no negated copy of the panel: the accumulators start as
+// -C and the result is negated back -- every intermediate value is the exact negative of the right-looking one
+// (round-to-nearest is symmetric).  So the factor is BIT-IDENTICAL to launch_cholesky_batched's (tested).
+//
+// Tile -> workgroup order: workgroups are dealt round-robin to the 8 XCDs (observed; speed only), so workgroup b gets
+// entry (b & 7) C + (b >> 3) of the sequence "matrix 0's tiles, matrix 1's tiles, ..", C = its length / 8: one XCD works
+// through whole matrices, whose two 128-row B strips (the panel's own rows, shared by ALL tiles of the matrix) then
+// stream through that XCD's L2 once, and tiles (I, 0), (I, 1) -- same A strip -- are neighbours.
+//
+// Pad rows (>= nlive: identity rows whose factor entries left of the diagonal are exact zeros) are neither loaded
+// nor multiplied nor stored: the y row the likelihood appends costs one 16-row block, not a 128-row tile.
+#include "ibo_common.h"
+#include <type_traits>
+
+#define U3_NW 8
+typedef double d2_t __attribute__((ext_vector_type(2)));
+#define U3_KS 32                       // columns per LDS stage of B
+
+typedef unsigned u3_v4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t u3_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+}
+__device__ __forceinline__ double u3_lo(const u3_v4 &v) { return __hiloint2double((int)v.y, (int)v.x); }
+__device__ __forceinline__ double u3_hi(const u3_v4 &v) { return __hiloint2double((int)v.w, (int)v.z); }
+
+// rows [r0, Npad) x columns [c0, c0 + K) of L into the packed store (fragment order, see above)
+__global__ __launch_bounds__(256) void chol_pack3_kernel(const double *__restrict__ L, int Npad, int r0, int c0, int K,
+                                                         double *__restrict__ Pk, size_t lstride, size_t pstride)
+{
+    L += blockIdx.z * lstride; Pk += blockIdx.z * pstride;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)(Npad - r0) * K;
+    if (e >= total) return;
+    const int h = (int)(e & 1), lane = (int)((e >> 1) & 63), nk8 = K >> 3;
+    const size_t gj = e >> 7;
+    const int j = (int)(gj % nk8), g = (int)(gj / nk8);
+    const int row = r0 + 16 * g + (lane & 15), col = c0 + 8 * j + 4 * h + (lane >> 4);
+    const double v = L[(size_t)row * Npad + col];
+    Pk[((((size_t)(row >> 4) * (Npad >> 3) + (col >> 3)) * 64 + lane) << 1) + h] = v;
+}
+
+// C[rows >= c0][c0 .. c0 + 16 ncb) -= Pk-rows x Pk-rows^T over k < c0.  128 x 128 tiles (I, J), J < ntc, J <= I for the
+// tiles that straddle the diagonal; 8 waves = 4 (row pairs of 16-row blocks) x 2 (four column-blocks each).
+__global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, int Npad, int c0, int ncb, int nlive_rb,
+                                                                  const double *Pk, size_t lstride, size_t pstride,
+                                                                  int tpm, int ntc, int batch, int chunk)
+{
+    __shared__ __attribute__((aligned(16))) double lds_b[2][U3_KS / 8 * 8 * 128];      // [stage][k8-step][column-block][lane][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // sequence entry of this workgroup (see the header): matrix m, tile t
+    const int q = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || q >= batch * tpm) return;
+    const int m = q / tpm, t = q - m * tpm;
+    L += (size_t)m * lstride; Pk += (size_t)m * pstride;
+    int I, J;
+    if (ntc == 2) { I = (t + 1) >> 1; J = t ? (t + 1) & 1 : 0; } else { I = t; J = 0; }      // (0,0), (1,0), (1,1), (2,0), (2,1), ..
+    const int wr = wave >> 1, wc = wave & 1;
+    const int gA = ((c0 + 128 * I) >> 4) + 2 * wr;               // first of this wave's two row-blocks (numbered from row 0)
+    const int gB = (c0 + 128 * J) >> 4;                          // first of the tile's eight column-blocks, as row-blocks of the panel
+    const int cb0 = 8 * J + 4 * wc;                              // this wave's first column-block inside the panel
+    const int nk8s = Npad >> 3;                                  // k8-steps per row-block of the packed store
+    const int K = c0;
+    const size_t pbytes = (size_t)Npad * Npad * sizeof(double);
+    const __amdgpu_buffer_rsrc_t rP = u3_rsrc(Pk, pbytes);
+    const unsigned lane16 = lane * 16;
+    // which of this wave's blocks exist: live rows only, the panel's columns only.  A wave with nothing to do runs the same
+    // loop (it stages B; its own fragments are pad rows -- exact zeros -- or the bounds check's zeros) and stores nothing.
+    const bool rowin[2] = {gA < nlive_rb, gA + 1 < nlive_rb};
+    // (tile-local row-blocks 2 wr, 2 wr + 1 against column-blocks 4 wc ..: wave (wr < 2, wc = 1) of a diagonal tile is all upper triangle)
+    const bool upper = I == J && wc == 1 && wr < 2;
+    const int ni = (cb0 < ncb && !upper) ? (rowin[1] ? 2 : (rowin[0] ? 1 : 0)) : 0;      // live row-blocks of this wave
+
+    // B staging: 32 fragments (k8-step f>>3, column-block f&7) of 1 KiB per stage, four per wave, in two halves
+    auto fetch_b = [&](int st, int half, u3_v4 (&v)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int f = wave + 8 * (2 * half + u);
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, (unsigned)(((gB + (f & 7)) * nk8s + st * (U3_KS / 8) + (f >> 3)) * 1024), 0);
+        }
+    };
+    auto stash_b = [&](int b, int half, const u3_v4 (&v)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) *(u3_v4 *)&lds_b[b][((wave + 8 * (2 * half + u)) * 64 + lane) * 2] = v[u];
+    };
+    const int nstage = K / U3_KS;                         // even: K is a multiple of 64
+    u3_v4 vb[2];
+    fetch_b(0, 0, vb); stash_b(0, 0, vb);
+    fetch_b(0, 1, vb); stash_b(0, 1, vb);
+    // A fragments: straight from the packed store, a ring of four register pairs, THREE k8-steps ahead -- the operand
+    // strips stream from HBM (a row-block's K range is read once per tile pair), and a step of one wave lasts about
+    // 4 x 16 MFMAs of pipe time, so three steps cover the memory latency with room to spare.
+    // The loop body below is branch-free straight-line code (two stages = eight steps per trip, every LDS offset an
+    // immediate, the prefetch of the stage after the last one reading harmless addresses): with a conditional load in the
+    // body the compiler's s_waitcnt placement falls back to vmcnt(0) at the first use after it -- the MFMAs then wait
+    // for the prefetch they have just issued (measured: MFMA pipe 71 % busy, and the same 52 TFLOP/s as update2.hip,
+    // whose loop has that flaw, although the traffic had fallen from 108 to 42 GB).
+    // accumulators <- MINUS the tile.  Element r of block (i, cb): row 16 (gA + i) + (lane>>4) + 4 r, column c0 + 16 (cb0 + cb) + (lane&15)
+    d4_t acc[2][4];
+    double *Cw = L + (size_t)(16 * gA + (lane >> 4)) * Npad + c0 + 16 * cb0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            const bool in = i < ni && cb0 + cb < ncb;
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[i][cb][r] = in ? -Cw[(size_t)(16 * i + 4 * r) * Npad + 16 * cb] : 0.0;
+        }
+
+    u3_v4 A[4][2];
+    const unsigned abase0 = (unsigned)(gA * nk8s) * 1024u, abase1 = (unsigned)((gA + 1) * nk8s) * 1024u;
+    // NI = live row-blocks of this wave (2; 1: the y row's block, whose neighbour is pad; 0: nothing -- pad rows, columns
+    // beyond the panel, or the blocks of a diagonal tile that lie wholly above the diagonal): the loop exists in three
+    // straight-line versions chosen once per wave, so the idle waves of a thin tile leave the MFMA pipe to their neighbours
+    auto run = [&](auto ni_tag) {
+        constexpr int NI = decltype(ni_tag)::value;
+        auto fetch_a = [&](int j, u3_v4 (&Aj)[2]) {       // k8-step j (past K: later columns' fragments or the bounds check's zeros, never used)
+            if (NI >= 1) Aj[0] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, abase0 + (unsigned)j * 1024u, 0);
+            if (NI >= 2) Aj[1] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, abase1 + (unsigned)j * 1024u, 0);
+        };
+        fetch_a(0, A[0]);
+        fetch_a(1, A[1]);
+        fetch_a(2, A[2]);
+        __syncthreads();
+        // one k8-step: 8 NI MFMAs on the fragments in CUR and the four B fragment pairs of this wave's column-blocks
+        auto mma = [&](const double *kb, int j8, const u3_v4 (&CUR)[2]) {
+            if (NI == 0) return;
+            d2_t b[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) b[cb] = *(const d2_t *)&kb[((j8 * 8 + cb) * 64) * 2];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const double av = h ? u3_hi(CUR[i]) : u3_lo(CUR[i]);
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++) acc[i][cb] = mfma_f64(av, h ? b[cb].y : b[cb].x, acc[i][cb]);
+                }
+        };
+        // a stage whose B fragments sit in LDS buffer BUF (a compile-time constant); it stages the next one into the other
+        auto stage = [&](int st, auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            const double *kb = &lds_b[BUF][(4 * wc * 64 + lane) * 2];
+            const int j = st * (U3_KS / 8);
+            fetch_a(j + 3, A[3]); fetch_b(st + 1, 0, vb);
+            mma(kb, 0, A[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(j + 4, A[0]);
+            mma(kb, 1, A[1]);
+            stash_b(BUF ^ 1, 0, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(j + 5, A[1]); fetch_b(st + 1, 1, vb);
+            mma(kb, 2, A[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(j + 6, A[2]);
+            mma(kb, 3, A[3]);
+            stash_b(BUF ^ 1, 1, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        for (int st = 0; st < nstage; st += 2) {
+            stage(st, std::integral_constant<int, 0>{});
+            stage(st + 1, std::integral_constant<int, 1>{});
+        }
+    };
+    if (ni == 0) { run(std::integral_constant<int, 0>{}); return; }      // this wave only helps staging B
+    run(std::integral_constant<int, 2>{});                   // (ni = 1, the y row's block: its neighbour is pad -- zeros -- and is not stored;
+                                                             //  a third, one-block version of the loop made hipcc spill 340 B/lane)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            if (i < ni && cb0 + cb < ncb) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) Cw[(size_t)(16 * i + 4 * r) * Npad + 16 * cb] = -acc[i][cb][r];
+            }
+        }
+}
+
+// Pk: Npad * Npad doubles per matrix, `pstride` apart.  nlive: rows >= nlive are identity pad (never touched).
+int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batch, size_t lstride, double *Pk, size_t pstride,
+                      hipStream_t s)
+{
+    if (r0 >= Npad || K <= 0) return 0;
+    const size_t total = (size_t)(Npad - r0) * K;
+    hipLaunchKernelGGL(chol_pack3_kernel, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, L, Npad, r0, c0, K, Pk,
+                       lstride, pstride);
+    return (int)hipGetLastError();
+}
+
+int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int batch, size_t lstride, const double *Pk,
+                        size_t pstride, hipStream_t s)
+{
+    if (c0 <= 0 || width <= 0) return 0;
+    const int nlive_rb = (nlive + 15) / 16;
+    const int rows = 16 * nlive_rb - c0;                     // live rows at and below the panel's first row
+    if (rows <= 0) return 0;
+    const int nrt = (rows + 127) / 128, ntc = width > 128 ? 2 : 1;
+    const int tpm = ntc == 2 ? 2 * nrt - 1 : nrt;
+    const long long total = (long long)tpm * batch;
+    const int chunk = (int)((total + 7) / 8);
+    hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)(8 * chunk)), dim3(U3_NW * 64), 0, s, L, Npad, c0, width / 16, nlive_rb, Pk,
+                       lstride, pstride, tpm, ntc, batch, chunk);
+    return (int)hipGetLastError();
+}
