@@ -60,6 +60,8 @@ static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch p
 static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
 static int g_chol_left = 1;      // ibo_set_option("chol_left", 0/1): ibo_nlml_grid factors in the left-looking outer order (update3.hip)
+static int g_nlml_groups = 2;    // ibo_set_option("nlml_groups", g): a batch of theta-points runs as g sub-batches on g streams (the latency-bound
+                                 // in-panel chain and the launch tails of one overlap the MFMA-bound updates of the other); values do not depend on it
 static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
 static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
 
@@ -302,6 +304,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_left")) { g_chol_left = value; return IBO_OK; }
+    if (key && !strcmp(key, "nlml_groups")) { if (value < 1 || value > 4) return fail(IBO_ERR_ARG, "nlml_groups: 1..4"); g_nlml_groups = value; return IBO_OK; }
     if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
@@ -1447,6 +1450,7 @@ struct NlmlWorkspace {
     DevBuf<int> dinfo;
     const double *padded = nullptr;                 // dL as it was when its matrices got their identity pad,
     int pad_Np = 0, pad_N = 0, pad_B = 0;           // and for which geometry
+    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};     // sub-batches of a grid run side by side (created on first use, kept)
 };
 static NlmlWorkspace g_nlml_ws[16];
 struct GradWorkspace {
@@ -1461,6 +1465,7 @@ extern "C" int ibo_trim(int device)
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
     ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release();
     ws.padded = nullptr;
+    for (int g = 0; g < 4; g++) if (ws.streams[g]) { (void)hipStreamDestroy(ws.streams[g]); ws.streams[g] = nullptr; }
     GradWorkspace &gw = g_grad_ws[device & 15];
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
     gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
@@ -1511,20 +1516,31 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         for (int k = 0; k < B; k++) KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p + nn * k, Np, 1.0, s));
         ws.padded = dL.p; ws.pad_Np = Np; ws.pad_N = N; ws.pad_B = B;
     }
+    HIP_TRY(hipStreamSynchronize(s));               // the identity pad is in place before the sub-batches' streams start
     for (int t0 = 0; t0 < n_theta; t0 += B) {
         const int nb = n_theta - t0 < B ? n_theta - t0 : B;
-        for (int k = 0; k < nb; k++) {
-            const int t = t0 + k;
-            KParams kp;
-            IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
-            KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, s, nullptr, 0, 1));
+        // sub-batches of at least 8 matrices, each on its own stream: one's in-panel chain (64 workgroups at a time, latency)
+        // and launch tails run beside the other's long-K updates
+        int G = left ? g_nlml_groups : 1;
+        while (G > 1 && nb / G < 8) G--;
+        for (int g = 0; g < G; g++) {
+            if (G > 1 && !ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
+            hipStream_t sg = G > 1 ? ws.streams[g] : s;
+            const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
+            for (int k = k0; k < k1; k++) {
+                const int t = t0 + k;
+                KParams kp;
+                IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
+                KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, sg, nullptr, 0, 1));
+            }
+            KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
+            // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
+            if (left) KERNEL_TRY(launch_cholesky_batched_left(dL.p + nn * k0, Np, d64.p + (size_t)(Np / 64) * 4096 * k0, dinfo.p + t0 + k0, ng, nn, 4, sg,
+                                                              ws.dP.p + pws * k0, pws, N + 1, N % 64 == 0 ? Np / 64 - 1 : Np / 64, N / 64));
+            else KERNEL_TRY(launch_cholesky_batched(dL.p + nn * k0, Np, d64.p + (size_t)(Np / 64) * 4096 * k0, dinfo.p + t0 + k0, ng, nn, 4, sg, ws.dP.p + pws * k0, pws));
+            KERNEL_TRY(launch_nlml_reduce(dL.p + nn * k0, Np, N, dout.p + 2 * (t0 + k0), sg, ng, nn));
         }
-        KERNEL_TRY(launch_nlml_aug(dL.p, Np, N, dY.p, s, nb, nn));
-        // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
-        if (left) KERNEL_TRY(launch_cholesky_batched_left(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s, ws.dP.p, pws, N + 1,
-                                                          N % 64 == 0 ? Np / 64 - 1 : Np / 64));
-        else KERNEL_TRY(launch_cholesky_batched(dL.p, Np, d64.p, dinfo.p + t0, nb, nn, 4, s, ws.dP.p, pws));
-        KERNEL_TRY(launch_nlml_reduce(dL.p, Np, N, dout.p + 2 * t0, s, nb, nn));
+        if (G > 1) for (int g = 0; g < G; g++) HIP_TRY(hipStreamSynchronize(ws.streams[g]));      // the next batch reuses the matrix slots
     }
     HIP_TRY(hipStreamSynchronize(s));
     std::vector<double> out(2 * (size_t)n_theta);

@@ -773,15 +773,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // tile reads and writes 128 KB for half a megaflop; here a row block is read once and written once, and its operands
 // (6 blocks of the diagonal block, 4 inverses) are shared by all row blocks through L2.
 // LDS: -X_i,j' for the (at most 3) earlier columns, one stage for the L / inverse block of the product at hand.
+// Pk (optional): the left-looking order's packed copy of the factor (update3.hip) -- the row block's finished columns go there
+// straight from LDS, in fragment order (what chol_pack3_kernel would re-read them from L for), and only block rows
+// >= rm_from are also stored row-major (a caller that reads nothing else of the rows below a panel: the likelihood's y row).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void chol_panel_rows_kernel(double *L, int Npad, int p0, int pend, const double *__restrict__ diag64, size_t lstride,
-                            size_t dstride)
+                            size_t dstride, double *__restrict__ Pk, size_t pstride, int rm_from)
 {
     __shared__ double Xs[3][64 * SD];
     __shared__ double Bs[64 * SD];
     TILE_IDS;
     L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
+    if (Pk) Pk += blockIdx.z * pstride;
     const int i = pend + blockIdx.x, P = pend - p0;
+    const bool rowmajor = !Pk || i >= rm_from;
     double *Ai = L + (size_t)i * 64 * Npad + (size_t)p0 * 64;
     // operand blocks in the order they are used: (jj, jp < jj): L_{p0+jj, p0+jp};  (jj, jj): inv(L_{p0+jj})
     auto fetch_b = [&](int jj, int jp, d2_t (&vb)[8]) {
@@ -796,6 +801,19 @@ void chol_panel_rows_kernel(double *L, int Npad, int p0, int pend, const double 
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[m][n][r] = Ai[(size_t)TILE_ROW(m, r) * Npad + jj * 64 + TILE_COL(n)];
     };
+    // column jj of the row block, held as -X in Xm (64 x SD), into the packed store: wave g takes 16-row block g, lane l
+    // the fragment element pair (row 16 g + (l & 15), columns 8 j + (l >> 4) and + 4) of every 8-column step j
+    auto pack_col = [&](int jj, const double *Xm) {
+        const int g = wv, nk8 = Npad >> 3;
+        double *dst = Pk + (((size_t)(i * 4 + g) * nk8 + (size_t)(p0 + jj) * 8) * 64 + lane) * 2;
+        const double *src = Xm + (16 * g + (lane & 15)) * SD + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            d2_t v;
+            v.x = -src[8 * j]; v.y = -src[8 * j + 4];
+            *(d2_t *)(dst + (size_t)j * 128) = v;
+        }
+    };
     d2_t vb[8];
     d4_t acc[2][2], accn[2][2];
     fetch_b(0, 0, vb);
@@ -805,6 +823,7 @@ void chol_panel_rows_kernel(double *L, int Npad, int p0, int pend, const double 
             tile64_stash<false, SD>(Bs, vb);
             __syncthreads();                            // also: -X of the previous column is in place
             fetch_b(jj, jp + 1, vb);
+            if (Pk && jp == jj - 1) pack_col(jp, Xs[jp]);       // (jj <= 3 here: column jp's -X is never overwritten before)
             tile64_mma_nt<SD>(Xs[jp], Bs, acc);
             __syncthreads();
         }
@@ -823,22 +842,28 @@ void chol_panel_rows_kernel(double *L, int Npad, int p0, int pend, const double 
         }
         d4_t x[2][2] = {};
         tile64_mma_nt_tri<SD>(As, Bs, x);
+        if (rowmajor) {
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+            for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int n = 0; n < 2; n++)
+                for (int n = 0; n < 2; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) Ai[(size_t)TILE_ROW(m, r) * Npad + jj * 64 + TILE_COL_TRI(n)] = x[m][n][r];
+                    for (int r = 0; r < 4; r++) Ai[(size_t)TILE_ROW(m, r) * Npad + jj * 64 + TILE_COL_TRI(n)] = x[m][n][r];
+        }
         __syncthreads();
-        if (jj + 1 < P) {
+        if (jj + 1 < P || Pk) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < 2; n++) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) As[TILE_ROW(m, r) * SD + TILE_COL_TRI(n)] = -x[m][n][r];
-                    acc[m][n] = accn[m][n];
+                    if (jj + 1 < P) acc[m][n] = accn[m][n];
                 }
+        }
+        if (Pk && jj + 1 == P) {                        // the last column (or a one-column panel): nobody packs it later
+            __syncthreads();
+            pack_col(jj, As);
         }
     }
 }
@@ -874,7 +899,9 @@ static int g_update2_min_tiles = 1024;               // ibo_set_option("update2_
 void set_chol_update2_min_tiles(int v) { g_update2_min_tiles = v; }
 
 // the block columns [p0, pend) of a panel whose columns are up to date: diagonal blocks, row blocks, K = 64 updates inside the panel
-static void chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, int *info_dev, int batch, size_t lstride, hipStream_t s)
+// Returns true when the rows below the panel went to the packed store Pk (left-looking order) on the way.
+static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, int *info_dev, int batch, size_t lstride, hipStream_t s,
+                         double *Pk = nullptr, size_t pstride = 0, int rm_from = 0)
 {
     const int nb = Npad / 64;
     const size_t dstride = (size_t)nb * 4096;
@@ -894,7 +921,8 @@ static void chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
     }
     if (rows_fused && pend < nb)
         hipLaunchKernelGGL(chol_panel_rows_kernel, dim3(nb - pend, 1, batch), dim3(256), 0, s, L, Npad, p0, pend, diag64,
-                           lstride, dstride);
+                           lstride, dstride, Pk, pstride, rm_from);
+    return rows_fused && pend < nb && Pk;
 }
 
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
@@ -927,9 +955,10 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // finished columns (Pk: Npad^2 doubles per matrix, pstride apart) that grows by a panel per step.  Same sums in the same order
 // as launch_cholesky_batched with the same panel width: identical bits.  nlive: rows >= nlive are identity pad (they are not
 // touched); nfactor: block columns to factor (a caller that never reads the last block column -- the likelihood's y row
-// alone in it -- passes nb - 1).
+// alone in it -- passes nb - 1); rm_from: the factor's blocks BELOW a panel's diagonal block are stored row-major for block rows
+// >= rm_from only (0: all of them, i.e. the whole factor; the likelihood reads the y row and the diagonal and passes N / 64).
 int launch_cholesky_batched_left(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride, int panel,
-                                 hipStream_t s, double *Pk, size_t pstride, int nlive, int nfactor)
+                                 hipStream_t s, double *Pk, size_t pstride, int nlive, int nfactor, int rm_from)
 {
     const int nb = Npad / 64;
     const int P = g_chol_panel > 0 ? g_chol_panel : panel;
@@ -941,8 +970,10 @@ int launch_cholesky_batched_left(double *L, int Npad, double *diag64, int *info_
             int rc = launch_chol_update3(L, Npad, 64 * p0, 64 * (pend - p0), nlive, batch, lstride, Pk, pstride, s);
             if (rc) return rc;
         }
-        chol_inpanel(L, Npad, p0, pend, diag64, info_dev, batch, lstride, s);
-        if (pend < nfactor) {
+        // the rows below the panel reach the packed store straight from chol_panel_rows_kernel's LDS where that kernel runs
+        // (and then only the block rows >= rm_from are also stored row-major), through chol_pack3_kernel otherwise
+        const bool packed = chol_inpanel(L, Npad, p0, pend, diag64, info_dev, batch, lstride, s, pend < nfactor ? Pk : nullptr, pstride, rm_from);
+        if (pend < nfactor && !packed) {
             int rc = launch_chol_pack3(L, Npad, 64 * pend, 64 * p0, 64 * (pend - p0), batch, lstride, Pk, pstride, s);
             if (rc) return rc;
         }
