@@ -59,6 +59,7 @@ static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to
 static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
 static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
 static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
+static int g_cov_fast = 1;       // ibo_set_option("cov_fast", 0/1): ibo_nlml_grid's covariance pass with scaled coordinates and the sweep's exp (see cov_matrix_kernel)
 static int g_chol_left = 1;      // ibo_set_option("chol_left", 0/1): ibo_nlml_grid factors in the left-looking outer order (update3.hip)
 static int g_nlml_groups = 2;    // ibo_set_option("nlml_groups", g): a batch of theta-points runs as g sub-batches on g streams (the latency-bound
                                  // in-panel chain and the launch tails of one overlap the MFMA-bound updates of the other); values do not depend on it
@@ -304,6 +305,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_left")) { g_chol_left = value; return IBO_OK; }
+    if (key && !strcmp(key, "cov_fast")) { g_cov_fast = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_groups")) { if (value < 1 || value > 4) return fail(IBO_ERR_ARG, "nlml_groups: 1..4"); g_nlml_groups = value; return IBO_OK; }
     if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
@@ -1447,6 +1449,7 @@ extern "C" int ibo_direct_max(ibo_gp_t *g, int D, const double *lb, const double
 // ------------------------------------------------------------------------ marginal-likelihood grid
 struct NlmlWorkspace {
     DevBuf<double> dX, dY, dout, dL, d64, dP;       // dP: packed panels of the trailing updates (update2.hip)
+    DevBuf<KParams> dkp;                            // the theta-points' kernel parameters (one covariance launch per sub-batch)
     DevBuf<int> dinfo;
     const double *padded = nullptr;                 // dL as it was when its matrices got their identity pad,
     int pad_Np = 0, pad_N = 0, pad_B = 0;           // and for which geometry
@@ -1463,7 +1466,7 @@ extern "C" int ibo_trim(int device)
 {
     IBO_TRY(use_device(device));
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
-    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release();
+    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release(); ws.dkp.release();
     ws.padded = nullptr;
     for (int g = 0; g < 4; g++) if (ws.streams[g]) { (void)hipStreamDestroy(ws.streams[g]); ws.streams[g] = nullptr; }
     GradWorkspace &gw = g_grad_ws[device & 15];
@@ -1516,6 +1519,12 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         for (int k = 0; k < B; k++) KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p + nn * k, Np, 1.0, s));
         ws.padded = dL.p; ws.pad_Np = Np; ws.pad_N = N; ws.pad_B = B;
     }
+    // every theta-point's kernel parameters go up once; a sub-batch's covariance matrices are one launch
+    std::vector<KParams> kps(n_theta);
+    for (int t = 0; t < n_theta; t++)
+        IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kps[t]));
+    IBO_TRY(ws.dkp.ensure(n_theta));
+    HIP_TRY(hipMemcpy(ws.dkp.p, kps.data(), sizeof(KParams) * n_theta, hipMemcpyHostToDevice));
     HIP_TRY(hipStreamSynchronize(s));               // the identity pad is in place before the sub-batches' streams start
     for (int t0 = 0; t0 < n_theta; t0 += B) {
         const int nb = n_theta - t0 < B ? n_theta - t0 : B;
@@ -1527,12 +1536,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
             if (G > 1 && !ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
             hipStream_t sg = G > 1 ? ws.streams[g] : s;
             const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
-            for (int k = k0; k < k1; k++) {
-                const int t = t0 + k;
-                KParams kp;
-                IBO_TRY(make_kparams(ktype, D, thetas + (size_t)t * nhyper, nhyper, sf2s ? sf2s[t] : 1.0, &kp));
-                KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k, Np, sg, nullptr, 0, 1));
-            }
+            KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg, g_cov_fast));
             KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
             // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
             if (left) KERNEL_TRY(launch_cholesky_batched_left(dL.p + nn * k0, Np, d64.p + (size_t)(Np / 64) * 4096 * k0, dinfo.p + t0 + k0, ng, nn, 4, sg,

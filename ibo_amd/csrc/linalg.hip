@@ -24,12 +24,23 @@
 // covers whole 128-byte segments.
 // (z is accumulated in the reference's order: sum_d w_d (a_d - b_d)^2.)
 #define COV_LD 33          // row stride of the staged points: odd (conflict-free column reads), >= IBO_DMAX
-__global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, const double *__restrict__ A1, int n2,
+// FAST (the marginal-likelihood grid, whose matrices never leave the device): coordinates scaled by sqrt(w_d) on their way
+// into LDS (two instead of three fp64 instructions per dimension and entry) and the 16-instruction exp_fast / 7-instruction
+// sqrt_fast of the sweep (relative error < 5e-16) instead of the library's -- 52 instead of 88 instructions per entry at
+// D = 16.  GP.R and everything a caller can read back keep the reference's order of operations (FAST = false).
+template <bool FAST>
+__global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp1, int n1, const double *__restrict__ A1, int n2,
                                                          const double *__restrict__ A2, int ldp, int square,
                                                          int diag_rule, double noise, double *__restrict__ K, int ldk,
                                                          double *__restrict__ K2, int np2, int lower_only,
-                                                         double *__restrict__ Eye, int *__restrict__ zero_word)
+                                                         double *__restrict__ Eye, int *__restrict__ zero_word,
+                                                         const KParams *__restrict__ kps, size_t kstride)
 {
+    // one matrix per blockIdx.z, its kernel parameters in kps[z] (device) and its output kstride doubles on: the
+    // likelihood grid's matrices in ONE launch (2145 workgroups per matrix do not fill the chip for long; 64 launches
+    // of 42 us each were 9 % of a grid)
+    const KParams &kp = kps ? kps[blockIdx.z] : kp1;
+    if (kps) K += blockIdx.z * kstride;
     __shared__ double AB[2 * 64 * COV_LD];           // the two tiles' points; afterwards the tile itself, transposed (64 x 65)
     double *As = AB, *Bs = AB + 64 * COV_LD;
     static_assert(2 * 64 * COV_LD >= 64 * 65, "the transposed tile reuses the staging buffers");
@@ -53,8 +64,9 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
     if (skip) return;
     for (int e = t; e < 64 * D; e += 256) {
         const int r = e / D, d = e - r * D;
-        As[r * COV_LD + d] = (i0 + r < n1) ? A1[(size_t)(i0 + r) * ldp + d] : 0.0;
-        Bs[r * COV_LD + d] = (j0 + r < n2) ? A2[(size_t)(j0 + r) * ldp + d] : 0.0;
+        const double sc = FAST ? kp.sw[d] : 1.0;
+        As[r * COV_LD + d] = (i0 + r < n1) ? A1[(size_t)(i0 + r) * ldp + d] * sc : 0.0;
+        Bs[r * COV_LD + d] = (j0 + r < n2) ? A2[(size_t)(j0 + r) * ldp + d] * sc : 0.0;
     }
     __syncthreads();
     double z[4][4] = {};
@@ -70,9 +82,11 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const double u = a[r] - b[c];
-                z[r][c] += w * (u * u);
+                if (FAST) z[r][c] = fma(u, u, z[r][c]);
+                else z[r][c] += w * (u * u);
             }
     }
+    const double log_sf2 = FAST ? log(kp.sf2) : 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int i = i0 + ty * 4 + r;
@@ -80,7 +94,12 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
         for (int c = 0; c < 4; c++) {
             const int j = j0 + tx + 16 * c;
             if (i < n1 && j < n2) {
-                double v = cov_from_z_rt(kp.family, z[r][c], kp.sf2);
+                double v;
+                if (FAST) {
+                    v = kp.family == FAM_SE ? cov_from_z_fast<FAM_SE>(z[r][c], log_sf2, kp.sf2)
+                        : (kp.family == FAM_M3 ? cov_from_z_fast<FAM_M3>(z[r][c], log_sf2, kp.sf2) : cov_from_z_fast<FAM_M5>(z[r][c], log_sf2, kp.sf2));
+                    if (square && i == j) v = kp.sf2;            // k(x, x), exactly
+                } else v = cov_from_z_rt(kp.family, z[r][c], kp.sf2);
                 if (square && i == j) {
                     // diag_rule 0: the reference never calls the kernel on the diagonal and
                     // hard-wires 1+noise (ego/gaussianprocess/__init__.py:138)
@@ -113,14 +132,35 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp, int n1, con
 // the diagonal only.  K may be NULL when only the working copy is wanted.
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
                       int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2, int lower_only,
-                      double *Eye, int *zero_word)
+                      double *Eye, int *zero_word, int fast)
 {
     int square = (A2 == nullptr);
     if (square) { A2 = A1; n2 = n1; }
     const int c = K2 ? np2 : n2, r = K2 ? np2 : n1;
     dim3 grid((c + 63) / 64, (r + 63) / 64);
-    hipLaunchKernelGGL(cov_matrix_kernel, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
-                       diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0, K2 ? Eye : nullptr, zero_word);
+    if (fast)
+        hipLaunchKernelGGL(cov_matrix_kernel<true>, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
+                           diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0, K2 ? Eye : nullptr, zero_word,
+                           (const KParams *)nullptr, (size_t)0);
+    else
+        hipLaunchKernelGGL(cov_matrix_kernel<false>, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
+                           diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0, K2 ? Eye : nullptr, zero_word,
+                           (const KParams *)nullptr, (size_t)0);
+    return (int)hipGetLastError();
+}
+
+// `batch` square covariance matrices K(A1, A1) (lower blocks only), parameters kps_dev[z] (device), outputs kstride doubles apart
+int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const double *A1, int ldp, int diag_rule, double noise,
+                              double *K, int ldk, size_t kstride, hipStream_t s, int fast)
+{
+    dim3 grid((n1 + 63) / 64, (n1 + 63) / 64, batch);
+    KParams dummy = KParams();
+    if (fast)
+        hipLaunchKernelGGL(cov_matrix_kernel<true>, grid, dim3(256), 0, s, dummy, n1, A1, n1, A1, ldp, 1, diag_rule, noise, K, ldk,
+                           (double *)nullptr, 0, 1, (double *)nullptr, (int *)nullptr, kps_dev, kstride);
+    else
+        hipLaunchKernelGGL(cov_matrix_kernel<false>, grid, dim3(256), 0, s, dummy, n1, A1, n1, A1, ldp, 1, diag_rule, noise, K, ldk,
+                           (double *)nullptr, 0, 1, (double *)nullptr, (int *)nullptr, kps_dev, kstride);
     return (int)hipGetLastError();
 }
 
@@ -868,6 +908,138 @@ void chol_panel_rows_kernel(double *L, int Npad, int p0, int pend, const double 
     }
 }
 
+// The same kernel on EIGHT waves (4 x 2 waves of 16 x 32): a lone wave per SIMD issues an fp64 MFMA every ~139 cycles at best
+// (tools/mfma_f64_peak), so the four-wave version's chain of ten dependent 64^3 products ran at 35 TFLOP/s -- 14 % of a
+// likelihood grid.  Two waves per SIMD take turns.  Every element sees the same MFMAs in the same order: identical bits.
+#define PR8_ROW(r) (wr8 * 16 + (lane >> 4) + 4 * (r))
+#define PR8_COL(n) (wc8 * 32 + (n) * 16 + (lane & 15))
+#define PR8_COL_TRI(n) ((wc8 ? ((n) ? 2 : 1) : ((n) ? 3 : 0)) * 16 + (lane & 15))
+__device__ __forceinline__ void pr8_fetch(const double *__restrict__ A, int lda, d2_t (&v)[4])
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = *(const d2_t *)(A + (size_t)(16 * u + (t >> 5)) * lda + (t & 31) * 2);
+}
+__device__ __forceinline__ void pr8_stash(double *As, const d2_t (&v)[4])
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        double *dst = As + (16 * u + (t >> 5)) * SD + (t & 31) * 2;
+        dst[0] = v[u].x; dst[1] = v[u].y;
+    }
+}
+__device__ __forceinline__ void pr8_mma_nt(const double *As, const double *Bs, d4_t (&acc)[2], int wr8, int wc8, int lane)
+{
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4++) {
+        const double a = As[(wr8 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+        double b[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++) b[n] = Bs[(wc8 * 32 + n * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[n] = mfma_f64(a, b[n], acc[n]);
+    }
+}
+template <int CB0, int CB1>
+__device__ __forceinline__ void pr8_mma_nt_tri_body(const double *As, const double *Bs, d4_t (&acc)[2], int wr8, int lane)
+{
+    double a[4 * (CB1 + 1)], b0[4 * (CB0 + 1)], b1[4 * (CB1 + 1)];
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+        a[k4] = As[(wr8 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+        if (k4 < 4 * (CB0 + 1)) b0[k4] = Bs[(CB0 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+        b1[k4] = Bs[(CB1 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+        if (k4 < 4 * (CB0 + 1)) acc[0] = mfma_f64(a[k4], b0[k4], acc[0]);
+        acc[1] = mfma_f64(a[k4], b1[k4], acc[1]);
+    }
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void chol_panel_rows8_kernel(double *L, int Npad, int p0, int pend, const double *__restrict__ diag64, size_t lstride,
+                             size_t dstride, double *__restrict__ Pk, size_t pstride, int rm_from)
+{
+    __shared__ double Xs[3][64 * SD];
+    __shared__ double Bs[64 * SD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr8 = wv >> 1, wc8 = wv & 1;
+    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
+    if (Pk) Pk += blockIdx.z * pstride;
+    const int i = pend + blockIdx.x, P = pend - p0;
+    const bool rowmajor = !Pk || i >= rm_from;
+    double *Ai = L + (size_t)i * 64 * Npad + (size_t)p0 * 64;
+    auto fetch_b = [&](int jj, int jp, d2_t (&vb)[4]) {
+        if (jp < jj) pr8_fetch(L + (size_t)(p0 + jj) * 64 * Npad + (size_t)(p0 + jp) * 64, Npad, vb);
+        else pr8_fetch(diag64 + (size_t)(p0 + jj) * 4096, 64, vb);
+    };
+    auto load_acc = [&](int jj, d4_t (&acc)[2]) {
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[n][r] = Ai[(size_t)PR8_ROW(r) * Npad + jj * 64 + PR8_COL(n)];
+    };
+    // column jj (held as -X in Xm) into the packed store: waves 2 g and 2 g + 1 share 16-row block g, four 8-column steps each
+    auto pack_col = [&](int jj, const double *Xm) {
+        const int g = wv >> 1, nk8 = Npad >> 3;
+        double *dst = Pk + (((size_t)(i * 4 + g) * nk8 + (size_t)(p0 + jj) * 8 + 4 * (wv & 1)) * 64 + lane) * 2;
+        const double *src = Xm + (16 * g + (lane & 15)) * SD + 32 * (wv & 1) + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d2_t v;
+            v.x = -src[8 * j]; v.y = -src[8 * j + 4];
+            *(d2_t *)(dst + (size_t)j * 128) = v;
+        }
+    };
+    d2_t vb[4];
+    d4_t acc[2], accn[2];
+    fetch_b(0, 0, vb);
+    load_acc(0, acc);
+    for (int jj = 0; jj < P; jj++) {
+        for (int jp = 0; jp < jj; jp++) {
+            pr8_stash(Bs, vb);
+            __syncthreads();                            // also: -X of the previous column is in place
+            fetch_b(jj, jp + 1, vb);
+            if (Pk && jp == jj - 1) pack_col(jp, Xs[jp]);
+            pr8_mma_nt(Xs[jp], Bs, acc, wr8, wc8, lane);
+            __syncthreads();
+        }
+        double *As = Xs[jj < 3 ? jj : 0];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) As[PR8_ROW(r) * SD + PR8_COL(n)] = acc[n][r];
+        pr8_stash(Bs, vb);
+        __syncthreads();
+        if (jj + 1 < P) {
+            fetch_b(jj + 1, 0, vb);
+            load_acc(jj + 1, accn);
+        }
+        d4_t x[2] = {};
+        if (wc8) pr8_mma_nt_tri_body<1, 2>(As, Bs, x, wr8, lane);
+        else pr8_mma_nt_tri_body<0, 3>(As, Bs, x, wr8, lane);
+        if (rowmajor) {
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Ai[(size_t)PR8_ROW(r) * Npad + jj * 64 + PR8_COL_TRI(n)] = x[n][r];
+        }
+        __syncthreads();
+        if (jj + 1 < P || Pk) {
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) As[PR8_ROW(r) * SD + PR8_COL_TRI(n)] = -x[n][r];
+                if (jj + 1 < P) acc[n] = accn[n];
+            }
+        }
+        if (Pk && jj + 1 == P) {
+            __syncthreads();
+            pack_col(jj, As);
+        }
+    }
+}
+
 static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,
                           hipStream_t s, const double *P = nullptr, int iend = 0)
 {
@@ -891,7 +1063,7 @@ static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, i
 // panel to the rest of the matrix once, with K = 64 P (fewer passes over the trailing matrix: large N, batches).
 static int g_chol_panel = 0;                         // 0 = choose; ibo_set_option("chol_panel", P)
 void set_chol_panel(int p) { g_chol_panel = p; }
-static int g_panel_rows = 1;                         // ibo_set_option("chol_panel_rows", 0/1): chol_panel_rows_kernel
+static int g_panel_rows = 2;                         // ibo_set_option("chol_panel_rows", 0/1/2): chol_panel_rows_kernel on four waves / chol_panel_rows8_kernel on eight
 void set_chol_panel_rows(int v) { g_panel_rows = v; }
 static int g_update2 = 1;                            // ibo_set_option("chol_update2", 0/1): packed-panel trailing update (update2.hip)
 void set_chol_update2(int v) { g_update2 = v; }
@@ -919,9 +1091,14 @@ static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
                                dstride, (double *)nullptr);
         if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s, nullptr, rows_fused ? pend : 0);
     }
-    if (rows_fused && pend < nb)
-        hipLaunchKernelGGL(chol_panel_rows_kernel, dim3(nb - pend, 1, batch), dim3(256), 0, s, L, Npad, p0, pend, diag64,
-                           lstride, dstride, Pk, pstride, rm_from);
+    if (rows_fused && pend < nb) {
+        if (g_panel_rows >= 2)
+            hipLaunchKernelGGL(chol_panel_rows8_kernel, dim3(nb - pend, 1, batch), dim3(512), 0, s, L, Npad, p0, pend, diag64,
+                               lstride, dstride, Pk, pstride, rm_from);
+        else
+            hipLaunchKernelGGL(chol_panel_rows_kernel, dim3(nb - pend, 1, batch), dim3(256), 0, s, L, Npad, p0, pend, diag64,
+                               lstride, dstride, Pk, pstride, rm_from);
+    }
     return rows_fused && pend < nb && Pk;
 }
 

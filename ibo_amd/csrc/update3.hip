@@ -57,11 +57,59 @@ __global__ __launch_bounds__(256) void chol_pack3_kernel(const double *__restric
     Pk[((((size_t)(row >> 4) * (Npad >> 3) + (col >> 3)) * 64 + lane) << 1) + h] = v;
 }
 
+// The single live row-block below the last full 128-row tile (the likelihood's y row: 1 live row, 15 of pad) against ALL of
+// the panel's column-blocks, one workgroup per matrix: wave w takes column-blocks 2 w and 2 w + 1 -- per k8-step one A and two
+// B fragments straight from the packed store (no LDS, no barrier), four MFMAs -- with the loads eight steps ahead (a wave
+// has 256 cycles of MFMA work per step, nothing like the latency of its loads).  As a 128-row tile the same block cost two
+// workgroups half a tile time each: 2 of 5 tiles of the last panel.  Same MFMAs on the same operands per element: same bits.
+__device__ __forceinline__ void u3_row_block(double *L, int Npad, int c0, int ncb, int g, const double *Pk, int wave, int lane)
+{
+    const int cbw = 2 * wave;
+    if (cbw >= ncb) return;
+    const int nk8s = Npad >> 3, K = c0;
+    const __amdgpu_buffer_rsrc_t rP = u3_rsrc(Pk, (size_t)Npad * Npad * sizeof(double));
+    const unsigned lane16 = lane * 16;
+    const bool two = cbw + 1 < ncb;
+    double *Cw = L + (size_t)(16 * g + (lane >> 4)) * Npad + c0 + 16 * cbw + (lane & 15);
+    d4_t acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[cb][r] = (cb == 0 || two) ? -Cw[(size_t)(4 * r) * Npad + 16 * cb] : 0.0;
+    const unsigned ba = (unsigned)(g * nk8s) * 1024u, bb0 = (unsigned)(((c0 >> 4) + cbw) * nk8s) * 1024u, bb1 = bb0 + (unsigned)nk8s * 1024u;
+    u3_v4 R[8][3];
+    auto fetch = [&](int j, u3_v4 (&F)[3]) {
+        F[0] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, ba + (unsigned)j * 1024u, 0);
+        F[1] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, bb0 + (unsigned)j * 1024u, 0);
+        F[2] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, bb1 + (unsigned)j * 1024u, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < 7; u++) fetch(u, R[u]);
+    for (int j = 0; j < K / 8; j += 8) {                  // K is a multiple of 64
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            fetch(j + u + 7, R[(u + 7) & 7]);              // (past K: later columns' fragments or the bounds check's zeros, never used)
+            const u3_v4 (&F)[3] = R[u];
+            acc[0] = mfma_f64(u3_lo(F[0]), u3_lo(F[1]), acc[0]);
+            acc[1] = mfma_f64(u3_lo(F[0]), u3_lo(F[2]), acc[1]);
+            acc[0] = mfma_f64(u3_hi(F[0]), u3_hi(F[1]), acc[0]);
+            acc[1] = mfma_f64(u3_hi(F[0]), u3_hi(F[2]), acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+        if (cb == 0 || two) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Cw[(size_t)(4 * r) * Npad + 16 * cb] = -acc[cb][r];
+        }
+}
+
 // C[rows >= c0][c0 .. c0 + 16 ncb) -= Pk-rows x Pk-rows^T over k < c0.  128 x 128 tiles (I, J), J < ntc, J <= I for the
 // tiles that straddle the diagonal; 8 waves = 4 (row pairs of 16-row blocks) x 2 (four column-blocks each).
 __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, int Npad, int c0, int ncb, int nlive_rb,
                                                                   const double *Pk, size_t lstride, size_t pstride,
-                                                                  int tpm, int ntc, int batch, int chunk)
+                                                                  int tpm, int ntc, int batch, int chunk, int rowtile)
 {
     __shared__ __attribute__((aligned(16))) double lds_b[2][U3_KS / 8 * 8 * 128];      // [stage][k8-step][column-block][lane][2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,6 +119,10 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
     if ((int)(blockIdx.x >> 3) >= chunk || q >= batch * tpm) return;
     const int m = q / tpm, t = q - m * tpm;
     L += (size_t)m * lstride; Pk += (size_t)m * pstride;
+    if (rowtile && t == tpm - 1) {                       // the matrix's last entry: the lone live row-block below the full tiles
+        u3_row_block(L, Npad, c0, ncb, nlive_rb - 1, Pk, wave, lane);
+        return;
+    }
     int I, J;
     if (ntc == 2) { I = (t + 1) >> 1; J = t ? (t + 1) & 1 : 0; } else { I = t; J = 0; }      // (0,0), (1,0), (1,1), (2,0), (2,1), ..
     const int wr = wave >> 1, wc = wave & 1;
@@ -213,11 +265,14 @@ int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int b
     const int nlive_rb = (nlive + 15) / 16;
     const int rows = 16 * nlive_rb - c0;                     // live rows at and below the panel's first row
     if (rows <= 0) return 0;
-    const int nrt = (rows + 127) / 128, ntc = width > 128 ? 2 : 1;
-    const int tpm = ntc == 2 ? 2 * nrt - 1 : nrt;
+    // 16 live rows below the last full tile (the likelihood's y row when N is a multiple of 128): one row-block workgroup
+    // per matrix instead of a 128-row tile per tile column
+    const int rowtile = (rows % 128 == 16 && rows > 128) ? 1 : 0;
+    const int nrt = rowtile ? rows / 128 : (rows + 127) / 128, ntc = width > 128 ? 2 : 1;
+    const int tpm = (ntc == 2 ? 2 * nrt - 1 : nrt) + rowtile;
     const long long total = (long long)tpm * batch;
     const int chunk = (int)((total + 7) / 8);
     hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)(8 * chunk)), dim3(U3_NW * 64), 0, s, L, Npad, c0, width / 16, nlive_rb, Pk,
-                       lstride, pstride, tpm, ntc, batch, chunk);
+                       lstride, pstride, tpm, ntc, batch, chunk, rowtile);
     return (int)hipGetLastError();
 }
