@@ -1719,7 +1719,9 @@ extern "C" int ibo_direct_host(objective_t objective, int ndim, const double *lb
         return 0;
     };
     ibo::DirectOptions o;
-    o.maxiter = maxiter; o.maxtime = maxtime; o.maxsample = maxsample; o.compat = compat != 0; o.per_rectangle = true;
+    // bit 1 of `compat`: the objective is called on one batch per iteration (probes + guessed child centres), the schedule
+    // the GPU objective runs under -- same (fmin, xmin, nsamples) as the per-rectangle call order (tested)
+    o.maxiter = maxiter; o.maxtime = maxtime; o.maxsample = maxsample; o.compat = (compat & 1) != 0; o.per_rectangle = (compat & 2) == 0;
     ibo::DirectResult r = ibo::direct_minimize(ev, ndim, lb, ub, o);
     if (fmin) *fmin = r.fmin;
     if (xmin) for (int i = 0; i < ndim; i++) xmin[i] = r.xmin[i];

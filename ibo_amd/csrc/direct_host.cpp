@@ -41,6 +41,11 @@ struct Pool {
     std::vector<char> alive;
     std::vector<double> cls_d;         // per class: its d
     std::vector<int> by_size;          // class numbers, ascending d
+    // per class, kept up to date by push / erase_many: the living members, the smallest y among them and the members that
+    // attain it -- all the potentially-optimal test looks at (it used to walk every rectangle twice per iteration)
+    std::vector<std::vector<int>> members, argmin;
+    std::vector<double> cls_best;
+    std::vector<int> pos;              // where rectangle j sits in members[cls[j]]
     size_t size() const { return y.size(); }
     int class_of(double dd)
     {
@@ -53,17 +58,38 @@ struct Pool {
         const int c = (int)cls_d.size();
         cls_d.push_back(dd);
         by_size.insert(by_size.begin() + lo, c);
+        members.emplace_back(); argmin.emplace_back(); cls_best.push_back(0.0);
         return c;
     }
     void push(const double *l, const double *u, const double *c, double yy, double dd)
     {
         lb.insert(lb.end(), l, l + D); ub.insert(ub.end(), u, u + D); ctr.insert(ctr.end(), c, c + D);
+        const int j = (int)y.size();
         y.push_back(yy); d.push_back(dd);
-        cls.push_back(class_of(dd)); alive.push_back(1);
+        const int k = class_of(dd);
+        cls.push_back(k); alive.push_back(1);
+        if (members[k].empty() || yy < cls_best[k]) { cls_best[k] = yy; argmin[k].assign(1, j); }
+        else if (yy == cls_best[k]) argmin[k].push_back(j);
+        pos.push_back((int)members[k].size());
+        members[k].push_back(j);
     }
     void erase_many(const std::vector<size_t> &dead)
     {
-        for (size_t j : dead) alive[j] = 0;
+        for (size_t j : dead) {
+            alive[j] = 0;
+            const int c = cls[j];
+            std::vector<int> &m = members[c];
+            m[pos[j]] = m.back(); pos[m.back()] = pos[j]; m.pop_back();
+            std::vector<int> &a = argmin[c];
+            for (size_t k = 0; k < a.size(); k++) if (a[k] == (int)j) { a.erase(a.begin() + k); break; }
+            if (a.empty() && !m.empty()) {                  // the class lost its best member(s): look again
+                double b = y[m[0]];
+                for (int k : m) if (y[k] < b) b = y[k];
+                cls_best[c] = b;
+                for (int k : m) if (y[k] == b) a.push_back(k);
+                std::sort(a.begin(), a.end());
+            }
+        }
     }
 };
 
@@ -71,12 +97,16 @@ struct Division {             // the two-phase division of one rectangle
     size_t src;
     std::vector<double> lb, ub, ctr;   // copy of the rectangle
     double y;
-    std::vector<int> dims;             // divided dimensions (probe order, then sorted)
+    std::vector<int> dims;             // divided dimensions, in probe order
+    std::vector<int> dims_probe;       // the same (plan_guess's slots are numbered by it)
     std::vector<double> probes;        // 2*dims x D unit-cube points
     std::vector<double> probe_vals;
     std::vector<double> kid_lb, kid_ub, kid_ctr, kid_d;   // 2*dims children
     std::vector<double> kid_vals;
     double mid_d;
+    // child centres guessed before the probe values are known (one GPU batch per iteration instead of two, see plan_guess)
+    std::vector<double> guess;         // 2*dims x D: (dimension dims[q], side 0 / 1) at 2 q + side
+    std::vector<double> guess_vals;
 };
 
 struct Search {
@@ -134,6 +164,47 @@ struct Search {
             }
         }
         dv.probe_vals.assign(dv.dims.size() * 2, 0.0);
+        dv.dims_probe = dv.dims;
+    }
+
+    // The child centres do not depend on the ORDER in which the longest sides are cut, although the children's boxes do:
+    // a child of side dd has the rectangle's centre in every other coordinate -- a side cut earlier has shrunk to its
+    // middle third [s1, s2] by then, whose centre s1 + (s2 - s1) / 2 is the old l + (u - l) / 2 -- and the centre of an
+    // outer third in dd.  In floating point the two expressions agree bit for bit except once in ~10^4 intervals, so the
+    // children are sampled in the SAME batch as the probes, at the centres computed here, and plan_children's real
+    // centres are compared with them afterwards: only a centre that differs in some bit is evaluated again, so every
+    // value is the objective at exactly the point the sequential search samples.
+    void plan_guess(Division &dv) const
+    {
+        const size_t m = dv.dims.size();
+        dv.guess.resize(2 * m * D);
+        for (size_t q = 0; q < m; q++) {
+            const int dd = dv.dims[q];
+            const double l = dv.lb[dd], u = dv.ub[dd], w = u - l;
+            const double s1 = l + w / 3., s2 = l + 2. * w / 3.;
+            double *g0 = &dv.guess[(2 * q) * D], *g1 = g0 + D;
+            for (int i = 0; i < D; i++) g0[i] = g1[i] = dv.ctr[i];
+            g0[dd] = l + (s1 - l) / 2.;
+            g1[dd] = s2 + (u - s2) / 2.;
+        }
+        dv.guess_vals.assign(2 * m, 0.0);
+    }
+    // after plan_children: children whose centre is the guessed one take its value; the others are appended to `redo`
+    // (as indices into dv.kid_ctr) for a second evaluation
+    void take_guess(Division &dv, std::vector<size_t> &redo) const
+    {
+        const size_t m = dv.dims.size();
+        redo.clear();
+        for (size_t q = 0; q < m; q++) {
+            const int dd = sc_order[q];
+            size_t pos = 0;
+            while (dv.dims_probe[pos] != dd) pos++;
+            for (int side = 0; side < 2; side++) {
+                const double *kc = &dv.kid_ctr[(2 * q + side) * D], *gc = &dv.guess[(2 * pos + side) * D];
+                if (std::memcmp(kc, gc, sizeof(double) * D) == 0) dv.kid_vals[2 * q + side] = dv.guess_vals[2 * pos + side];
+                else redo.push_back(2 * q + side);
+            }
+        }
     }
 
     void plan_children(Division &dv) const
@@ -234,23 +305,20 @@ void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out
     const char *alive = pool.alive.data();
     out.clear();
     const size_t C = pool.cls_d.size();
-    std::vector<double> best(C, 0.0);              // per class: smallest y among the living
-    std::vector<char> has(C, 0);
-    for (size_t j = 0; j < n; j++) {
-        if (!alive[j]) continue;
-        const int c = cls[j];
-        if (!has[c] || Y[j] < best[c]) { best[c] = Y[j]; has[c] = 1; }
-    }
-    std::vector<double> gd, gy;                    // the classes that have members, ascending d
+    std::vector<double> gd, gy;                    // the classes that have members, ascending d, and their smallest y
     std::vector<int> rank(C, -1);
+    std::vector<size_t> cand;
     for (int c : pool.by_size)
-        if (has[c]) { rank[c] = (int)gd.size(); gd.push_back(pool.cls_d[c]); gy.push_back(best[c]); }
+        if (!pool.members[c].empty()) {
+            rank[c] = (int)gd.size(); gd.push_back(pool.cls_d[c]); gy.push_back(pool.cls_best[c]);
+            for (int j : pool.argmin[c]) cand.push_back((size_t)j);
+        }
+    std::sort(cand.begin(), cand.end());           // pool order: the order the reference collects them in
     const size_t G = gd.size();
-    for (size_t j = 0; j < n; j++) {               // pool order: the order the reference collects them in
-        if (!alive[j]) continue;
+    (void)n; (void)alive;
+    for (size_t j : cand) {
         const size_t g = (size_t)rank[cls[j]];
         const double yj = Y[j], dj = Dd[j];
-        if (yj > gy[g]) continue;                  // a rectangle of the same size is better
         double maxI1 = DBL_MIN, minI2 = DBL_MAX;
         for (size_t h = 0; h < g; h++) {
             double v = (yj - gy[h]) / (dj - gd[h]);
@@ -291,17 +359,37 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
         double dd = 0.0;
         for (int i = 0; i < D; i++) { dv.ctr[i] = 0.0 + (1.0 - 0.0) / 2.; dd += (0.0 - dv.ctr[i]) * (0.0 - dv.ctr[i]); }
         double y0;
-        if ((res.status = S.evaluate(dv.ctr.data(), 1, &y0))) return res;
-        S.account(dv.ctr.data(), y0);
-        dv.y = y0; dv.mid_d = std::sqrt(dd);
-        S.plan_probes(dv);
-        if (!dv.dims.empty() && (res.status = S.evaluate(dv.probes.data(), (int)dv.dims.size() * 2, dv.probe_vals.data()))) return res;
-        S.plan_children(dv);
-        if (!dv.dims.empty() && (res.status = S.evaluate(dv.kid_ctr.data(), (int)dv.dims.size() * 2, dv.kid_vals.data()))) return res;
+        if (opt.per_rectangle) {
+            if ((res.status = S.evaluate(dv.ctr.data(), 1, &y0))) return res;
+            S.account(dv.ctr.data(), y0);
+            dv.y = y0; dv.mid_d = std::sqrt(dd);
+            S.plan_probes(dv);
+            if (!dv.dims.empty() && (res.status = S.evaluate(dv.probes.data(), (int)dv.dims.size() * 2, dv.probe_vals.data()))) return res;
+            S.plan_children(dv);
+            if (!dv.dims.empty() && (res.status = S.evaluate(dv.kid_ctr.data(), (int)dv.dims.size() * 2, dv.kid_vals.data()))) return res;
+        } else {
+            // centre, probes and guessed child centres in one batch (none of the points depends on a value)
+            S.plan_probes(dv);
+            S.plan_guess(dv);
+            const size_t c = dv.dims.size() * 2;
+            std::vector<double> p0(dv.ctr), v0(1 + 2 * c, 0.0);
+            p0.insert(p0.end(), dv.probes.begin(), dv.probes.end());
+            p0.insert(p0.end(), dv.guess.begin(), dv.guess.end());
+            if ((res.status = S.evaluate(p0.data(), (int)(1 + 2 * c), v0.data()))) return res;
+            y0 = v0[0];
+            S.account(dv.ctr.data(), y0);
+            dv.y = y0; dv.mid_d = std::sqrt(dd);
+            for (size_t q = 0; q < c; q++) { dv.probe_vals[q] = v0[1 + q]; dv.guess_vals[q] = v0[1 + c + q]; }
+            S.plan_children(dv);
+            std::vector<size_t> redo0;
+            S.take_guess(dv, redo0);
+            for (size_t k : redo0)
+                if ((res.status = S.evaluate(&dv.kid_ctr[k * D], 1, &dv.kid_vals[k]))) return res;
+        }
         S.apply(dv, pool);
     }
 
-    std::vector<size_t> pot, dead;
+    std::vector<size_t> pot, dead, redo, fix_div, fix_kid;
     std::vector<Division> divs;
     std::vector<double> pts, vals;
     bool done = false;
@@ -331,24 +419,36 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
                 if (time(nullptr) - start > opt.maxtime) { done = true; break; }
             }
         } else {
-            for (int phase = 0; phase < 2; phase++) {
-                pts.clear();
-                for (size_t qd = 0; qd < ndiv; qd++) {
-                    Division &dv = divs[qd];
-                    if (phase == 0) { S.plan_probes(dv); pts.insert(pts.end(), dv.probes.begin(), dv.probes.end()); }
-                    else { S.plan_children(dv); pts.insert(pts.end(), dv.kid_ctr.begin(), dv.kid_ctr.end()); }
+            // ONE batch per iteration: every rectangle's probes and, behind them, its guessed child centres (plan_guess)
+            pts.clear();
+            for (size_t qd = 0; qd < ndiv; qd++) {
+                Division &dv = divs[qd];
+                S.plan_probes(dv);
+                S.plan_guess(dv);
+                pts.insert(pts.end(), dv.probes.begin(), dv.probes.end());
+                pts.insert(pts.end(), dv.guess.begin(), dv.guess.end());
+            }
+            int np = (int)(pts.size() / D);
+            vals.assign(np, 0.0);
+            if (np && (res.status = S.evaluate(pts.data(), np, vals.data()))) return res;
+            size_t o = 0;
+            pts.clear(); fix_div.clear(); fix_kid.clear();
+            for (size_t qd = 0; qd < ndiv; qd++) {
+                Division &dv = divs[qd];
+                const size_t c = dv.dims.size() * 2;
+                for (size_t q = 0; q < c; q++) { dv.probe_vals[q] = vals[o + q]; dv.guess_vals[q] = vals[o + c + q]; }
+                o += 2 * c;
+                S.plan_children(dv);
+                S.take_guess(dv, redo);
+                for (size_t k : redo) {                  // a centre that differs from its guess in some bit: sampled again
+                    fix_div.push_back(qd); fix_kid.push_back(k);
+                    pts.insert(pts.end(), dv.kid_ctr.begin() + k * D, dv.kid_ctr.begin() + (k + 1) * D);
                 }
-                int np = (int)(pts.size() / D);
-                vals.assign(np, 0.0);
-                if (np && (res.status = S.evaluate(pts.data(), np, vals.data()))) return res;
-                size_t o = 0;
-                for (size_t qd = 0; qd < ndiv; qd++) {
-                    Division &dv = divs[qd];
-                    size_t c = dv.dims.size() * 2;
-                    std::vector<double> &dst = phase == 0 ? dv.probe_vals : dv.kid_vals;
-                    for (size_t q = 0; q < c; q++) dst[q] = vals[o + q];
-                    o += c;
-                }
+            }
+            if (!fix_div.empty()) {
+                vals.assign(fix_div.size(), 0.0);
+                if ((res.status = S.evaluate(pts.data(), (int)fix_div.size(), vals.data()))) return res;
+                for (size_t f = 0; f < fix_div.size(); f++) divs[fix_div[f]].kid_vals[fix_kid[f]] = vals[f];
             }
             for (size_t qd = 0; qd < ndiv; qd++) {
                 Division &dv = divs[qd];

@@ -205,9 +205,11 @@ def direct(f, bounds, args=None, debug=False, maxiter=None, maxsample=None, maxt
 
 
 def cdirect(f, bounds, args=None, maxiter=10, maxtime=10, maxsample=200000, compat=True, return_samples=False,
-            **kwargs):
+            batched=False, **kwargs):
     """native DIRECT on a Python objective (optimize.py:310-343) -> (fmin, xmin).
-    compat=True keeps the reference's dimension-0 quirk."""
+    compat=True keeps the reference's dimension-0 quirk.  batched=True runs the schedule the GPU objective
+    is evaluated under (one batch per iteration: probes plus verified guesses of the child centres); the result, the
+    point and the sample count are those of the sequential call order, only the order of the calls to f differs."""
     if args is None:
         args = []
     n = len(bounds)
@@ -222,7 +224,7 @@ def cdirect(f, bounds, args=None, maxiter=10, maxtime=10, maxsample=200000, comp
     ns = ctypes.c_int64()
     cb = _lib.OBJECTIVE(objective)
     _lib.check(_lib.lib.ibo_direct_host(cb, n, _lib.dp(lower), _lib.dp(upper), int(maxiter), int(maxtime),
-                                        int(maxsample), 1 if compat else 0, ctypes.byref(fmin), _lib.dp(xmin),
+                                        int(maxsample), (1 if compat else 0) | (2 if batched else 0), ctypes.byref(fmin), _lib.dp(xmin),
                                         ctypes.byref(ns)))
     if return_samples:
         return fmin.value, xmin, ns.value

@@ -301,7 +301,10 @@ int ibo_direct_max(ibo_gp_t *gp, int D, const double *lb, const double *ub,
 
 /* DIRECT minimisation of a HOST callback with the reference's semantics
  * (cpp/direct.cpp:329; what ego.utils.optimize.cdirect wraps), plus the sample
- * counter and the compat switch.  Host-side only: no GPU is touched. */
+ * counter and the compat switch (bit 0).  Bit 1 of `compat` selects the batched schedule ibo_direct_max runs the GPU
+ * objective under -- one evaluation batch per iteration: every potentially-optimal rectangle's probes plus its child
+ * centres, guessed before the probe values are known and verified bit for bit afterwards -- with the same
+ * (fmin, xmin, nsamples) as the sequential call order.  Host-side only: no GPU is touched. */
 int ibo_direct_host(double (*objective)(int, double *), int ndim, const double *lb, const double *ub,
                     int maxiter, int maxtime, int maxsample, int compat,
                     double *fmin, double *xmin, int64_t *nsamples);

@@ -131,6 +131,43 @@ def test_direct_grouped_selection_matches_the_all_pairs_reference(oracle):
         assert ns == ref[2] and fm == ref[0] and np.array_equal(xm, ref[1])
 
 
+def test_direct_one_batch_per_iteration_equals_the_sequential_search(oracle):
+    """the schedule ibo_direct_max runs the GPU objective under: probes and GUESSED child centres of all potentially-optimal
+    rectangles in one batch per iteration, the guesses verified bit for bit against the centres the division produces and
+    re-sampled where they differ -- same minimum, point and sample count as the sequential search, and the objective is
+    never asked for a point the sequential search does not visit (beyond the guesses that turn out wrong)"""
+    from ibo_amd.utils.optimize import cdirect
+    rs = np.random.RandomState(29)
+    cases = []
+    for D in (1, 2, 3, 4, 6, 8, 17):
+        c = rs.rand(D); w = rs.uniform(.5, 3, D); ph = rs.rand(D) * 6
+        cases.append((lambda x, c=c, w=w, ph=ph: float(np.sum(w * (x - c) ** 2) + .3 * np.sum(np.sin(9 * x + ph))), D, [[0., 1.]] * D))
+    cases.append((lambda x: float(np.round(np.sum((x - .4) ** 2), 1)), 3, [[0., 1.]] * 3))
+    cases.append((lambda x: 0.0, 2, [[0., 1.]] * 2))
+    cases.append((lambda x: float(np.sum((x - .3) ** 2)), 3, [[0., 1.], [.5, .5], [0., 1.]]))       # a fixed dimension
+    cases.append((lambda x: float(np.sum((x - .3) ** 2)), 3, [[.5, .5], [0., 1.], [0., 1.]]))       # the dimension-0 stall
+    cases.append((lambda x: float(np.sum(np.cos(7 * x))), 5, [[-3., 11.]] * 5))
+    for f, D, b in cases:
+        for maxiter, maxsample in ((1, 20000), (9, 20000), (40, 20000), (40, 300)):
+            seen_seq, seen_bat = set(), set()
+
+            def fs(x, seen=seen_seq): seen.add(x.tobytes()); return f(x)
+            def fb(x, seen=seen_bat): seen.add(x.tobytes()); return f(x)
+            a = cdirect(fs, b, maxiter=maxiter, maxsample=maxsample, return_samples=True)
+            c = cdirect(fb, b, maxiter=maxiter, maxsample=maxsample, return_samples=True, batched=True)
+            assert a[0] == c[0] and np.array_equal(a[1], c[1]) and a[2] == c[2], (D, maxiter, maxsample)
+            if maxsample > 300:
+                # every point of the sequential search is sampled; the extra ones are guesses that did not survive the check
+                assert seen_seq <= seen_bat and len(seen_bat - seen_seq) <= max(2, len(seen_seq) // 500), (len(seen_seq), len(seen_bat))
+    # the guess really is wrong now and then (that is why it is verified): count over a long search in a stretched box
+    seen_seq, seen_bat = set(), set()
+    g = lambda x: float(np.sum((x - 1.2345) ** 2))
+    a = cdirect(lambda x: (seen_seq.add(x.tobytes()), g(x))[1], [[-7.3, 11.9]] * 3, maxiter=120, maxsample=100000, return_samples=True)
+    c = cdirect(lambda x: (seen_bat.add(x.tobytes()), g(x))[1], [[-7.3, 11.9]] * 3, maxiter=120, maxsample=100000, return_samples=True, batched=True)
+    assert a[0] == c[0] and np.array_equal(a[1], c[1]) and a[2] == c[2]
+    print("DIRECT: %d distinct points, %d guessed centres re-sampled" % (len(seen_seq), len(seen_bat - seen_seq)))
+
+
 def test_direct_beyond_sixteen_dimensions_orders_ties_as_the_reference_library(oracle):
     """more than 16 longest sides: cpp/direct.cpp:194's std::sort is an introsort there, and with equal probe values the
     cut order is whatever it leaves.  The host DIRECT calls std::sort, the oracle restates libstdc++'s algorithm; both
