@@ -149,12 +149,83 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
     return (int)hipGetLastError();
 }
 
+// The likelihood grid's covariance pass: lower part of K(X, X) + noise I for `batch` parameter sets, one launch.
+// 32 x 128 entries per workgroup (2 x 8 per thread), workgroups numbered over the tiles that touch the lower triangle only
+// (a 2-D grid would dispatch as many dead workgroups as live ones), a row's 128 columns leave in eight consecutive 128-byte
+// stores -- 1 KiB per row and tile: with 64 x 64 tiles (512-byte row segments) the 4.3 GB of a 64-matrix grid went out at
+// 1.7 TB/s.  Scaled coordinates, exp_fast / sqrt_fast as cov_matrix_kernel<true>.
+__global__ __launch_bounds__(256) void cov_grid_kernel(const KParams *__restrict__ kps, int n, const double *__restrict__ X, int ldp,
+                                                       double noise, double *__restrict__ K, int ldk, size_t kstride)
+{
+    __shared__ double As[32 * COV_LD];
+    __shared__ double Bs[128 * COV_LD];
+    const KParams &kp = kps[blockIdx.z];
+    K += blockIdx.z * kstride;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, D = kp.D;
+    // tile (I, J): rows 32 I .., columns 128 J ..; row I has I / 4 + 1 tiles; rows 4 a .. 4 a + 3 start at 2 a (a + 1)
+    const int q = blockIdx.x;
+    int a = (int)((sqrt(1.0 + 2.0 * (double)q) - 1.0) * 0.5);
+    while (2 * (a + 1) * (a + 2) <= q) a++;
+    while (2 * a * (a + 1) > q) a--;
+    const int rem = q - 2 * a * (a + 1);
+    const int I = 4 * a + rem / (a + 1), J = rem % (a + 1);
+    const int i0 = 32 * I, j0 = 128 * J;
+    if (i0 >= n) return;
+    for (int e = t; e < 32 * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        As[r * COV_LD + d] = (i0 + r < n) ? X[(size_t)(i0 + r) * ldp + d] * kp.sw[d] : 0.0;
+    }
+    for (int e = t; e < 128 * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        Bs[r * COV_LD + d] = (j0 + r < n) ? X[(size_t)(j0 + r) * ldp + d] * kp.sw[d] : 0.0;
+    }
+    __syncthreads();
+    double z[2][8] = {};
+    for (int d = 0; d < D; d++) {
+        double av[2], bv[8];
+#pragma unroll
+        for (int r = 0; r < 2; r++) av[r] = As[(ty * 2 + r) * COV_LD + d];
+#pragma unroll
+        for (int c = 0; c < 8; c++) bv[c] = Bs[(tx + 16 * c) * COV_LD + d];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const double u = av[r] - bv[c];
+                z[r][c] = fma(u, u, z[r][c]);
+            }
+    }
+    const double log_sf2 = log(kp.sf2);
+    const int fam = kp.family;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int i = i0 + ty * 2 + r;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int j = j0 + tx + 16 * c;
+            if (i < n && j < n && j <= (i | 63)) {         // the 64 x 64 blocks on and below the diagonal, as the factorisation reads them
+                double v = fam == FAM_SE ? cov_from_z_fast<FAM_SE>(z[r][c], log_sf2, kp.sf2)
+                           : (fam == FAM_M3 ? cov_from_z_fast<FAM_M3>(z[r][c], log_sf2, kp.sf2) : cov_from_z_fast<FAM_M5>(z[r][c], log_sf2, kp.sf2));
+                if (i == j) v = kp.sf2 + noise;            // k(x, x) + noise, exactly
+                K[(size_t)i * ldk + j] = v;
+            }
+        }
+    }
+}
+
 // `batch` square covariance matrices K(A1, A1) (lower blocks only), parameters kps_dev[z] (device), outputs kstride doubles apart
 int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const double *A1, int ldp, int diag_rule, double noise,
                               double *K, int ldk, size_t kstride, hipStream_t s, int fast)
 {
     dim3 grid((n1 + 63) / 64, (n1 + 63) / 64, batch);
     KParams dummy = KParams();
+    if (fast && diag_rule == 1) {
+        const int nI = (n1 + 31) / 32;                   // tiles: sum over rows I of I / 4 + 1
+        long ntile = 0;
+        for (int I = 0; I < nI; I++) ntile += I / 4 + 1;
+        hipLaunchKernelGGL(cov_grid_kernel, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
+        return (int)hipGetLastError();
+    }
     if (fast)
         hipLaunchKernelGGL(cov_matrix_kernel<true>, grid, dim3(256), 0, s, dummy, n1, A1, n1, A1, ldp, 1, diag_rule, noise, K, ldk,
                            (double *)nullptr, 0, 1, (double *)nullptr, (int *)nullptr, kps_dev, kstride);
@@ -957,6 +1028,29 @@ __device__ __forceinline__ void pr8_mma_nt_tri_body(const double *As, const doub
         acc[1] = mfma_f64(a[k4], b1[k4], acc[1]);
     }
 }
+// the same product with the fragments read as they are used (the preloading version holds up to 96 VGPRs of fragments: too
+// many beside four column blocks of accumulators at four waves per SIMD)
+template <int CB0, int CB1>
+__device__ __forceinline__ void pr8_mma_nt_tri_stream(const double *As, const double *Bs, d4_t (&acc)[2], int wr8, int lane)
+{
+    const double *ap = As + (wr8 * 16 + (lane & 15)) * SD + (lane >> 4);
+    const double *b0p = Bs + (CB0 * 16 + (lane & 15)) * SD + (lane >> 4), *b1p = Bs + (CB1 * 16 + (lane & 15)) * SD + (lane >> 4);
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4 += 4) {
+        double a[4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] = ap[(k4 + u) * 4];
+            if (k4 + u < 4 * (CB0 + 1)) b0[u] = b0p[(k4 + u) * 4];
+            b1[u] = b1p[(k4 + u) * 4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k4 + u < 4 * (CB0 + 1)) acc[0] = mfma_f64(a[u], b0[u], acc[0]);
+            acc[1] = mfma_f64(a[u], b1[u], acc[1]);
+        }
+    }
+}
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void chol_panel_rows8_kernel(double *L, int Npad, int p0, int pend, const double *__restrict__ diag64, size_t lstride,
                              size_t dstride, double *__restrict__ Pk, size_t pstride, int rm_from)
@@ -1040,6 +1134,95 @@ void chol_panel_rows8_kernel(double *L, int Npad, int p0, int pend, const double
     }
 }
 
+// The row block's panel RIGHT-LOOKING inside the workgroup: all P column blocks' accumulators stay in registers (16 VGPRs per
+// block and wave), and as soon as column jj's X_jj = (block) inv(L_jj)^T is formed it is applied to the later columns,
+// acc_j'' -= X_jj L_j''jj^T.  Only the current X sits in LDS (one 64 x 64 stage for it, one for the operand block), 66 KB
+// instead of 133: TWO workgroups per CU, so one's barriers and operand fetches hide behind the other's MFMAs.  Every element
+// still receives the updates of columns 0, 1, .. in that order, each as 16 ascending k4-steps: identical bits.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void chol_panel_rows8r_kernel(double *L, int Npad, int p0, int pend, const double *__restrict__ diag64, size_t lstride,
+                              size_t dstride, double *__restrict__ Pk, size_t pstride, int rm_from)
+{
+    __shared__ double Xc[64 * SD];
+    __shared__ double Bs[64 * SD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr8 = wv >> 1, wc8 = wv & 1;
+    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride;
+    if (Pk) Pk += blockIdx.z * pstride;
+    const int i = pend + blockIdx.x, P = pend - p0;
+    const bool rowmajor = !Pk || i >= rm_from;
+    double *Ai = L + (size_t)i * 64 * Npad + (size_t)p0 * 64;
+    // operand blocks in the order they are used: for jj = 0 .. P-1: inv(L_{p0+jj}), then L_{p0+j2, p0+jj} for j2 = jj+1 .. P-1
+    auto fetch_b = [&](int jj, int j2, d2_t (&vb)[4]) {
+        if (j2 > jj) pr8_fetch(L + (size_t)(p0 + j2) * 64 * Npad + (size_t)(p0 + jj) * 64, Npad, vb);
+        else pr8_fetch(diag64 + (size_t)(p0 + jj) * 4096, 64, vb);
+    };
+    auto pack_col = [&](int jj, const double *Xm) {       // column jj (held as -X in Xm) into the packed store (chol_panel_rows8_kernel)
+        const int g = wv >> 1, nk8 = Npad >> 3;
+        double *dst = Pk + (((size_t)(i * 4 + g) * nk8 + (size_t)(p0 + jj) * 8 + 4 * (wv & 1)) * 64 + lane) * 2;
+        const double *src = Xm + (16 * g + (lane & 15)) * SD + 32 * (wv & 1) + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d2_t v;
+            v.x = -src[8 * j]; v.y = -src[8 * j + 4];
+            *(d2_t *)(dst + (size_t)j * 128) = v;
+        }
+    };
+    d2_t vb[4];
+    d4_t acc[4][2];                                       // P <= 4 column blocks of this wave's 16 x 32 piece
+    fetch_b(0, 0, vb);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (c < P) {
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[c][n][r] = Ai[(size_t)PR8_ROW(r) * Npad + c * 64 + PR8_COL(n)];
+        }
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        if (jj >= P) break;
+        // X_jj = acc_jj inv(L_jj)^T
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Xc[PR8_ROW(r) * SD + PR8_COL(n)] = acc[jj][n][r];
+        pr8_stash(Bs, vb);
+        __syncthreads();
+        if (jj + 1 < P) fetch_b(jj, jj + 1, vb); 
+        d4_t x[2] = {};
+        if (wc8) pr8_mma_nt_tri_stream<1, 2>(Xc, Bs, x, wr8, lane);
+        else pr8_mma_nt_tri_stream<0, 3>(Xc, Bs, x, wr8, lane);
+        if (rowmajor) {
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Ai[(size_t)PR8_ROW(r) * Npad + jj * 64 + PR8_COL_TRI(n)] = x[n][r];
+        }
+        __syncthreads();                                  // everybody has read Xc and Bs
+        if (jj + 1 < P || Pk) {
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Xc[PR8_ROW(r) * SD + PR8_COL_TRI(n)] = -x[n][r];
+        }
+        // the later columns take column jj's update: acc_j2 -= X_jj L_{j2,jj}^T
+#pragma unroll
+        for (int j2 = 1; j2 < 4; j2++) {
+            if (j2 <= jj || j2 >= P) continue;
+            pr8_stash(Bs, vb);
+            __syncthreads();                              // also: -X_jj is in place
+            if (j2 + 1 < P) fetch_b(jj, j2 + 1, vb); else fetch_b(jj + 1, jj + 1, vb);
+            if (Pk && j2 == jj + 1) pack_col(jj, Xc);
+            pr8_mma_nt(Xc, Bs, acc[j2], wr8, wc8, lane);
+            __syncthreads();
+        }
+        if (Pk && jj + 1 == P) {                          // the last column: nobody packs it later
+            __syncthreads();
+            pack_col(jj, Xc);
+        }
+    }
+}
+
 static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,
                           hipStream_t s, const double *P = nullptr, int iend = 0)
 {
@@ -1063,7 +1246,7 @@ static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, i
 // panel to the rest of the matrix once, with K = 64 P (fewer passes over the trailing matrix: large N, batches).
 static int g_chol_panel = 0;                         // 0 = choose; ibo_set_option("chol_panel", P)
 void set_chol_panel(int p) { g_chol_panel = p; }
-static int g_panel_rows = 2;                         // ibo_set_option("chol_panel_rows", 0/1/2): chol_panel_rows_kernel on four waves / chol_panel_rows8_kernel on eight
+static int g_panel_rows = 3;                         // ibo_set_option("chol_panel_rows", 0/1/2): chol_panel_rows_kernel on four waves / chol_panel_rows8_kernel on eight / 3: chol_panel_rows8r_kernel, right-looking inside the workgroup, two workgroups per CU
 void set_chol_panel_rows(int v) { g_panel_rows = v; }
 static int g_update2 = 1;                            // ibo_set_option("chol_update2", 0/1): packed-panel trailing update (update2.hip)
 void set_chol_update2(int v) { g_update2 = v; }
@@ -1092,7 +1275,10 @@ static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
         if (jb + 1 < pend) launch_update(L, Npad, jb, jb + 1, jb + 1, pend, batch, lstride, s, nullptr, rows_fused ? pend : 0);
     }
     if (rows_fused && pend < nb) {
-        if (g_panel_rows >= 2)
+        if (g_panel_rows >= 3)
+            hipLaunchKernelGGL(chol_panel_rows8r_kernel, dim3(nb - pend, 1, batch), dim3(512), 0, s, L, Npad, p0, pend, diag64,
+                               lstride, dstride, Pk, pstride, rm_from);
+        else if (g_panel_rows >= 2)
             hipLaunchKernelGGL(chol_panel_rows8_kernel, dim3(nb - pend, 1, batch), dim3(512), 0, s, L, Npad, p0, pend, diag64,
                                lstride, dstride, Pk, pstride, rm_from);
         else
