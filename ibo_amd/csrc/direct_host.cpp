@@ -305,16 +305,28 @@ void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out
     const char *alive = pool.alive.data();
     out.clear();
     const size_t C = pool.cls_d.size();
-    std::vector<double> gd, gy;                    // the classes that have members, ascending d, and their smallest y
-    std::vector<int> rank(C, -1);
-    std::vector<size_t> cand;
+    // (scratch kept between calls: this runs once per iteration of every search)
+    static thread_local std::vector<double> gd, gy, sufmin;    // the classes that have members, ascending d; their smallest y; min of gy beyond
+    static thread_local std::vector<int> rank;
+    static thread_local std::vector<size_t> cand;
+    gd.clear(); gy.clear(); cand.clear();
+    rank.assign(C, -1);
     for (int c : pool.by_size)
-        if (!pool.members[c].empty()) {
-            rank[c] = (int)gd.size(); gd.push_back(pool.cls_d[c]); gy.push_back(pool.cls_best[c]);
-            for (int j : pool.argmin[c]) cand.push_back((size_t)j);
-        }
-    std::sort(cand.begin(), cand.end());           // pool order: the order the reference collects them in
+        if (!pool.members[c].empty()) { rank[c] = (int)gd.size(); gd.push_back(pool.cls_d[c]); gy.push_back(pool.cls_best[c]); }
     const size_t G = gd.size();
+    // A rectangle is rejected as soon as some LARGER class holds a value <= its own (the slope to it is <= 0: minI2 <= 0).
+    // With the minimum of gy over the larger classes at hand that is one comparison, and it removes all but the few classes on
+    // the descending staircase before any slope is formed -- the same decisions as forming them all (a quotient with a positive
+    // denominator is <= 0 exactly when its numerator is).  NaN values fall through to the full test.
+    sufmin.assign(G + 1, DBL_MAX);
+    for (size_t h = G; h-- > 0;) sufmin[h] = (gy[h] < sufmin[h + 1] || gy[h] != gy[h]) ? gy[h] : sufmin[h + 1];
+    for (int c : pool.by_size) {
+        if (pool.members[c].empty()) continue;
+        const size_t g = (size_t)rank[c];
+        if (g + 1 < G && sufmin[g + 1] <= gy[g]) continue;      // every member of the class fails the minI2 test
+        for (int j : pool.argmin[c]) cand.push_back((size_t)j);
+    }
+    std::sort(cand.begin(), cand.end());           // pool order: the order the reference collects them in
     (void)n; (void)alive;
     for (size_t j : cand) {
         const size_t g = (size_t)rank[cls[j]];
