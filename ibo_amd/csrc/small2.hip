@@ -136,6 +136,121 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
     }
 }
 
+// kstar_small_kernel and wk_small_kernel in ONE launch: every (tile, 16-row block g of W) workgroup generates the k* rows its
+// row-block multiplies -- rows < 16 g + 16, a 128-row stage at a time, all 16 waves one 16 x 16 tile each, into a
+// double-buffered LDS stage -- and wave w consumes the stage's 8-column step w straight from LDS.  k* is regenerated by
+// every row-block's workgroup (on average N / 32 times), which costs each of them a microsecond or two of exp() spread over
+// 1024 threads, but a DIRECT batch of a few dozen points is bound by its launches, not its arithmetic: one launch and the
+// trip of k* through HBM less per batch (maximizeEI runs ~50 dependent batches).  The workgroups of the LAST row-block see
+// every stage and also write the stages' parts of the two mean dot products.  Same MFMAs on the same operands, same order of
+// every sum as the two-kernel path: identical values.
+template <int FAM, int KA4>
+__global__ __launch_bounds__(SM_NW * 64) void wkf_small_kernel(InlineCand ic, SweepArgs a, double *__restrict__ qpart, double *__restrict__ mupart,
+                                                               int Mp, int inlined)
+{
+    constexpr int KA = 4 * KA4;
+    __shared__ double lds_c[SM_TC * (KA + 1)];
+    __shared__ double lds_tab[2048];
+    __shared__ double lds_al[2][128];
+    __shared__ double lds_m[2][SM_NW][16];
+    __shared__ double lds_k[2][32 * 2 * 64];          // [buffer][k4-step of the stage][cand-block][lane]; afterwards the partial V tiles
+    __shared__ double lds_s[SM_TC][17];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ctile = blockIdx.x, g = gridDim.y - 1 - blockIdx.y;       // the longest rows of W first
+    const int Npad = a.Npad, nk8 = Npad >> 3;
+    const int nsteps = 2 * g + 2, nst = (nsteps + 15) >> 4;
+    const bool means = g == (int)gridDim.y - 1;
+    lds_tab[tid] = a.exp_tab[tid];
+    lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
+    s2_stage_candidates<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)ctile * SM_TC, lds_c,
+                                                    inlined ? (const double *)__builtin_amdgcn_kernarg_segment_ptr() : nullptr);
+    const int rt = wave >> 1, gcb = wave & 1;
+    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * (KA + 1) + (lane >> 4)];
+    const double2 *Wp2 = (const double2 *)a.Wp + (size_t)g * nk8 * 64 + lane;
+    d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // operands of a stage are requested one stage ahead (X fragments, this wave's W fragments, the alpha window): their L2
+    // round trip would otherwise sit in front of every stage's exp() and barrier
+    double xan[KA4];
+    double2 avn = {0.0, 0.0};
+    double aln0 = 0.0, aln1 = 0.0;
+    auto request = [&](int t) {
+        const int tile = t * 8 + rt, j = 16 * t + wave;
+        const double *xa = a.XA + (size_t)tile * KA4 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KA4; s++) xan[s] = xa[s * 64];
+        avn = (j < nsteps) ? Wp2[(size_t)j * 64] : double2{0.0, 0.0};
+        if (means && tid < 128) { aln0 = a.alphaY[t * 128 + tid]; aln1 = a.alpha1[t * 128 + tid]; }
+    };
+    request(0);
+    for (int t = 0; t < nst; t++) {
+        const int j = 16 * t + wave;                   // this wave's 8-column step of the stage
+        double xa[KA4];
+#pragma unroll
+        for (int s = 0; s < KA4; s++) xa[s] = xan[s];
+        const double2 av = avn;
+        if (means && tid < 128) { lds_al[0][tid] = aln0; lds_al[1][tid] = aln1; }
+        if (t + 1 < nst) request(t + 1);
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KA4; s++) y = mfma_f64(xa[s], cfrag[4 * s], y);
+        double *dst = &lds_k[t & 1][((rt * 4) * 2 + gcb) * 64 + lane];
+        double kv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            kv[r] = s2_kstar<FAM>(y[r], a.kp.sf2, lds_tab);
+            dst[r * 128] = kv[r];
+        }
+        __syncthreads();                               // the stage (and its alpha window) is in LDS; the other buffer's readers are done
+        if (means) {
+            double muY = 0.0, mu1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kl = rt * 16 + 4 * r + (lane >> 4);
+                muY = fma(lds_al[0][kl], kv[r], muY);
+                mu1 = fma(lds_al[1][kl], kv[r], mu1);
+            }
+            muY += __shfl_xor(muY, 16); muY += __shfl_xor(muY, 32);
+            mu1 += __shfl_xor(mu1, 16); mu1 += __shfl_xor(mu1, 32);
+            if (lane < 16) { lds_m[0][wave][lane] = muY; lds_m[1][wave][lane] = mu1; }
+        }
+        if (j < nsteps) {
+            const double *kb = &lds_k[t & 1][(4 * wave) * 64 + lane];       // k4-steps 2 w, 2 w + 1 of the stage: ((2 w) 2 + cb) 64
+            acc0 = mfma_f64(av.x, kb[0], acc0); acc1 = mfma_f64(av.x, kb[64], acc1);
+            acc0 = mfma_f64(av.y, kb[128], acc0); acc1 = mfma_f64(av.y, kb[192], acc1);
+        }
+        if (means) {
+            __syncthreads();
+            if (tid < 2 * SM_TC) {
+                const int which = tid >> 5, c = tid & 31;
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < SM_NW / 2; w++) s += lds_m[which][2 * w + (c >> 4)][c & 15];
+                mupart[(size_t)(t * 2 + which) * Mp + ctile * SM_TC + c] = s;
+            }
+        }
+    }
+    __syncthreads();                                   // everybody has read the last stage: its LDS becomes the partial V tiles
+    double *lds_v = &lds_k[0][0];                      // [wave][cand-block][lane 64 x 4]: 16 x 2 x 256 doubles = both buffers exactly
+#pragma unroll
+    for (int r = 0; r < 4; r++) { lds_v[(wave * 2 + 0) * 256 + lane * 4 + r] = acc0[r]; lds_v[(wave * 2 + 1) * 256 + lane * 4 + r] = acc1[r]; }
+    __syncthreads();
+    if (tid < 512) {
+        const int cb = tid >> 8, e = tid & 255, l = e >> 2, r = e & 3;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_NW; w++) v += lds_v[(w * 2 + cb) * 256 + e];
+        lds_s[16 * cb + (l & 15)][(l >> 4) + 4 * r] = v * v;
+    }
+    __syncthreads();
+    if (tid < SM_TC) {
+        double q = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) q += lds_s[tid][rr];
+        qpart[(size_t)g * Mp + ctile * SM_TC + tid] = q;
+    }
+}
+
 // one thread per candidate: q over the row-blocks, the mean parts over the stages (index order), the acquisition
 __global__ __launch_bounds__(64) void small_finish_kernel(SweepArgs a, const double *__restrict__ qpart, const double *__restrict__ mupart, int Mp,
                                                           int nrb, int nst)
@@ -212,6 +327,32 @@ static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, in
     return (int)hipGetLastError();
 }
 
+static int g_small_fused = 1;                        // ibo_set_option("small_fused", 0/1): wkf_small_kernel instead of kstar + wk
+void set_small_fused(int v) { g_small_fused = v; }
+
+template <int FAM>
+static int launch_wkf_small(const SweepArgs &a, double *qpart, double *mupart, int Mp, dim3 grid, hipStream_t s)
+{
+    InlineCand ic;
+    int inl = 0;
+    if (a.cand_host && a.M * a.kp.D <= SM_INLINE && g_small_inline) {
+        memcpy(ic.v, a.cand_host, sizeof(double) * (size_t)(a.M * a.kp.D));
+        inl = 1;
+    }
+    switch ((a.kp.D + 2 + 3) / 4) {
+    case 1: hipLaunchKernelGGL((wkf_small_kernel<FAM, 1>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 2: hipLaunchKernelGGL((wkf_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 3: hipLaunchKernelGGL((wkf_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 4: hipLaunchKernelGGL((wkf_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 5: hipLaunchKernelGGL((wkf_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 6: hipLaunchKernelGGL((wkf_small_kernel<FAM, 6>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 7: hipLaunchKernelGGL((wkf_small_kernel<FAM, 7>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 8: hipLaunchKernelGGL((wkf_small_kernel<FAM, 8>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    default: hipLaunchKernelGGL((wkf_small_kernel<FAM, 9>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    }
+    return (int)hipGetLastError();
+}
+
 // doubles of workspace: Kf (Mp NA128) + qpart (Npad/16 Mp) + mupart (2 NA128/128 Mp), Mp = M rounded up to 32
 size_t small_sweep_workspace(int Npad, int64_t M)
 {
@@ -226,12 +367,24 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     double *Kf = ws, *qpart = Kf + (size_t)Mp * NA128, *mupart = qpart + (size_t)nrb * Mp;
     if (e0) (void)hipEventRecord(e0, s);
     int rc;
-    const dim3 g1(ctiles, nst);
-    if (a.kp.family == FAM_SE) rc = launch_kstar_small<FAM_SE>(a, Kf, mupart, Mp, g1, s);
-    else if (a.kp.family == FAM_M3) rc = launch_kstar_small<FAM_M3>(a, Kf, mupart, Mp, g1, s);
-    else rc = launch_kstar_small<FAM_M5>(a, Kf, mupart, Mp, g1, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(wk_small_kernel, dim3(ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
+    // small models (at most two 128-row stages) and few tiles: one launch in which every row-block's workgroup makes its own
+    // k*.  Measured (maximizeEI, ~53 batches of ~47 points): N = 64 1.50 -> 1.36 ms; but N = 1024 1.85 -> 2.15 ms and
+    // N = 2048 2.38 -> 3.2 ms -- the fused workgroup walks its stages one after the other (MFMA chain, exp chains, a barrier
+    // each: ~0.6 us per stage) where the separate k* kernel has a workgroup per stage working side by side.
+    if (g_small_fused && ctiles <= 8 && (nst <= 2 || g_small_fused > 1)) {
+        const dim3 gf(ctiles, nrb);
+        if (a.kp.family == FAM_SE) rc = launch_wkf_small<FAM_SE>(a, qpart, mupart, Mp, gf, s);
+        else if (a.kp.family == FAM_M3) rc = launch_wkf_small<FAM_M3>(a, qpart, mupart, Mp, gf, s);
+        else rc = launch_wkf_small<FAM_M5>(a, qpart, mupart, Mp, gf, s);
+        if (rc) return rc;
+    } else {
+        const dim3 g1(ctiles, nst);
+        if (a.kp.family == FAM_SE) rc = launch_kstar_small<FAM_SE>(a, Kf, mupart, Mp, g1, s);
+        else if (a.kp.family == FAM_M3) rc = launch_kstar_small<FAM_M3>(a, Kf, mupart, Mp, g1, s);
+        else rc = launch_kstar_small<FAM_M5>(a, Kf, mupart, Mp, g1, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wk_small_kernel, dim3(ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
+    }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a.M + 63) / 64;
     hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(64), 0, s, a, qpart, mupart, Mp, nrb, nst);
