@@ -301,7 +301,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "gemv_max")) { g_gemv_max = value; return IBO_OK; }
     if (key && !strcmp(key, "flag_poll")) { g_flag_poll = value; return IBO_OK; }
     if (key && !strcmp(key, "small_inline")) { set_small_inline(value); return IBO_OK; }
-    if (key && !strcmp(key, "small_fused")) { set_small_fused(value); return IBO_OK; }
+    if (key && !strcmp(key, "small_local")) { set_small_local(value); return IBO_OK; }
     if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }

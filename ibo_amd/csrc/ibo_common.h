@@ -204,7 +204,7 @@ int launch_sweep2_refresh(const SweepArgs &a, int row_first, int row_last, hipSt
 bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);
 void set_small_inline(int v);
-void set_small_fused(int v);         // small batches: k* generation inside the W K* kernel (one launch less per batch)        // the gallery's refresh kernel keeps whole vectors in LDS (N <= ~5500)
+void set_small_local(int v);         // small batches: every wave makes the k* it multiplies, one launch for k* and W K* (small2.hip)
 // small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
 int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 size_t small_sweep_workspace(int Npad, int64_t M);      // its LDS budget holds both alpha vectors (N <= ~5000)

@@ -136,111 +136,92 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
     }
 }
 
-// kstar_small_kernel and wk_small_kernel in ONE launch: every (tile, 16-row block g of W) workgroup generates the k* rows its
-// row-block multiplies -- rows < 16 g + 16, a 128-row stage at a time, all 16 waves one 16 x 16 tile each, into a
-// double-buffered LDS stage -- and wave w consumes the stage's 8-column step w straight from LDS.  k* is regenerated by
-// every row-block's workgroup (on average N / 32 times), which costs each of them a microsecond or two of exp() spread over
-// 1024 threads, but a DIRECT batch of a few dozen points is bound by its launches, not its arithmetic: one launch and the
-// trip of k* through HBM less per batch (maximizeEI runs ~50 dependent batches).  The workgroups of the LAST row-block see
-// every stage and also write the stages' parts of the two mean dot products.  Same MFMAs on the same operands, same order of
-// every sum as the two-kernel path: identical values.
+// WAVE-LOCAL k*: the exponent GEMM's output layout (lane l: row (l>>4) + 4 r, candidate l & 15) IS the B-fragment layout of the
+// product that follows, so a wave can make the k* of a 16-row tile and multiply it with its W fragments without anything
+// leaving its registers -- no LDS stage, no barrier, no trip of k* through memory.  Workgroup (tile, row-block g): wave w takes
+// the 16-row tiles rt = w, w + 16, .. <= g of both candidate blocks; per tile 2 (KA4 + 4) MFMAs and 8 exp() per lane, the next
+// tile's fragments of X and W requested while this one is computed.  k* is regenerated by every row-block (N / 32 times on
+// average) but a DIRECT batch is bound by its launches: one launch instead of two, ~4 us of kernel instead of 6 + 9 at N = 1024.
+// The last row-block's workgroups see every row and also form the two mean dot products (one part per tile: nst = 1 for the
+// finish kernel).  Sums run in a fixed order (tiles ascending per wave, waves ascending): deterministic.
 template <int FAM, int KA4>
-__global__ __launch_bounds__(SM_NW * 64) void wkf_small_kernel(InlineCand ic, SweepArgs a, double *__restrict__ qpart, double *__restrict__ mupart,
+__global__ __launch_bounds__(SM_NW * 64) void wkl_small_kernel(InlineCand ic, SweepArgs a, double *__restrict__ qpart, double *__restrict__ mupart,
                                                                int Mp, int inlined)
 {
     constexpr int KA = 4 * KA4;
     __shared__ double lds_c[SM_TC * (KA + 1)];
     __shared__ double lds_tab[2048];
-    __shared__ double lds_al[2][128];
-    __shared__ double lds_m[2][SM_NW][16];
-    __shared__ double lds_k[2][32 * 2 * 64];          // [buffer][k4-step of the stage][cand-block][lane]; afterwards the partial V tiles
+    __shared__ double lds_v[SM_NW][2][256];          // partial V tiles: [wave][cand-block][lane 64 x 4]
     __shared__ double lds_s[SM_TC][17];
+    __shared__ double lds_m[2][SM_NW][2][16];        // partial means [which][wave][cand-block][cand]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ctile = blockIdx.x, g = gridDim.y - 1 - blockIdx.y;       // the longest rows of W first
-    const int Npad = a.Npad, nk8 = Npad >> 3;
-    const int nsteps = 2 * g + 2, nst = (nsteps + 15) >> 4;
+    const int nk8 = a.Npad >> 3;
     const bool means = g == (int)gridDim.y - 1;
     lds_tab[tid] = a.exp_tab[tid];
     lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
     s2_stage_candidates<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)ctile * SM_TC, lds_c,
                                                     inlined ? (const double *)__builtin_amdgcn_kernarg_segment_ptr() : nullptr);
-    const int rt = wave >> 1, gcb = wave & 1;
-    const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * (KA + 1) + (lane >> 4)];
+    const double *cfrag0 = &lds_c[(lane & 15) * (KA + 1) + (lane >> 4)], *cfrag1 = cfrag0 + 16 * (KA + 1);
     const double2 *Wp2 = (const double2 *)a.Wp + (size_t)g * nk8 * 64 + lane;
     d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    // operands of a stage are requested one stage ahead (X fragments, this wave's W fragments, the alpha window): their L2
-    // round trip would otherwise sit in front of every stage's exp() and barrier
-    double xan[KA4];
-    double2 avn = {0.0, 0.0};
-    double aln0 = 0.0, aln1 = 0.0;
-    auto request = [&](int t) {
-        const int tile = t * 8 + rt, j = 16 * t + wave;
-        const double *xa = a.XA + (size_t)tile * KA4 * 64 + lane;
+    double mY0 = 0.0, mY1 = 0.0, m10 = 0.0, m11 = 0.0;
+    double xan[KA4], aYn[4], a1n[4];
+    double2 w0n = {0.0, 0.0}, w1n = {0.0, 0.0};
+    auto request = [&](int rt) {
+        const double *xa = a.XA + (size_t)rt * KA4 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KA4; s++) xan[s] = xa[s * 64];
-        avn = (j < nsteps) ? Wp2[(size_t)j * 64] : double2{0.0, 0.0};
-        if (means && tid < 128) { aln0 = a.alphaY[t * 128 + tid]; aln1 = a.alpha1[t * 128 + tid]; }
+        w0n = Wp2[(size_t)(2 * rt) * 64];
+        w1n = Wp2[(size_t)(2 * rt + 1) * 64];
+        if (means) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { aYn[r] = a.alphaY[16 * rt + 4 * r + (lane >> 4)]; a1n[r] = a.alpha1[16 * rt + 4 * r + (lane >> 4)]; }
+        }
     };
-    request(0);
-    for (int t = 0; t < nst; t++) {
-        const int j = 16 * t + wave;                   // this wave's 8-column step of the stage
-        double xa[KA4];
+    if (wave <= g) request(wave);
+    for (int rt = wave; rt <= g; rt += SM_NW) {
+        double xa[KA4], aY[4], a1v[4];
 #pragma unroll
         for (int s = 0; s < KA4; s++) xa[s] = xan[s];
-        const double2 av = avn;
-        if (means && tid < 128) { lds_al[0][tid] = aln0; lds_al[1][tid] = aln1; }
-        if (t + 1 < nst) request(t + 1);
-        d4_t y = {0.0, 0.0, 0.0, 0.0};
+        const double2 w0 = w0n, w1 = w1n;
 #pragma unroll
-        for (int s = 0; s < KA4; s++) y = mfma_f64(xa[s], cfrag[4 * s], y);
-        double *dst = &lds_k[t & 1][((rt * 4) * 2 + gcb) * 64 + lane];
-        double kv[4];
+        for (int r = 0; r < 4; r++) { aY[r] = aYn[r]; a1v[r] = a1n[r]; }
+        if (rt + SM_NW <= g) request(rt + SM_NW);
+        d4_t y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KA4; s++) { y0 = mfma_f64(xa[s], cfrag0[4 * s], y0); y1 = mfma_f64(xa[s], cfrag1[4 * s], y1); }
+        const double wk[4] = {w0.x, w0.y, w1.x, w1.y};
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            kv[r] = s2_kstar<FAM>(y[r], a.kp.sf2, lds_tab);
-            dst[r * 128] = kv[r];
-        }
-        __syncthreads();                               // the stage (and its alpha window) is in LDS; the other buffer's readers are done
-        if (means) {
-            double muY = 0.0, mu1 = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int kl = rt * 16 + 4 * r + (lane >> 4);
-                muY = fma(lds_al[0][kl], kv[r], muY);
-                mu1 = fma(lds_al[1][kl], kv[r], mu1);
-            }
-            muY += __shfl_xor(muY, 16); muY += __shfl_xor(muY, 32);
-            mu1 += __shfl_xor(mu1, 16); mu1 += __shfl_xor(mu1, 32);
-            if (lane < 16) { lds_m[0][wave][lane] = muY; lds_m[1][wave][lane] = mu1; }
-        }
-        if (j < nsteps) {
-            const double *kb = &lds_k[t & 1][(4 * wave) * 64 + lane];       // k4-steps 2 w, 2 w + 1 of the stage: ((2 w) 2 + cb) 64
-            acc0 = mfma_f64(av.x, kb[0], acc0); acc1 = mfma_f64(av.x, kb[64], acc1);
-            acc0 = mfma_f64(av.y, kb[128], acc0); acc1 = mfma_f64(av.y, kb[192], acc1);
-        }
-        if (means) {
-            __syncthreads();
-            if (tid < 2 * SM_TC) {
-                const int which = tid >> 5, c = tid & 31;
-                double s = 0.0;
-#pragma unroll
-                for (int w = 0; w < SM_NW / 2; w++) s += lds_m[which][2 * w + (c >> 4)][c & 15];
-                mupart[(size_t)(t * 2 + which) * Mp + ctile * SM_TC + c] = s;
-            }
+            const double k0 = s2_kstar<FAM>(y0[r], a.kp.sf2, lds_tab), k1 = s2_kstar<FAM>(y1[r], a.kp.sf2, lds_tab);
+            acc0 = mfma_f64(wk[r], k0, acc0);
+            acc1 = mfma_f64(wk[r], k1, acc1);
+            if (means) { mY0 = fma(aY[r], k0, mY0); mY1 = fma(aY[r], k1, mY1); m10 = fma(a1v[r], k0, m10); m11 = fma(a1v[r], k1, m11); }
         }
     }
-    __syncthreads();                                   // everybody has read the last stage: its LDS becomes the partial V tiles
-    double *lds_v = &lds_k[0][0];                      // [wave][cand-block][lane 64 x 4]: 16 x 2 x 256 doubles = both buffers exactly
 #pragma unroll
-    for (int r = 0; r < 4; r++) { lds_v[(wave * 2 + 0) * 256 + lane * 4 + r] = acc0[r]; lds_v[(wave * 2 + 1) * 256 + lane * 4 + r] = acc1[r]; }
+    for (int r = 0; r < 4; r++) { lds_v[wave][0][lane * 4 + r] = acc0[r]; lds_v[wave][1][lane * 4 + r] = acc1[r]; }
+    if (means) {
+        mY0 += __shfl_xor(mY0, 16); mY0 += __shfl_xor(mY0, 32); mY1 += __shfl_xor(mY1, 16); mY1 += __shfl_xor(mY1, 32);
+        m10 += __shfl_xor(m10, 16); m10 += __shfl_xor(m10, 32); m11 += __shfl_xor(m11, 16); m11 += __shfl_xor(m11, 32);
+        if (lane < 16) { lds_m[0][wave][0][lane] = mY0; lds_m[0][wave][1][lane] = mY1; lds_m[1][wave][0][lane] = m10; lds_m[1][wave][1][lane] = m11; }
+    }
     __syncthreads();
     if (tid < 512) {
+        // element e of candidate block cb: lane l = e >> 2, r = e & 3 -> row (l >> 4) + 4 r, candidate 16 cb + (l & 15)
         const int cb = tid >> 8, e = tid & 255, l = e >> 2, r = e & 3;
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < SM_NW; w++) v += lds_v[(w * 2 + cb) * 256 + e];
+        for (int w = 0; w < SM_NW; w++) v += lds_v[w][cb][e];
         lds_s[16 * cb + (l & 15)][(l >> 4) + 4 * r] = v * v;
+    } else if (means && tid < 512 + 2 * SM_TC) {
+        const int which = (tid - 512) >> 5, c = (tid - 512) & 31;
+        double sm = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_NW; w++) sm += lds_m[which][w][c >> 4][c & 15];
+        mupart[(size_t)which * Mp + ctile * SM_TC + c] = sm;
     }
     __syncthreads();
     if (tid < SM_TC) {
@@ -327,11 +308,11 @@ static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, in
     return (int)hipGetLastError();
 }
 
-static int g_small_fused = 1;                        // ibo_set_option("small_fused", 0/1): wkf_small_kernel instead of kstar + wk
-void set_small_fused(int v) { g_small_fused = v; }
+static int g_small_local = 1;                        // ibo_set_option("small_local", 0/1): wkl_small_kernel (wave-local k*)
+void set_small_local(int v) { g_small_local = v; }
 
 template <int FAM>
-static int launch_wkf_small(const SweepArgs &a, double *qpart, double *mupart, int Mp, dim3 grid, hipStream_t s)
+static int launch_wkl_small(const SweepArgs &a, double *qpart, double *mupart, int Mp, dim3 grid, hipStream_t s)
 {
     InlineCand ic;
     int inl = 0;
@@ -340,15 +321,15 @@ static int launch_wkf_small(const SweepArgs &a, double *qpart, double *mupart, i
         inl = 1;
     }
     switch ((a.kp.D + 2 + 3) / 4) {
-    case 1: hipLaunchKernelGGL((wkf_small_kernel<FAM, 1>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 2: hipLaunchKernelGGL((wkf_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 3: hipLaunchKernelGGL((wkf_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 4: hipLaunchKernelGGL((wkf_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 5: hipLaunchKernelGGL((wkf_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 6: hipLaunchKernelGGL((wkf_small_kernel<FAM, 6>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 7: hipLaunchKernelGGL((wkf_small_kernel<FAM, 7>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 8: hipLaunchKernelGGL((wkf_small_kernel<FAM, 8>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    default: hipLaunchKernelGGL((wkf_small_kernel<FAM, 9>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 1: hipLaunchKernelGGL((wkl_small_kernel<FAM, 1>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 2: hipLaunchKernelGGL((wkl_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 3: hipLaunchKernelGGL((wkl_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 4: hipLaunchKernelGGL((wkl_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 5: hipLaunchKernelGGL((wkl_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 6: hipLaunchKernelGGL((wkl_small_kernel<FAM, 6>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 7: hipLaunchKernelGGL((wkl_small_kernel<FAM, 7>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    case 8: hipLaunchKernelGGL((wkl_small_kernel<FAM, 8>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    default: hipLaunchKernelGGL((wkl_small_kernel<FAM, 9>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
     }
     return (int)hipGetLastError();
 }
@@ -367,16 +348,19 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     double *Kf = ws, *qpart = Kf + (size_t)Mp * NA128, *mupart = qpart + (size_t)nrb * Mp;
     if (e0) (void)hipEventRecord(e0, s);
     int rc;
-    // small models (at most two 128-row stages) and few tiles: one launch in which every row-block's workgroup makes its own
-    // k*.  Measured (maximizeEI, ~53 batches of ~47 points): N = 64 1.50 -> 1.36 ms; but N = 1024 1.85 -> 2.15 ms and
-    // N = 2048 2.38 -> 3.2 ms -- the fused workgroup walks its stages one after the other (MFMA chain, exp chains, a barrier
-    // each: ~0.6 us per stage) where the separate k* kernel has a workgroup per stage working side by side.
-    if (g_small_fused && ctiles <= 8 && (nst <= 2 || g_small_fused > 1)) {
-        const dim3 gf(ctiles, nrb);
-        if (a.kp.family == FAM_SE) rc = launch_wkf_small<FAM_SE>(a, qpart, mupart, Mp, gf, s);
-        else if (a.kp.family == FAM_M3) rc = launch_wkf_small<FAM_M3>(a, qpart, mupart, Mp, gf, s);
-        else rc = launch_wkf_small<FAM_M5>(a, qpart, mupart, Mp, gf, s);
+    int nst_fin = nst;                                   // mean parts per candidate the finish kernel sums
+    // few tiles on a small model (DIRECT's batches, single posteriors): ONE launch, every wave making the k* it multiplies
+    // (wkl_small_kernel).  Every row-block's workgroup regenerates k* (N / 32 times on average): measured under the tracer
+    // 4.4 us at N = 64, but 15 us at N = 1024 and 28-34 us at N = 2048 against 6 + 8.6 / 6 + 16 for the two separate kernels --
+    // its 14-instruction exp() chains are then the throughput of the 128 CUs it occupies.  (A stage-by-stage fusion through an
+    // LDS stage and a barrier per 128 rows was measured too: 0.6 us per stage, slower from N = 512 on, and removed.)
+    if (g_small_local && ctiles <= 4 && (nrb <= 32 || g_small_local > 1)) {
+        const dim3 gl(ctiles, nrb);
+        if (a.kp.family == FAM_SE) rc = launch_wkl_small<FAM_SE>(a, qpart, mupart, Mp, gl, s);
+        else if (a.kp.family == FAM_M3) rc = launch_wkl_small<FAM_M3>(a, qpart, mupart, Mp, gl, s);
+        else rc = launch_wkl_small<FAM_M5>(a, qpart, mupart, Mp, gl, s);
         if (rc) return rc;
+        nst_fin = 1;
     } else {
         const dim3 g1(ctiles, nst);
         if (a.kp.family == FAM_SE) rc = launch_kstar_small<FAM_SE>(a, Kf, mupart, Mp, g1, s);
@@ -387,7 +371,7 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a.M + 63) / 64;
-    hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(64), 0, s, a, qpart, mupart, Mp, nrb, nst);
+    hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(64), 0, s, a, qpart, mupart, Mp, nrb, nst_fin);
     rc = (int)hipGetLastError();
     if (rc) return rc;
     return launch_argmax_final(a, nfin, s);
