@@ -382,6 +382,9 @@ int orc_sweep_fast(int D, const double *W, const double *alpha, const double *X,
     long c;
     int nthreads = 1;
 #ifdef _OPENMP
+    /* *threads_used on entry: threads to use (<= 0: the runtime's default).  A container's CPU quota is usually far below
+       the CPUs it can see; the caller knows it (oracle.py: effective_cores) and the OpenMP runtime does not. */
+    if (threads_used && *threads_used > 0) omp_set_num_threads(*threads_used);
 #pragma omp parallel
     {
 #pragma omp single
@@ -397,7 +400,7 @@ int orc_sweep_fast(int D, const double *W, const double *alpha, const double *X,
     {
         double *r = (double *)malloc(sizeof(double) * (size_t)N * ORC_CB);      /* r[k * ORC_CB + b] */
         long c0;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 8)
         for (c0 = 0; c0 < M; c0 += ORC_CB) {
             const int nb = (int)(M - c0 < ORC_CB ? M - c0 : ORC_CB);
             double mu[ORC_CB], q[ORC_CB];

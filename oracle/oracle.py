@@ -334,7 +334,30 @@ def sweep_native(gp, cand, acq=ACQ_EI, parm=0.01, erf_mode=ERF_LIBM, clamp_lo=CL
     return dict(mu=mu, s2=s2, acq=av, best_val=bv.value, best_idx=bi.value)
 
 
-def sweep_fast(gp, cand, acq=ACQ_EI, parm=0.01, erf_mode=ERF_LIBM, clamp_lo=CLAMP_NATIVE):
+def effective_cores():
+    """CPUs this process may really use: the affinity mask cut down to the cgroup's CPU quota (a container often sees every CPU
+    of the host but is throttled to a few cores' worth of time; OpenMP would start one thread per visible CPU)"""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(float(txt[0]) / float(txt[1])))))
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(math.ceil(q / per))))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def sweep_fast(gp, cand, acq=ACQ_EI, parm=0.01, erf_mode=ERF_LIBM, clamp_lo=CLAMP_NATIVE, threads=None):
     """best-effort all-core CPU sweep (alpha cached, triangular W = L^-1, OpenMP): same values as
     sweep_native up to rounding.  Returns dict(acq, best_val, best_idx, threads)."""
     assert gp.prior is None
@@ -343,7 +366,7 @@ def sweep_fast(gp, cand, acq=ACQ_EI, parm=0.01, erf_mode=ERF_LIBM, clamp_lo=CLAM
     N = len(gp.Y)
     W = _f64(np.linalg.inv(np.linalg.cholesky(gp.factor_matrix())))
     alpha = _f64(W.T.dot(W.dot(gp.Y)))
-    av = np.empty(M); bv = c_double(); bi = c_long(); nt = c_int()
+    av = np.empty(M); bv = c_double(); bi = c_long(); nt = c_int(effective_cores() if threads is None else int(threads))
     rc = lib().orc_sweep_fast(D, _dp(W), _dp(alpha), _dp(gp.X), N, acq, gp.kern.ktype, _dp(gp.kern.oracle_hyper()),
                               gp.kern.sf2_native, float(parm), gp.noise, erf_mode, clamp_lo, float(np.max(gp.Y)), M,
                               _dp(cand), _dp(av), ctypes.byref(bv), ctypes.byref(bi), ctypes.byref(nt))

@@ -14,3 +14,5 @@ python3 tools/run_configs.py c2 c3 c4 c5 > profiles/${TAG}_configs_c2_c5.jsonl 2
 for n in 1024 2048 4096; do bash tools/fit_trace.sh $n > profiles/${TAG}_fit_trace_$n.txt 2>&1; done
 FUZZ_DIRECT_CASES=12 timeout 1500 python3 tools/fuzz_gpu.py 200 3 > $O/fuzz.txt 2>&1; { grep -c "rel err" $O/fuzz.txt; grep "FAIL" $O/fuzz.txt | head; grep "worst" $O/fuzz.txt; sort -t'e' -k1 $O/fuzz.txt | grep "rel err" | awk '{print}' | sort -k14 -g | tail -5; tail -4 $O/fuzz.txt; } > profiles/${TAG}_fuzz_summary.txt
 tail -3 profiles/${TAG}_latencies.txt; cat profiles/${TAG}_configs_c2_c5.jsonl | cut -c1-300
+# only gpurun_out/ travels back from the GPU box: take a copy of everything this script put under profiles/
+mkdir -p $O/profiles; cp profiles/${TAG}_* $O/profiles/
