@@ -45,18 +45,24 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ctile = blockIdx.x, t = blockIdx.y;
     const int NA128 = (a.Npad + 127) & ~127;
+    // the X fragments do not depend on the candidates: their L2 round trip runs beside the staging below
+    const int rt = wave >> 1, gcb = wave & 1;
+    const int tile = t * 8 + rt;
+    double xav[KA4];
+    {
+        const double *xa = a.XA + (size_t)tile * KA4 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KA4; s++) xav[s] = xa[s * 64];
+    }
     lds_tab[tid] = a.exp_tab[tid];
     lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
     if (tid < 128) { lds_al[0][tid] = a.alphaY[t * 128 + tid]; lds_al[1][tid] = a.alpha1[t * 128 + tid]; }
     s2_stage_candidates<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)ctile * SM_TC, lds_c,
                                                     inlined ? (const double *)__builtin_amdgcn_kernarg_segment_ptr() : nullptr);
-    const int rt = wave >> 1, gcb = wave & 1;
-    const int tile = t * 8 + rt;
     const double *cfrag = &lds_c[(16 * gcb + (lane & 15)) * (KA + 1) + (lane >> 4)];
-    const double *xa = a.XA + (size_t)tile * KA4 * 64 + lane;
     d4_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < KA4; s++) y = mfma_f64(xa[s * 64], cfrag[4 * s], y);
+    for (int s = 0; s < KA4; s++) y = mfma_f64(xav[s], cfrag[4 * s], y);
     double muY = 0.0, mu1 = 0.0;
     double *dst = Kf + (((size_t)ctile * (NA128 / 4) + tile * 4) * 2 + gcb) * 64 + lane;
 #pragma unroll
@@ -93,28 +99,24 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
     const double2 *Wp2 = (const double2 *)a.Wp + (size_t)g * nk8 * 64 + lane;
     const double *Kb = Kf + (size_t)ctile * (NA128 / 4) * 128 + lane;
     d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    // this wave's steps j = wave, wave + 16, ..: every operand of a step is requested before the previous step's MFMAs
-    double2 av = {0.0, 0.0};
-    double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;
-    int j = wave;
-    if (j < nsteps) {
-        av = Wp2[(size_t)j * 64];
-        b00 = Kb[(size_t)(2 * j) * 128]; b01 = Kb[(size_t)(2 * j) * 128 + 64];
-        b10 = Kb[(size_t)(2 * j + 1) * 128]; b11 = Kb[(size_t)(2 * j + 1) * 128 + 64];
-    }
-    while (j < nsteps) {
-        const int jn = j + SM_NW;
-        double2 avn = av;
-        double n00 = 0.0, n01 = 0.0, n10 = 0.0, n11 = 0.0;
-        if (jn < nsteps) {
-            avn = Wp2[(size_t)jn * 64];
-            n00 = Kb[(size_t)(2 * jn) * 128]; n01 = Kb[(size_t)(2 * jn) * 128 + 64];
-            n10 = Kb[(size_t)(2 * jn + 1) * 128]; n11 = Kb[(size_t)(2 * jn + 1) * 128 + 64];
+    // this wave's steps j = wave, wave + 16, ..: the operands of TWO steps are in flight while a step's MFMAs issue (one step
+    // ahead left an L2 round trip per step on the chain of the longest row-blocks: 16 steps at N = 2048)
+    struct Ops { double2 av; double b00, b01, b10, b11; };
+    auto fetch = [&](int j) {
+        Ops o = {{0.0, 0.0}, 0.0, 0.0, 0.0, 0.0};
+        if (j < nsteps) {
+            o.av = Wp2[(size_t)j * 64];
+            o.b00 = Kb[(size_t)(2 * j) * 128]; o.b01 = Kb[(size_t)(2 * j) * 128 + 64];
+            o.b10 = Kb[(size_t)(2 * j + 1) * 128]; o.b11 = Kb[(size_t)(2 * j + 1) * 128 + 64];
         }
-        acc0 = mfma_f64(av.x, b00, acc0); acc1 = mfma_f64(av.x, b01, acc1);
-        acc0 = mfma_f64(av.y, b10, acc0); acc1 = mfma_f64(av.y, b11, acc1);
-        av = avn; b00 = n00; b01 = n01; b10 = n10; b11 = n11;
-        j = jn;
+        return o;
+    };
+    Ops c0 = fetch(wave), c1 = fetch(wave + SM_NW);
+    for (int j = wave; j < nsteps; j += SM_NW) {
+        const Ops c2 = fetch(j + 2 * SM_NW);
+        acc0 = mfma_f64(c0.av.x, c0.b00, acc0); acc1 = mfma_f64(c0.av.x, c0.b01, acc1);
+        acc0 = mfma_f64(c0.av.y, c0.b10, acc0); acc1 = mfma_f64(c0.av.y, c0.b11, acc1);
+        c0 = c1; c1 = c2;
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) { lds_v[wave][0][lane * 4 + r] = acc0[r]; lds_v[wave][1][lane * 4 + r] = acc1[r]; }
@@ -232,35 +234,39 @@ __global__ __launch_bounds__(SM_NW * 64) void wkl_small_kernel(InlineCand ic, Sw
     }
 }
 
-// one thread per candidate: q over the row-blocks, the mean parts over the stages (index order), the acquisition
-__global__ __launch_bounds__(64) void small_finish_kernel(SweepArgs a, const double *__restrict__ qpart, const double *__restrict__ mupart, int Mp,
-                                                          int nrb, int nst)
+// 64 candidates per workgroup of 1024 threads: sixteen threads per candidate each sum a contiguous sixteenth of the row-blocks'
+// q (all their loads in flight at once: one L2 round trip instead of nrb / 16 dependent ones -- the kernel was 7 of a DIRECT
+// batch's 22 us), the stages' mean parts likewise; the sixteen partial sums are added in index order by the candidate's first
+// thread, which then evaluates the acquisition.  Every sum has a fixed order: the result does not depend on scheduling.
+__global__ __launch_bounds__(1024) void small_finish_kernel(SweepArgs a, const double *__restrict__ qpart, const double *__restrict__ mupart, int Mp,
+                                                            int nrb, int nst)
 {
-    const int lane = threadIdx.x;
+    __shared__ double lds_q[16][64], lds_y[16][64], lds_1[16][64];
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
     const int64_t li = (int64_t)blockIdx.x * 64 + lane;
     const bool valid = li < a.M;
     const int64_t ci = valid ? li : a.M - 1;
-    // The sums keep their index order, but the loads of 16 terms are in flight together: one term at a time, each
-    // load's L2 round trip (~270 ns) sat on the dependent chain -- 128 + 32 of them at N = 2048 made this the longest
-    // of the three kernels (35 us against 15 for the product itself).
-    double q = 0.0, my = 0.0, m1 = 0.0;
-    for (int g0 = 0; g0 < nrb; g0 += 16) {
-        double v[16];
+    {
+        const int per = (nrb + 15) >> 4, g0 = p * per;
+        double v[8];
+        double qs = 0.0;
+        for (int gb = 0; gb < per; gb += 8) {            // (per <= 8 up to N = 2048: one round)
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = g0 + u < nrb ? qpart[(size_t)(g0 + u) * Mp + ci] : 0.0;
+            for (int u = 0; u < 8; u++) v[u] = (gb + u < per && g0 + gb + u < nrb) ? qpart[(size_t)(g0 + gb + u) * Mp + ci] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; u++) if (g0 + u < nrb) q += v[u];
-    }
-    for (int t0 = 0; t0 < nst; t0 += 8) {
-        double vy[8], v1[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            vy[u] = t0 + u < nst ? mupart[(size_t)(2 * (t0 + u)) * Mp + ci] : 0.0;
-            v1[u] = t0 + u < nst ? mupart[(size_t)(2 * (t0 + u) + 1) * Mp + ci] : 0.0;
+            for (int u = 0; u < 8; u++) if (gb + u < per && g0 + gb + u < nrb) qs += v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) if (t0 + u < nst) { my += vy[u]; m1 += v1[u]; }
+        lds_q[p][lane] = qs;
+        const int pers = (nst + 15) >> 4, t0 = p * pers;
+        double ys = 0.0, os = 0.0;
+        for (int t = t0; t < t0 + pers && t < nst; t++) { ys += mupart[(size_t)(2 * t) * Mp + ci]; os += mupart[(size_t)(2 * t + 1) * Mp + ci]; }
+        lds_y[p][lane] = ys; lds_1[p][lane] = os;
     }
+    __syncthreads();
+    if (p != 0) return;
+    double q = 0.0, my = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) { q += lds_q[u][lane]; my += lds_y[u][lane]; m1 += lds_1[u][lane]; }
     bool excl;
     double val = s2_finish(a, a.cand + ci * a.kp.D, q, my, m1, li, valid, excl);
     int64_t idx = a.index_base + li;
@@ -371,7 +377,7 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a.M + 63) / 64;
-    hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(64), 0, s, a, qpart, mupart, Mp, nrb, nst_fin);
+    hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(1024), 0, s, a, qpart, mupart, Mp, nrb, nst_fin);
     rc = (int)hipGetLastError();
     if (rc) return rc;
     return launch_argmax_final(a, nfin, s);
