@@ -91,7 +91,13 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * the factorisation), "chol_pipe" (software-pipelined block columns from ~1300 rows), "step_split" T (without it: block columns with more
  * than T tiles as two launches, row blocks then updates; 256),
  * "trinv_wide" (eight-wave tiles in the small levels of the triangular inversion), "update2_min_tiles", "fused2_min_nb".
- * Env IBO_SWEEP_IMPL=gemv|mfma too. */
+ * ibo_nlml_grid (same values whatever the setting, except "cov_fast", which changes the covariance entries by a rounding error):
+ * "chol_left" (left-looking outer order from one packed copy of the factor), "nlml_groups" (sub-batches on their own streams),
+ * "chol_panel_rows" 0..3 (which kernel takes the rows below a panel), "cov_fast".  Small batches: "small_local" 0/1/2 (the
+ * wave-local k* kernel: never / up to 512 observations / always).
+ * Env IBO_SWEEP_IMPL=gemv|mfma too.
+ * Threading: handles are independent, but the per-device workspaces behind ibo_nlml_grid / ibo_nlml_grad, the option switches
+ * and the allocation pool are process-wide and unsynchronised beyond the pool's mutex: use one thread per device. */
 int         ibo_set_option(const char *key, int value);
 
 /* ---------------------------------------------------------------- device memory */

@@ -454,6 +454,15 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
             cand = np.random.RandomState(N).rand(M, D); cand[min(M - 1, 7)] = X[5]
             opt(b"small2", 1); r = sweep(GP, cand, outputs=("mu", "s2", "acq"))
             assert r["kernel"] == "wk_small_kernel"
+            if M <= 128 and N <= 4096:
+                # the wave-local kernel (k* made by the wave that multiplies it: the default up to 512 observations) forced on,
+                # and the separate k* / product kernels forced: same values to rounding
+                opt(b"small_local", 2); rl = sweep(GP, cand, outputs=("mu", "s2", "acq"))
+                opt(b"small_local", 0); rs = sweep(GP, cand, outputs=("mu", "s2", "acq"))
+                opt(b"small_local", 1)
+                for k in ("mu", "s2", "acq"):
+                    close(rl[k], rs[k], rtol=1e-9, atol=1e-11); close(rl[k], r[k], rtol=1e-9, atol=1e-11)
+                assert rl["best_idx"] == rs["best_idx"] == r["best_idx"]
             opt(b"small2", 0); r0 = sweep(GP, cand, outputs=("mu", "s2", "acq"))
             assert r0["kernel"] == ("sweep_gemv_kernel" if M <= 16 else "sweep_mfma_kernel<split>") and r0["best_idx"] == r["best_idx"]
             opt(b"sweep_path", 1); rg = sweep(GP, cand[:40], outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
@@ -472,7 +481,7 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
         for v, x, ns in runs[1:]:
             assert ns == runs[0][2] and np.array_equal(x, runs[0][1]); close(v, runs[0][0], rtol=1e-9)
     finally:
-        opt(b"small2", 1); opt(b"zero_copy", 1); opt(b"sweep_path", 0)
+        opt(b"small2", 1); opt(b"zero_copy", 1); opt(b"sweep_path", 0); opt(b"small_local", 1)
 
 
 def test_incremental_sweep_state_equals_full_sweeps(ibo):
