@@ -1938,8 +1938,15 @@ int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double 
                      const double *alpha, double *partial, double *out, hipStream_t s)
 {
     dim3 grid((N + 63) / 64, (N + 63) / 64);
-    if (gs.nh <= 17) hipLaunchKernelGGL(nlml_grad_kernel<17>, grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
-    else hipLaunchKernelGGL(nlml_grad_kernel<IBO_GRAD_MAX>, grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
+    // at most 17 derivatives per pass (17 accumulators per thread: 64 VGPRs, no spills): beyond 16 dimensions the components go
+    // in two passes that each rebuild K_ab -- the 33-accumulator instantiation needed 256 VGPRs, 232 spilled SGPRs, occupancy 1
+    const int nblk = (int)(grid.x * grid.y);
+    for (int h0 = 0; h0 < gs.nh; h0 += 17) {
+        GradSpec part;
+        part.nh = gs.nh - h0 < 17 ? gs.nh - h0 : 17;
+        for (int h = 0; h < part.nh; h++) { part.mode[h] = gs.mode[h0 + h]; part.dim[h] = gs.dim[h0 + h]; }
+        hipLaunchKernelGGL(nlml_grad_kernel<17>, grid, dim3(256), 0, s, kp, part, N, X, ldx, Kinv, ldk, alpha, partial + (size_t)h0 * nblk);
+    }
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(gs.nh), dim3(256), 0, s, partial, (int)(grid.x * grid.y), out);
     return (int)hipGetLastError();
 }
