@@ -1449,7 +1449,7 @@ extern "C" int ibo_direct_max(ibo_gp_t *g, int D, const double *lb, const double
 
 // ------------------------------------------------------------------------ marginal-likelihood grid
 struct NlmlWorkspace {
-    DevBuf<double> dX, dY, dout, dL, d64, dP;       // dP: packed panels of the trailing updates (update2.hip)
+    DevBuf<double> dX, dY, dout, dL, d64, dP;       // dP: packed store of the trailing updates (update3.hip)
     DevBuf<KParams> dkp;                            // the theta-points' kernel parameters (one covariance launch per sub-batch)
     DevBuf<int> dinfo;
     const double *padded = nullptr;                 // dL as it was when its matrices got their identity pad,
@@ -1507,10 +1507,10 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     IBO_TRY(dX.ensure((size_t)N * D)); IBO_TRY(dY.ensure(N));
     IBO_TRY(dout.ensure(2 * (size_t)n_theta)); IBO_TRY(dinfo.ensure(n_theta));
     IBO_TRY(dL.ensure(nn * B)); IBO_TRY(d64.ensure((size_t)(Np / 64) * 4096 * B));
-    // packed operands of the trailing updates, per matrix: the whole factor in fragment order (left-looking order,
-    // update3.hip) or both packed copies of one 4-block panel (right-looking, update2.hip)
+    // packed operands of the trailing updates, per matrix: the factor's finished columns in fragment order (update3.hip; the
+    // right-looking A/B order writes and reads one panel of it at a time)
     const bool left = g_chol_left != 0;
-    const size_t pws = left ? nn : 2 * (size_t)Np * 256;
+    const size_t pws = nn;
     IBO_TRY(ws.dP.ensure(pws * B));
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));

@@ -218,8 +218,8 @@ int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const d
                               double *K, int ldk, size_t kstride, hipStream_t s, int fast);
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the
 // inverses of the 64x64 diagonal blocks; info (device int) gets the 1-based failing pivot or 0
-// ws (optional): workspace of 2 * Npad * 64 * panel doubles per matrix (wstride apart) for the packed-panel trailing
-// update (update2.hip); without it the 64 x 64-tile update kernel runs.  Results are bit-identical either way.
+// ws (optional): Npad * Npad doubles per matrix (wstride apart), the packed store of the packed-operand trailing update
+// (update3.hip: launch_chol_update2); without it the 64 x 64-tile update kernel runs.  Results are bit-identical either way.
 int launch_cholesky(double *L, int Npad, double *diag64, int *info_dev, hipStream_t s, double *ws = nullptr);
 int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride,
                             int panel, hipStream_t s, double *ws = nullptr, size_t wstride = 0);

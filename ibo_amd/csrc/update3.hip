@@ -62,11 +62,11 @@ __global__ __launch_bounds__(256) void chol_pack3_kernel(const double *__restric
 // B fragments straight from the packed store (no LDS, no barrier), four MFMAs -- with the loads eight steps ahead (a wave
 // has 256 cycles of MFMA work per step, nothing like the latency of its loads).  As a 128-row tile the same block cost two
 // workgroups half a tile time each: 2 of 5 tiles of the last panel.  Same MFMAs on the same operands per element: same bits.
-__device__ __forceinline__ void u3_row_block(double *L, int Npad, int c0, int ncb, int g, const double *Pk, int wave, int lane)
+__device__ __forceinline__ void u3_row_block(double *L, int Npad, int c0, int ncb, int g, const double *Pk, int wave, int lane, int kb8, int K)
 {
     const int cbw = 2 * wave;
     if (cbw >= ncb) return;
-    const int nk8s = Npad >> 3, K = c0;
+    const int nk8s = Npad >> 3;
     const __amdgpu_buffer_rsrc_t rP = u3_rsrc(Pk, (size_t)Npad * Npad * sizeof(double));
     const unsigned lane16 = lane * 16;
     const bool two = cbw + 1 < ncb;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void u3_row_block(double *L, int Npad, int c0, int nc
     for (int cb = 0; cb < 2; cb++)
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[cb][r] = (cb == 0 || two) ? -Cw[(size_t)(4 * r) * Npad + 16 * cb] : 0.0;
-    const unsigned ba = (unsigned)(g * nk8s) * 1024u, bb0 = (unsigned)(((c0 >> 4) + cbw) * nk8s) * 1024u, bb1 = bb0 + (unsigned)nk8s * 1024u;
+    const unsigned ba = (unsigned)(g * nk8s + kb8) * 1024u, bb0 = (unsigned)(((c0 >> 4) + cbw) * nk8s + kb8) * 1024u, bb1 = bb0 + (unsigned)nk8s * 1024u;
     u3_v4 R[8][3];
     auto fetch = [&](int j, u3_v4 (&F)[3]) {
         F[0] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, ba + (unsigned)j * 1024u, 0);
@@ -105,32 +105,41 @@ __device__ __forceinline__ void u3_row_block(double *L, int Npad, int c0, int nc
         }
 }
 
-// C[rows >= c0][c0 .. c0 + 16 ncb) -= Pk-rows x Pk-rows^T over k < c0.  128 x 128 tiles (I, J), J < ntc, J <= I for the
-// tiles that straddle the diagonal; 8 waves = 4 (row pairs of 16-row blocks) x 2 (four column-blocks each).
+// C[rows >= c0][c0 .. c0 + 16 ncb) -= Pk-rows x Pk-rows^T over the columns k of the k8-steps [kb8, kb8 + K / 8).  The region
+// starts ON the diagonal (first row = first column = c0): 128 x 128 tiles (I, J), J < ntc, J <= I; 8 waves = 4 (row pairs of 16-row
+// blocks) x 2 (four column-blocks each).  Left-looking (launch_chol_update3): a panel's <= 256 columns, all finished columns
+// (kb8 = 0, K = c0).  Right-looking (launch_chol_update2, the single-matrix fits beyond 2048 rows and the A/B path of the grid):
+// the whole trailing matrix, the last panel's K = 256 columns.
 __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, int Npad, int c0, int ncb, int nlive_rb,
                                                                   const double *Pk, size_t lstride, size_t pstride,
-                                                                  int tpm, int ntc, int batch, int chunk, int rowtile)
+                                                                  int tpm, int ntc, int batch, int chunk, int rowtile, int kb8, int K)
 {
     __shared__ __attribute__((aligned(16))) double lds_b[2][U3_KS / 8 * 8 * 128];      // [stage][k8-step][column-block][lane][2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // sequence entry of this workgroup (see the header): matrix m, tile t
-    const int q = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || q >= batch * tpm) return;
+    // (chunk = 0, fewer than 8 matrices: plain order -- neighbouring tiles on different XCDs find each other's strips in the
+    // memory-side cache; whole-matrix chunks per XCD would leave most L2s without a matrix)
+    const int q = chunk ? (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if ((chunk && (int)(blockIdx.x >> 3) >= chunk) || q >= batch * tpm) return;
     const int m = q / tpm, t = q - m * tpm;
     L += (size_t)m * lstride; Pk += (size_t)m * pstride;
     if (rowtile && t == tpm - 1) {                       // the matrix's last entry: the lone live row-block below the full tiles
-        u3_row_block(L, Npad, c0, ncb, nlive_rb - 1, Pk, wave, lane);
+        u3_row_block(L, Npad, c0, ncb, nlive_rb - 1, Pk, wave, lane, kb8, K);
         return;
     }
+    // (0,0), (1,0), (1,1), (2,0), .. : row I holds min(I + 1, ntc) tiles
     int I, J;
-    if (ntc == 2) { I = (t + 1) >> 1; J = t ? (t + 1) & 1 : 0; } else { I = t; J = 0; }      // (0,0), (1,0), (1,1), (2,0), (2,1), ..
+    {
+        const int tri = ntc * (ntc + 1) / 2;
+        if (t < tri) { I = 0; int rem = t; while (rem > I) { rem -= I + 1; I++; } J = rem; }
+        else { I = ntc + (t - tri) / ntc; J = (t - tri) % ntc; }
+    }
     const int wr = wave >> 1, wc = wave & 1;
     const int gA = ((c0 + 128 * I) >> 4) + 2 * wr;               // first of this wave's two row-blocks (numbered from row 0)
     const int gB = (c0 + 128 * J) >> 4;                          // first of the tile's eight column-blocks, as row-blocks of the panel
     const int cb0 = 8 * J + 4 * wc;                              // this wave's first column-block inside the panel
     const int nk8s = Npad >> 3;                                  // k8-steps per row-block of the packed store
-    const int K = c0;
     const size_t pbytes = (size_t)Npad * Npad * sizeof(double);
     const __amdgpu_buffer_rsrc_t rP = u3_rsrc(Pk, pbytes);
     const unsigned lane16 = lane * 16;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int f = wave + 8 * (2 * half + u);
-            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, (unsigned)(((gB + (f & 7)) * nk8s + st * (U3_KS / 8) + (f >> 3)) * 1024), 0);
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rP, lane16, (unsigned)(((gB + (f & 7)) * nk8s + kb8 + st * (U3_KS / 8) + (f >> 3)) * 1024), 0);
         }
     };
     auto stash_b = [&](int b, int half, const u3_v4 (&v)[2]) {
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
         }
 
     u3_v4 A[4][2];
-    const unsigned abase0 = (unsigned)(gA * nk8s) * 1024u, abase1 = (unsigned)((gA + 1) * nk8s) * 1024u;
+    const unsigned abase0 = (unsigned)(gA * nk8s + kb8) * 1024u, abase1 = (unsigned)((gA + 1) * nk8s + kb8) * 1024u;
     // NI = live row-blocks of this wave (2; 1: the y row's block, whose neighbour is pad; 0: nothing -- pad rows, columns
     // beyond the panel, or the blocks of a diagonal tile that lie wholly above the diagonal): the loop exists in three
     // straight-line versions chosen once per wave, so the idle waves of a thin tile leave the MFMA pipe to their neighbours
@@ -258,21 +267,46 @@ int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batc
     return (int)hipGetLastError();
 }
 
+// region: rows >= c0 (live ones), columns [c0, c0 + width), updated with the packed columns [kbeg, kend) (multiples of 64)
+static int launch_update3_region(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
+                                 const double *Pk, size_t pstride, hipStream_t s)
+{
+    if (width <= 0 || kend <= kbeg) return 0;
+    const int nlive_rb = (nlive + 15) / 16;
+    const int rows = 16 * nlive_rb - c0;                     // live rows at and below the region's first row
+    if (rows <= 0) return 0;
+    const int ncb = width / 16;
+    // 16 live rows below the last full tile (the likelihood's y row when N is a multiple of 128): one row-block workgroup
+    // per matrix instead of a 128-row tile per tile column
+    const int rowtile = (rows % 128 == 16 && rows > 128 && ncb <= 16) ? 1 : 0;
+    const int nrt = rowtile ? rows / 128 : (rows + 127) / 128;
+    int ntc = (width + 127) / 128;
+    if (ntc > nrt) ntc = nrt;                                // tile columns beyond the last tile row lie above the diagonal
+    const int tpm = ntc * (ntc + 1) / 2 + (nrt - ntc) * ntc + rowtile;
+    const long long total = (long long)tpm * batch;
+    const int chunk = batch >= 8 ? (int)((total + 7) / 8) : 0;
+    hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)(chunk ? 8 * chunk : total)), dim3(U3_NW * 64), 0, s, L, Npad, c0, ncb, nlive_rb, Pk,
+                       lstride, pstride, tpm, ntc, batch, chunk, rowtile, kbeg / 8, kend - kbeg);
+    return (int)hipGetLastError();
+}
+
 int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int batch, size_t lstride, const double *Pk,
                         size_t pstride, hipStream_t s)
 {
-    if (c0 <= 0 || width <= 0) return 0;
-    const int nlive_rb = (nlive + 15) / 16;
-    const int rows = 16 * nlive_rb - c0;                     // live rows at and below the panel's first row
-    if (rows <= 0) return 0;
-    // 16 live rows below the last full tile (the likelihood's y row when N is a multiple of 128): one row-block workgroup
-    // per matrix instead of a 128-row tile per tile column
-    const int rowtile = (rows % 128 == 16 && rows > 128) ? 1 : 0;
-    const int nrt = rowtile ? rows / 128 : (rows + 127) / 128, ntc = width > 128 ? 2 : 1;
-    const int tpm = (ntc == 2 ? 2 * nrt - 1 : nrt) + rowtile;
-    const long long total = (long long)tpm * batch;
-    const int chunk = (int)((total + 7) / 8);
-    hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)(8 * chunk)), dim3(U3_NW * 64), 0, s, L, Npad, c0, width / 16, nlive_rb, Pk,
-                       lstride, pstride, tpm, ntc, batch, chunk, rowtile);
-    return (int)hipGetLastError();
+    if (c0 <= 0) return 0;
+    return launch_update3_region(L, Npad, c0, width, 0, c0, nlive, batch, lstride, Pk, pstride, s);
+}
+
+// RIGHT-LOOKING use of the same kernel: after the block columns [p0, pend) are finished, the whole trailing matrix takes their
+// K = 64 (pend - p0) update.  ws: Npad * Npad doubles per matrix (`wstride` apart) -- the packed store, of which only the
+// panel's columns, rows >= 64 pend, are written and read.  Lpanel: where the finished columns live (out-of-place factorisations).
+int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t lstride, double *ws, size_t wstride,
+                        hipStream_t s, const double *Lpanel)
+{
+    if (!Lpanel) Lpanel = L;
+    const int r0 = 64 * pend;
+    if (r0 >= Npad) return 0;
+    int rc = launch_chol_pack3(Lpanel, Npad, r0, 64 * p0, 64 * (pend - p0), batch, lstride, ws, wstride, s);
+    if (rc) return rc;
+    return launch_update3_region(L, Npad, r0, Npad - r0, 64 * p0, 64 * pend, Npad, batch, lstride, ws, wstride, s);
 }
