@@ -492,6 +492,7 @@ static int make_kparams(int ktype, int D, const double *hyper, int nhyper, doubl
 // |x~|^2 bounds the absolute error of y = a_k + b_c + x~.c~ by ~|x~|^2 * 2^-52
 static int dot_form_ok(const KParams &kp, const double *X, int N, int D)
 {
+    if (D > IBO_DDOT) return 0;                      // 33 .. 64 dimensions: difference-form kernels only
     double mx = 0.0;
     for (int i = 0; i < N; i++) {
         double n2 = 0.0;
@@ -510,7 +511,7 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
 {
     if (N < 1) return fail(IBO_ERR_ARG, "N=%d", N);
     if (!X || !Y) return fail(IBO_ERR_ARG, "X/Y is NULL");
-    g->N = N; g->D = D; g->Npad = round_up(N + (reverse ? 0 : g->reserve), 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
+    g->N = N; g->D = D; g->Npad = round_up(N + (reverse ? 0 : g->reserve), 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64)));
     g->reversed = reverse;
     const int Np = g->Npad, DP = g->DP;
     size_t nn = (size_t)Np * Np;
@@ -1097,7 +1098,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     SweepArgs a;
     memset(&a, 0, sizeof(a));
     a.kp = g->kp; a.N = g->N; a.Npad = g->Npad; a.DP = g->DP; a.M = M;
-    a.Xs = g->Xs.p; a.ak = g->ak.p; a.XA = g->XA.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = g_dot_override >= 0 ? g_dot_override : g->dot_form;
+    a.Xs = g->Xs.p; a.ak = g->ak.p; a.XA = g->XA.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = (g_dot_override >= 0 && g->D <= IBO_DDOT) ? g_dot_override : g->dot_form;
     a.Xp = g->Xp.p; a.W = g->W.p; a.Wp = g->Wp.p; a.alphaY = g->alphaY.p; a.alpha1 = g->alpha1.p;
     a.cand = cand_dev; a.cand_host = cand_host;
     a.prior.nb = g->nb; a.prior.theta = g->ptheta; a.prior.means = g->pmeans.p; a.prior.beta = g->pbeta.p;

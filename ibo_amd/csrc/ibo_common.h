@@ -5,7 +5,9 @@
 #include <stdint.h>
 #include <math.h>
 
-#define IBO_DMAX 32            // largest input dimensionality handled on device (rows of X are padded to DP = 4, 8, 16 or 32)
+#define IBO_DMAX 64            // largest input dimensionality handled on device (rows of X are padded to DP = 4, 8, 16, 32 or 64)
+#define IBO_DDOT 32            // ... and the largest for which the dot-form kernels (sweep2.hip, small2.hip: exponent GEMM of up to
+                               // nine k4-steps) are instantiated; beyond, the difference-form kernels of sweep.hip take every batch
 
 // covariance families after normalising the reference's four kernel types to
 // "weighted squared distance z = sum_d w_d (x_d - c_d)^2, then a scalar map":
@@ -96,7 +98,7 @@ __device__ __forceinline__ double cov_from_z_rt(int fam, double z, double sf2)
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // which derivative each hyper-parameter index asks for (nlml_grad_kernel)
-#define IBO_GRAD_MAX 33          // D length scales + the signal magnitude
+#define IBO_GRAD_MAX 65          // D length scales + the signal magnitude
 struct GradSpec {
     int nh;
     int mode[IBO_GRAD_MAX];     // 0 SE-ARD length scale of dimension dim[h]; 1 SE-iso length scale; 2 signal

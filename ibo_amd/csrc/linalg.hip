@@ -23,12 +23,14 @@
 // 4096 x 4096 matrix in 16 dimensions against 25 now).  A thread's columns are 16 apart: a row's store instruction
 // covers whole 128-byte segments.
 // (z is accumulated in the reference's order: sum_d w_d (a_d - b_d)^2.)
-#define COV_LD 33          // row stride of the staged points: odd (conflict-free column reads), >= IBO_DMAX
+// row stride of the staged points: odd (conflict-free column reads), >= the dimension: 33 up to 32 dimensions, 65 beyond (a
+// template parameter: the wider stride halves the workgroups a CU holds)
+#define COV_LD LD
 // FAST (the marginal-likelihood grid, whose matrices never leave the device): coordinates scaled by sqrt(w_d) on their way
 // into LDS (two instead of three fp64 instructions per dimension and entry) and the 16-instruction exp_fast / 7-instruction
 // sqrt_fast of the sweep (relative error < 5e-16) instead of the library's -- 52 instead of 88 instructions per entry at
 // D = 16.  GP.R and everything a caller can read back keep the reference's order of operations (FAST = false).
-template <bool FAST>
+template <bool FAST, int LD>
 __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp1, int n1, const double *__restrict__ A1, int n2,
                                                          const double *__restrict__ A2, int ldp, int square,
                                                          int diag_rule, double noise, double *__restrict__ K, int ldk,
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp1, int n1, co
     if (kps) K += blockIdx.z * kstride;
     __shared__ double AB[2 * 64 * COV_LD];           // the two tiles' points; afterwards the tile itself, transposed (64 x 65)
     double *As = AB, *Bs = AB + 64 * COV_LD;
-    static_assert(2 * 64 * COV_LD >= 64 * 65, "the transposed tile reuses the staging buffers");
+    static_assert(2 * 64 * LD >= 64 * 65, "the transposed tile reuses the staging buffers");
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64, D = kp.D;
     if (zero_word && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) *zero_word = 0;
@@ -130,6 +132,12 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp1, int n1, co
 // K2 (optional, square case): a second, np2 x np2 copy of K padded with the identity -- the matrix the
 // factorisation works on, written by the same kernel instead of a separate pad-and-copy pass: its blocks on and below
 // the diagonal only.  K may be NULL when only the working copy is wanted.
+#define COV_LAUNCH(FASTV, DIMS, GRID, STREAM, ...)                                                                         \
+    do {                                                                                                              \
+        if ((DIMS) <= 32) hipLaunchKernelGGL((cov_matrix_kernel<FASTV, 33>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);        \
+        else hipLaunchKernelGGL((cov_matrix_kernel<FASTV, 65>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);                     \
+    } while (0)
+
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
                       int ldp, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2, int np2, int lower_only,
                       double *Eye, int *zero_word, int fast)
@@ -139,11 +147,11 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
     const int c = K2 ? np2 : n2, r = K2 ? np2 : n1;
     dim3 grid((c + 63) / 64, (r + 63) / 64);
     if (fast)
-        hipLaunchKernelGGL(cov_matrix_kernel<true>, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
+        COV_LAUNCH(true, kp.D, grid, s, kp, n1, A1, n2, A2, ldp, square,
                            diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0, K2 ? Eye : nullptr, zero_word,
                            (const KParams *)nullptr, (size_t)0);
     else
-        hipLaunchKernelGGL(cov_matrix_kernel<false>, grid, dim3(256), 0, s, kp, n1, A1, n2, A2, ldp, square,
+        COV_LAUNCH(false, kp.D, grid, s, kp, n1, A1, n2, A2, ldp, square,
                            diag_rule, noise, K, ldk, K2, np2, square && !K2 ? lower_only : 0, K2 ? Eye : nullptr, zero_word,
                            (const KParams *)nullptr, (size_t)0);
     return (int)hipGetLastError();
@@ -154,6 +162,7 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
 // (a 2-D grid would dispatch as many dead workgroups as live ones), a row's 128 columns leave in eight consecutive 128-byte
 // stores -- 1 KiB per row and tile: with 64 x 64 tiles (512-byte row segments) the 4.3 GB of a 64-matrix grid went out at
 // 1.7 TB/s.  Scaled coordinates, exp_fast / sqrt_fast as cov_matrix_kernel<true>.
+template <int LD>
 __global__ __launch_bounds__(256) void cov_grid_kernel(const KParams *__restrict__ kps, int n, const double *__restrict__ X, int ldp,
                                                        double noise, double *__restrict__ K, int ldk, size_t kstride)
 {
@@ -223,14 +232,16 @@ int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const d
         const int nI = (n1 + 31) / 32;                   // tiles: sum over rows I of I / 4 + 1
         long ntile = 0;
         for (int I = 0; I < nI; I++) ntile += I / 4 + 1;
-        hipLaunchKernelGGL(cov_grid_kernel, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
+        // (ldp = the dimension here: the points are handed over unpadded)
+        if (ldp <= 32) hipLaunchKernelGGL(cov_grid_kernel<33>, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
+        else hipLaunchKernelGGL(cov_grid_kernel<65>, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
         return (int)hipGetLastError();
     }
     if (fast)
-        hipLaunchKernelGGL(cov_matrix_kernel<true>, grid, dim3(256), 0, s, dummy, n1, A1, n1, A1, ldp, 1, diag_rule, noise, K, ldk,
+        COV_LAUNCH(true, ldp, grid, s, dummy, n1, A1, n1, A1, ldp, 1, diag_rule, noise, K, ldk,
                            (double *)nullptr, 0, 1, (double *)nullptr, (int *)nullptr, kps_dev, kstride);
     else
-        hipLaunchKernelGGL(cov_matrix_kernel<false>, grid, dim3(256), 0, s, dummy, n1, A1, n1, A1, ldp, 1, diag_rule, noise, K, ldk,
+        COV_LAUNCH(false, ldp, grid, s, dummy, n1, A1, n1, A1, ldp, 1, diag_rule, noise, K, ldk,
                            (double *)nullptr, 0, 1, (double *)nullptr, (int *)nullptr, kps_dev, kstride);
     return (int)hipGetLastError();
 }
@@ -1862,7 +1873,7 @@ int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, 
 // through LDS once per hyper-parameter -- 128 barriers for 256 pairs: 181 us at N = 2048, D = 8; now 25).
 // Per-workgroup partial sums, reduced in a fixed order by grad_reduce_kernel.
 // ------------------------------------------------------------------------
-template <int GM>          // GM >= gs.nh: accumulators held per thread (17 covers D <= 16 without the registers of 33)
+template <int GM, int LD>  // GM >= gs.nh: accumulators held per thread; LD: row stride of the staged points (33 or 65)
 __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs, int N, const double *__restrict__ X,
                                                         int ldx, const double *__restrict__ Kinv, int ldk,
                                                         const double *__restrict__ alpha, double *__restrict__ partial)
@@ -1945,7 +1956,8 @@ int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double 
         GradSpec part;
         part.nh = gs.nh - h0 < 17 ? gs.nh - h0 : 17;
         for (int h = 0; h < part.nh; h++) { part.mode[h] = gs.mode[h0 + h]; part.dim[h] = gs.dim[h0 + h]; }
-        hipLaunchKernelGGL(nlml_grad_kernel<17>, grid, dim3(256), 0, s, kp, part, N, X, ldx, Kinv, ldk, alpha, partial + (size_t)h0 * nblk);
+        if (kp.D <= 32) hipLaunchKernelGGL((nlml_grad_kernel<17, 33>), grid, dim3(256), 0, s, kp, part, N, X, ldx, Kinv, ldk, alpha, partial + (size_t)h0 * nblk);
+        else hipLaunchKernelGGL((nlml_grad_kernel<17, 65>), grid, dim3(256), 0, s, kp, part, N, X, ldx, Kinv, ldk, alpha, partial + (size_t)h0 * nblk);
     }
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(gs.nh), dim3(256), 0, s, partial, (int)(grid.x * grid.y), out);
     return (int)hipGetLastError();

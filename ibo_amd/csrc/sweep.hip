@@ -504,7 +504,9 @@ static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
     else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
     else if (a.DP == 16) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 32, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
+    else if (a.DP == 32) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 32, NW, RBW, CBW, KCH, DOT>), grid, block, 0, s, a);
+    else if (!DOT) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 64, NW, RBW, CBW, KCH, false>), grid, block, 0, s, a);     // 33 .. 64 dimensions: difference form only
+    else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 
@@ -525,7 +527,9 @@ static int launch_mfma_split(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     if (a.DP == 4) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 4, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
     else if (a.DP == 8) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 8, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
     else if (a.DP == 16) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 16, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 32, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
+    else if (a.DP == 32) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 32, 16, 1, 1, 64, DOT, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
+    else if (!DOT) hipLaunchKernelGGL((sweep_mfma_kernel<FAM, 64, 16, 1, 1, 64, false, IBO_SPLIT_PANEL, true>), grid, block, 0, s, a);
+    else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 

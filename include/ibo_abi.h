@@ -124,7 +124,9 @@ int ibo_gp_destroy(ibo_gp_t *gp);
  * hyper: nhyper doubles per kernel type (see IBO_K_*); sf2 multiplies the
  * kernel (1 for SE kernels, magnitude^2 for SV / Matern in the Python model).
  * On IBO_ERR_NOT_PD *info (optional) receives the 1-based failing pivot.
- * 1 <= D <= 32 (IBO_ERR_ARG otherwise; the reference has no limit, its tests and demos stay below 7).
+ * 1 <= D <= 64 (IBO_ERR_ARG otherwise; the reference has no limit, its tests and demos stay below 7).  Up to 32 dimensions
+ * the exponent-GEMM kernels take the sweeps; 33 .. 64 run through the difference-form kernels only (and without the kept
+ * state of ibo_acq_sweep_incremental: every call is a full sweep).
  */
 int ibo_gp_fit(ibo_gp_t *gp, int ktype, int N, int D,
                const double *X_host, const double *Y_host,
@@ -338,7 +340,7 @@ int ibo_trim(int device);
  * computeGradient=True), ego/gaussianprocess/trainhyper.py:47-75, with dK/dtheta_h as
  * Kernel.derivative(X, h) builds it (ego/gaussianprocess/kernel.py).  modes[h]: 0 SE-ARD length
  * scale of dimension dims[h]; 1 SE-iso length scale; 2 signal magnitude (2K); 3 Matern-3/2 and
- * 4 Matern-5/2 length scale.  grad_host receives ngrad values (1 <= ngrad <= 33).
+ * 4 Matern-5/2 length scale.  grad_host receives ngrad values (1 <= ngrad <= 65; 17 per pass of the gradient kernel).
  */
 int ibo_nlml_grad(int device, int ktype, int N, int D, const double *X_host, const double *Y_host,
                   const double *hyper_host, int nhyper, double sf2, double noise,

@@ -1513,7 +1513,7 @@ def test_sv_ard_kernel_and_ego_alias(ibo, oracle):
 def test_seventeen_to_thirty_two_dimensions(ibo, oracle):
     """D = 17..32 (rows of X padded to 32 coordinates, six to nine k4-steps in the exponent GEMM, the 3072-row alpha window,
     up to 33 gradient components): every sweep kernel, the fit, the block extension + refresh kernel, NLML with its
-    gradient and DIRECT against the CPU oracle; D = 33 is refused"""
+    gradient and DIRECT against the CPU oracle"""
     import oracle.oracle as orc
     from ibo_amd import _lib, DeviceArray
     from ibo_amd.gaussianprocess import GaussianProcess
@@ -1611,6 +1611,87 @@ def test_seventeen_to_thirty_two_dimensions(ibo, oracle):
         probe = np.random.RandomState(151).rand(40, 20)
         close(PG.posteriors(probe), opg.posteriors(probe), atol=1e-9)
         with pytest.raises(Exception):
-            GaussianProcess(K.GaussianKernel_iso([1.5]), np.random.rand(10, 33), np.random.rand(10), noise=.1).posterior(np.zeros(33))
+            GaussianProcess(K.GaussianKernel_iso([1.5]), np.random.rand(10, 65), np.random.rand(10), noise=.1).posterior(np.zeros(65))
+    finally:
+        opt(b"sweep_variant", 4); opt(b"sweep_path", 0); opt(b"small2", 1); opt(b"dot_form", -1)
+
+
+def test_thirty_three_to_sixty_four_dimensions(ibo, oracle):
+    """D = 33..64 (the reference's kernels are dimension-agnostic, ego/gaussianprocess/kernel.py:147-149): rows of X padded to 64
+    coordinates, every batch through the difference-form kernels of sweep.hip (the exponent-GEMM kernels are instantiated up
+    to 32 dimensions) -- the fit, large / small / single-point sweeps, the block extension, the likelihood grid, NLML with up to
+    65 partial derivatives (four passes of 17) and DIRECT against the CPU oracle; D = 65 is refused"""
+    import oracle.oracle as orc
+    from ibo_amd import _lib, DeviceArray
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood, nlml_grid
+    from ibo_amd.acquisition import sweep, maximizeEI
+    opt = lambda k, v: _lib.check(_lib.lib.ibo_set_option(k, v))
+    cases = [(700, 33, K.GaussianKernel_ard([2.0 + .01 * d for d in range(33)]), ("ard", [2.0 + .01 * d for d in range(33)])),
+             (900, 40, K.MaternKernel5([2.2, 1.0]), ("m5", [2.2, 1.0])),
+             (300, 57, K.GaussianKernel_iso([2.5]), ("iso", [2.5])),
+             (1100, 64, K.GaussianKernel_ard([2.4] * 64), ("ard", [2.4] * 64)),
+             (500, 64, K.MaternKernel3([2.6, 1.0]), ("m3", [2.6, 1.0]))]
+    try:
+        for N, D, kern, (okind, ohyp) in cases:
+            X, Y = synth(N + D, N, D)
+            GP = GaussianProcess(kern, X, Y, noise=.1)
+            ogp = oracle.GP(oracle.Kern(okind, ohyp), X, Y, noise=.1)
+            close(GP.R, ogp.R, rtol=1e-12); close(GP.L, ogp.L, rtol=1e-8, atol=1e-12)
+            M = 8300
+            cand = np.random.RandomState(N).rand(M, D); cand[77] = X[5]; cand[M - 1] = cand[0]
+            r = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            assert r["kernel"] == "sweep_mfma_kernel"
+            idx = np.r_[np.arange(0, M, M // 40), 77, M - 1, r["best_idx"]]
+            o = oracle.sweep_native(ogp, cand[idx], oracle.ACQ_EI, .01)
+            close(r["mu"][idx], o["mu"], atol=1e-9); close(r["s2"][idx], o["s2"]); close(r["acq"][idx], o["acq"], atol=ACQ_ATOL)
+            assert r["best_idx"] == int(np.argmax(r["acq"]))
+            rs = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            assert rs["kernel"] == "sweep_mfma_kernel<split>"
+            rg = sweep(GP, cand[:9], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            assert rg["kernel"] == "sweep_gemv_kernel"
+            opt(b"dot_form", 1)                                   # a forced dot form is ignored beyond 32 dimensions
+            rf = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
+            opt(b"dot_form", -1)
+            for k in ("mu", "s2", "acq"):
+                close(rs[k], r[k][:300], rtol=1e-9, atol=1e-11); close(rg[k], r[k][:9], rtol=1e-9, atol=1e-11); close(rf[k], rs[k], rtol=0, atol=0)
+            mu1, s21 = GP.posterior(cand[3]); o1 = ogp.posteriors(cand[3:4])
+            close(mu1, o1[0][0], atol=1e-9); close(s21, o1[1][0])
+        # block extension in 48 dimensions (every round a full sweep: no kept state without the exponent-GEMM kernels)
+        N0, D = 500, 48
+        X, Y = synth(148, N0 + 3, D)
+        kern = K.GaussianKernel_ard([2.3] * D)
+        GP = GaussianProcess(kern, X[:N0], Y[:N0], noise=.1)
+        dc = DeviceArray.from_host(np.random.RandomState(149).rand(9001, D))
+        for rnd in range(3):
+            r = sweep(GP, dc, acq='ei', xi=.4, native=False, incremental=True, outputs=("mu", "s2", "acq"))
+            assert r["kernel"] == "sweep_mfma_kernel"
+            f = sweep(GaussianProcess(kern, GP.X, GP.Y, noise=.1), dc, acq='ei', xi=.4, native=False, outputs=("mu", "s2", "acq"))
+            close(r["mu"], f["mu"], rtol=1e-9, atol=1e-10); close(r["s2"], f["s2"], rtol=1e-9); assert r["best_idx"] == f["best_idx"]
+            GP.addData(X[len(GP.X)], Y[len(GP.X)])
+        ogp = oracle.GP(oracle.Kern("ard", [2.3] * D), np.asarray(GP.X), np.asarray(GP.Y), noise=.1)
+        probe = np.random.RandomState(150).rand(30, D)
+        close(GP.posteriors(probe), ogp.posteriors(probe), atol=1e-9)
+        # NLML and its 41 / 65 / 64 partial derivatives; the grid
+        for N, D, name, cls, hyp in ((300, 40, "svard", K.SVGaussianKernel_ard, [2.0 + .02 * d for d in range(40)] + [1.1]),
+                                     (200, 64, "svard", K.SVGaussianKernel_ard, [2.5] * 64 + [.9]),
+                                     (200, 64, "ard", K.GaussianKernel_ard, [2.2 + .01 * d for d in range(64)])):
+            X, Y = synth(N + D, N, D)
+            v, d = marginalLikelihood(cls(hyp), X, Y, len(hyp), True, noise=1e-3)
+            ov, od = orc.marginal_likelihood(orc.Kern(name, hyp), X, Y, len(hyp), True, 1e-3)
+            close(v, ov); close(d, od, atol=1e-9)
+        X, Y = synth(164, 400, 50)
+        th = np.exp(np.random.RandomState(165).uniform(np.log(1.5), np.log(4.), size=(9, 50)))
+        vals, _ = nlml_grid(K.GaussianKernel_ard, th, X, Y, noise=1e-2)
+        for t in (0, 4, 8):
+            close(vals[t], orc.nlml_c(orc.Kern("ard", th[t]), X, Y, noise=1e-2), rtol=1e-9)
+        # DIRECT over a 36-dimensional box
+        X, Y = synth(166, 150, 36)
+        GP = GaussianProcess(K.GaussianKernel_iso([2.5]), X, Y, noise=.1)
+        ogp = oracle.GP(oracle.Kern("iso", [2.5]), X, Y, noise=.1)
+        opt_v, opt_x = maximizeEI(GP, [[0., 1.]] * 36, maxiter=4)
+        o, ox, _ = oracle.acqmax_native(ogp, [[0., 1.]] * 36, oracle.ACQ_EI, .01, maxiter=4)
+        close(opt_v, o, atol=ACQ_ATOL); close(opt_x, ox, rtol=1e-9, atol=1e-12)
     finally:
         opt(b"sweep_variant", 4); opt(b"sweep_path", 0); opt(b"small2", 1); opt(b"dot_form", -1)
