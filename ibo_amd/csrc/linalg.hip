@@ -158,29 +158,29 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
 }
 
 // The likelihood grid's covariance pass: lower part of K(X, X) + noise I for `batch` parameter sets, one launch.
-// 32 x 128 entries per workgroup (2 x 8 per thread), workgroups numbered over the tiles that touch the lower triangle only
-// (a 2-D grid would dispatch as many dead workgroups as live ones), a row's 128 columns leave in eight consecutive 128-byte
-// stores -- 1 KiB per row and tile: with 64 x 64 tiles (512-byte row segments) the 4.3 GB of a 64-matrix grid went out at
-// 1.7 TB/s.  Scaled coordinates, exp_fast / sqrt_fast as cov_matrix_kernel<true>.
+// 64 x 128 entries per workgroup (4 x 8 per thread: 12 LDS reads per dimension for 32 entries), workgroups numbered over the
+// tiles that touch the lower triangle only (a 2-D grid would dispatch as many dead workgroups as live ones), a row's 128
+// columns leave in eight consecutive 128-byte stores -- 1 KiB per row and tile: with 64 x 64 tiles (512-byte row segments) the
+// 4.3 GB of a 64-matrix grid went out at 1.7 TB/s.  Scaled coordinates, exp_fast / sqrt_fast as cov_matrix_kernel<true>.
 template <int LD>
 __global__ __launch_bounds__(256) void cov_grid_kernel(const KParams *__restrict__ kps, int n, const double *__restrict__ X, int ldp,
                                                        double noise, double *__restrict__ K, int ldk, size_t kstride)
 {
-    __shared__ double As[32 * COV_LD];
+    __shared__ double As[64 * COV_LD];
     __shared__ double Bs[128 * COV_LD];
     const KParams &kp = kps[blockIdx.z];
     K += blockIdx.z * kstride;
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4, D = kp.D;
-    // tile (I, J): rows 32 I .., columns 128 J ..; row I has I / 4 + 1 tiles; rows 4 a .. 4 a + 3 start at 2 a (a + 1)
+    // tile (I, J): rows 64 I .., columns 128 J ..; row I has I / 2 + 1 tiles; rows 2 a, 2 a + 1 start at a (a + 1)
     const int q = blockIdx.x;
-    int a = (int)((sqrt(1.0 + 2.0 * (double)q) - 1.0) * 0.5);
-    while (2 * (a + 1) * (a + 2) <= q) a++;
-    while (2 * a * (a + 1) > q) a--;
-    const int rem = q - 2 * a * (a + 1);
-    const int I = 4 * a + rem / (a + 1), J = rem % (a + 1);
-    const int i0 = 32 * I, j0 = 128 * J;
+    int a = (int)((sqrt(1.0 + 4.0 * (double)q) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) <= q) a++;
+    while (a * (a + 1) > q) a--;
+    const int rem = q - a * (a + 1);
+    const int I = 2 * a + rem / (a + 1), J = rem % (a + 1);
+    const int i0 = 64 * I, j0 = 128 * J;
     if (i0 >= n) return;
-    for (int e = t; e < 32 * D; e += 256) {
+    for (int e = t; e < 64 * D; e += 256) {
         const int r = e / D, d = e - r * D;
         As[r * COV_LD + d] = (i0 + r < n) ? X[(size_t)(i0 + r) * ldp + d] * kp.sw[d] : 0.0;
     }
@@ -189,15 +189,15 @@ __global__ __launch_bounds__(256) void cov_grid_kernel(const KParams *__restrict
         Bs[r * COV_LD + d] = (j0 + r < n) ? X[(size_t)(j0 + r) * ldp + d] * kp.sw[d] : 0.0;
     }
     __syncthreads();
-    double z[2][8] = {};
+    double z[4][8] = {};
     for (int d = 0; d < D; d++) {
-        double av[2], bv[8];
+        double av[4], bv[8];
 #pragma unroll
-        for (int r = 0; r < 2; r++) av[r] = As[(ty * 2 + r) * COV_LD + d];
+        for (int r = 0; r < 4; r++) av[r] = As[(ty * 4 + r) * COV_LD + d];
 #pragma unroll
         for (int c = 0; c < 8; c++) bv[c] = Bs[(tx + 16 * c) * COV_LD + d];
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const double u = av[r] - bv[c];
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void cov_grid_kernel(const KParams *__restrict
     const double log_sf2 = log(kp.sf2);
     const int fam = kp.family;
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int i = i0 + ty * 2 + r;
+    for (int r = 0; r < 4; r++) {
+        const int i = i0 + ty * 4 + r;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int j = j0 + tx + 16 * c;
@@ -229,9 +229,9 @@ int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const d
     dim3 grid((n1 + 63) / 64, (n1 + 63) / 64, batch);
     KParams dummy = KParams();
     if (fast && diag_rule == 1) {
-        const int nI = (n1 + 31) / 32;                   // tiles: sum over rows I of I / 4 + 1
+        const int nI = (n1 + 63) / 64;                   // tiles: sum over rows I of I / 2 + 1
         long ntile = 0;
-        for (int I = 0; I < nI; I++) ntile += I / 4 + 1;
+        for (int I = 0; I < nI; I++) ntile += I / 2 + 1;
         // (ldp = the dimension here: the points are handed over unpadded)
         if (ldp <= 32) hipLaunchKernelGGL(cov_grid_kernel<33>, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
         else hipLaunchKernelGGL(cov_grid_kernel<65>, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
