@@ -241,6 +241,7 @@ void set_trinv_wide(int v);
 void set_step_split(int v);
 void set_chol_pipe(int v);
 void set_chol_panel_rows(int v);
+void set_chol_panel_diag(int v);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
 // Ework (identity on entry) / Eout, optional: W = L^-1 rides along -- Eout receives (L^-1)^T, blocks on and above the diagonal
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s,

@@ -1264,6 +1264,75 @@ void set_chol_update2(int v) { g_update2 = v; }
 static int g_update2_min_tiles = 1024;               // ibo_set_option("update2_min_tiles"): 128 x 128 tiles (over the batch) from which the packed-panel kernel takes the update
 void set_chol_update2_min_tiles(int v) { g_update2_min_tiles = v; }
 
+// The panel's (64 P)^2 DIAGONAL block in one launch, one workgroup per matrix: for each of its P block columns the diagonal
+// factorisation (chol_diag_kernel), the row blocks below it inside the block (chol_trsm_kernel) and their K = 64 updates
+// (chol_update_kernel) -- the same helpers on the same operands in the same order, identical bits -- without the 3 P - 2
+// launches of one workgroup per matrix each (11 per panel, 1.5 ms of a 64-theta grid at N = 4096).  The blocks travel through
+// global memory (the workgroup reads back what it stored: one CU, one L1) and LDS holds the chain's three 64 x 64 stages.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void chol_panel_diag_kernel(double *L, int Npad, int p0, int P, double *__restrict__ diag64, int *info, size_t lstride, size_t dstride)
+{
+    __shared__ double S[64 * SD];
+    __shared__ double V[64 * SD];
+    __shared__ double T[64 * SD];
+    TILE_IDS;
+    L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride; info += blockIdx.z;
+    for (int j = 0; j < P; j++) {
+        const int jb = p0 + j;
+        double *Djj = L + (size_t)jb * 64 * Npad + (size_t)jb * 64;
+        diag64_load(Djj, Npad, S, V, T);
+        __syncthreads();
+        diag64_factor_invert(S, V, T, jb * 64, info);
+        diag64_store(Djj, Npad, diag64 + (size_t)jb * 4096, S, V);
+        __syncthreads();
+        for (int r = j + 1; r < P; r++) {               // X_rj = A_rj inv(L_jj)^T
+            double *Arj = L + (size_t)(p0 + r) * 64 * Npad + (size_t)jb * 64;
+            d2_t va[8];
+            tile64_fetch(Arj, Npad, va);
+            tile64_stash<false, SD>(S, va);
+            __syncthreads();
+            d4_t acc[2][2] = {};
+            tile64_mma_nt_tri<SD>(S, V, acc);
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) Arj[(size_t)TILE_ROW(m, q) * Npad + TILE_COL_TRI(n)] = acc[m][n][q];
+            __syncthreads();
+        }
+        for (int c = j + 1; c < P; c++)                  // A_rc -= X_rj X_cj^T, r >= c
+            for (int r = c; r < P; r++) {
+                const double *Xr = L + (size_t)(p0 + r) * 64 * Npad + (size_t)jb * 64, *Xc = L + (size_t)(p0 + c) * 64 * Npad + (size_t)jb * 64;
+                double *C = L + (size_t)(p0 + r) * 64 * Npad + (size_t)(p0 + c) * 64;
+                d2_t va[8], vb[8];
+                tile64_fetch(Xr, Npad, va);
+                tile64_fetch(Xc, Npad, vb);
+                d4_t acc[2][2];
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) acc[m][n][q] = C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)];
+                tile64_stash<true, SD>(S, va);
+                tile64_stash<false, SD>(T, vb);
+                __syncthreads();
+                tile64_mma_nt<SD>(S, T, acc);
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
+                __syncthreads();
+            }
+    }
+}
+
+static int g_panel_diag = 1;                         // ibo_set_option("chol_panel_diag", 0/1): chol_panel_diag_kernel
+void set_chol_panel_diag(int v) { g_panel_diag = v; }
+
 // the block columns [p0, pend) of a panel whose columns are up to date: diagonal blocks, row blocks, K = 64 updates inside the panel
 // Returns true when the rows below the panel went to the packed store Pk (left-looking order) on the way.
 static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, int *info_dev, int batch, size_t lstride, hipStream_t s,
@@ -1276,6 +1345,9 @@ static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
     // (taken when the rows fill the chip: with few of them the short launches it replaces finish sooner; either way
     // the bits are the same)
     const bool rows_fused = g_panel_rows && pend - p0 <= 4 && (size_t)(nb - pend) * batch >= 256;
+    if (rows_fused && g_panel_diag)                  // the diagonal block's 3 P - 2 launches as one
+        hipLaunchKernelGGL(chol_panel_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, p0, pend - p0, diag64, info_dev, lstride, dstride);
+    else
     for (int jb = p0; jb < pend; jb++) {
         hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, info_dev,
                            lstride, dstride, (double *)nullptr);
