@@ -297,6 +297,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "chol_pipe")) { set_chol_pipe(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_diag")) { set_chol_panel_diag(value); return IBO_OK; }
+    if (key && !strcmp(key, "chol_tail")) { set_chol_tail(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_ride")) { g_chol_ride = value; return IBO_OK; }
     if (key && !strcmp(key, "small2")) { g_small2 = value; return IBO_OK; }
     if (key && !strcmp(key, "gemv_max")) { g_gemv_max = value; return IBO_OK; }

@@ -234,6 +234,10 @@ int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batc
                       hipStream_t s);
 int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int batch, size_t lstride, const double *Pk,
                         size_t pstride, hipStream_t s);
+// the same kernel on any region that starts on the diagonal (rows >= c0, columns [c0, c0 + width)) and any range [kbeg, kend) of packed columns
+int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
+                              const double *Pk, size_t pstride, hipStream_t s);
+void set_chol_tail(int blocks);
 void set_chol_panel(int p);
 void set_chol_update2(int v);
 void set_chol_update2_min_tiles(int v);

@@ -1330,6 +1330,8 @@ void chol_panel_diag_kernel(double *L, int Npad, int p0, int P, double *__restri
     }
 }
 
+static int g_chol_tail = 20;                         // ibo_set_option("chol_tail", blocks): block columns of the left-looking order's right-looking tail (0: none)
+void set_chol_tail(int v) { g_chol_tail = v; }
 static int g_panel_diag = 1;                         // ibo_set_option("chol_panel_diag", 0/1): chol_panel_diag_kernel
 void set_chol_panel_diag(int v) { g_panel_diag = v; }
 
@@ -1410,10 +1412,18 @@ int launch_cholesky_batched_left(double *L, int Npad, double *diag64, int *info_
     const int P = g_chol_panel > 0 ? g_chol_panel : panel;
     if (nfactor <= 0 || nfactor > nb) nfactor = nb;
     HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
+    // THE TAIL.  Left-looking, the last panels have few tiles (17 .. 5 per matrix over the last 1024 columns) and a long K: the
+    // chip runs half empty (46 .. 81 % of the update kernel's rate on panels 12 .. 15 of 16).  From block column `tail` on the
+    // order changes: ONE update brings all remaining columns up to date with everything before `tail` (many tiles, long K), and
+    // inside the tail the order is right-looking (after each panel a K = 256 update of the remaining tail columns: short K, but
+    // the tail is small).  Every element still receives its terms in ascending k: identical bits.
+    int tail = nfactor;
+    if (g_chol_tail > 0 && nfactor > g_chol_tail + P) tail = (nfactor - g_chol_tail) / P * P;
     for (int p0 = 0; p0 < nfactor; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
-        if (p0 > 0) {
-            int rc = launch_chol_update3(L, Npad, 64 * p0, 64 * (pend - p0), nlive, batch, lstride, Pk, pstride, s);
+        if (p0 > 0 && p0 <= tail) {
+            const int width = p0 == tail ? 64 * (nfactor - p0) : 64 * (pend - p0);
+            int rc = launch_chol_update3_range(L, Npad, 64 * p0, width, 0, 64 * p0, nlive, batch, lstride, Pk, pstride, s);
             if (rc) return rc;
         }
         // the rows below the panel reach the packed store straight from chol_panel_rows_kernel's LDS where that kernel runs
@@ -1421,6 +1431,10 @@ int launch_cholesky_batched_left(double *L, int Npad, double *diag64, int *info_
         const bool packed = chol_inpanel(L, Npad, p0, pend, diag64, info_dev, batch, lstride, s, pend < nfactor ? Pk : nullptr, pstride, rm_from);
         if (pend < nfactor && !packed) {
             int rc = launch_chol_pack3(L, Npad, 64 * pend, 64 * p0, 64 * (pend - p0), batch, lstride, Pk, pstride, s);
+            if (rc) return rc;
+        }
+        if (p0 >= tail && pend < nfactor) {              // inside the tail: this panel's update of the columns still to come
+            int rc = launch_chol_update3_range(L, Npad, 64 * pend, 64 * (nfactor - pend), 64 * p0, 64 * pend, nlive, batch, lstride, Pk, pstride, s);
             if (rc) return rc;
         }
     }

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
     if ((chunk && (int)(blockIdx.x >> 3) >= chunk) || q >= batch * tpm) return;
     const int m = q / tpm, t = q - m * tpm;
     L += (size_t)m * lstride; Pk += (size_t)m * pstride;
-    if (rowtile && t == tpm - 1) {                       // the matrix's last entry: the lone live row-block below the full tiles
-        u3_row_block(L, Npad, c0, ncb, nlive_rb - 1, Pk, wave, lane, kb8, K);
+    if (rowtile && t >= tpm - rowtile) {                 // the matrix's last entries: the lone live row-block below the full tiles,
+        const int ri = t - (tpm - rowtile);              // 16 column-blocks (256 columns) per workgroup
+        u3_row_block(L, Npad, c0 + 256 * ri, ncb - 16 * ri < 16 ? ncb - 16 * ri : 16, nlive_rb - 1, Pk, wave, lane, kb8, K);
         return;
     }
     // (0,0), (1,0), (1,1), (2,0), .. : row I holds min(I + 1, ntc) tiles
@@ -268,7 +269,7 @@ int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batc
 }
 
 // region: rows >= c0 (live ones), columns [c0, c0 + width), updated with the packed columns [kbeg, kend) (multiples of 64)
-static int launch_update3_region(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
+int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
                                  const double *Pk, size_t pstride, hipStream_t s)
 {
     if (width <= 0 || kend <= kbeg) return 0;
@@ -278,7 +279,7 @@ static int launch_update3_region(double *L, int Npad, int c0, int width, int kbe
     const int ncb = width / 16;
     // 16 live rows below the last full tile (the likelihood's y row when N is a multiple of 128): one row-block workgroup
     // per matrix instead of a 128-row tile per tile column
-    const int rowtile = (rows % 128 == 16 && rows > 128 && ncb <= 16) ? 1 : 0;
+    const int rowtile = (rows % 128 == 16 && rows > 128) ? (ncb + 15) / 16 : 0;
     const int nrt = rowtile ? rows / 128 : (rows + 127) / 128;
     int ntc = (width + 127) / 128;
     if (ntc > nrt) ntc = nrt;                                // tile columns beyond the last tile row lie above the diagonal
@@ -294,7 +295,7 @@ int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int b
                         size_t pstride, hipStream_t s)
 {
     if (c0 <= 0) return 0;
-    return launch_update3_region(L, Npad, c0, width, 0, c0, nlive, batch, lstride, Pk, pstride, s);
+    return launch_chol_update3_range(L, Npad, c0, width, 0, c0, nlive, batch, lstride, Pk, pstride, s);
 }
 
 // RIGHT-LOOKING use of the same kernel: after the block columns [p0, pend) are finished, the whole trailing matrix takes their
@@ -308,5 +309,5 @@ int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t
     if (r0 >= Npad) return 0;
     int rc = launch_chol_pack3(Lpanel, Npad, r0, 64 * p0, 64 * (pend - p0), batch, lstride, ws, wstride, s);
     if (rc) return rc;
-    return launch_update3_region(L, Npad, r0, Npad - r0, 64 * p0, 64 * pend, Npad, batch, lstride, ws, wstride, s);
+    return launch_chol_update3_range(L, Npad, r0, Npad - r0, 64 * p0, 64 * pend, Npad, batch, lstride, ws, wstride, s);
 }
