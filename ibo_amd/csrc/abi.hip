@@ -54,6 +54,8 @@ static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path,
 static int g_fused2_min_nb = 33;  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
 static int g_chol_fused2 = 1;    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
 static int g_zero_copy = 1;      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
+static int g_small_trace = 0;    // ibo_set_option("small_trace", 1: start / 2: print to stderr): host-side split of the zero-copy small batches
+static double g_st_launch = 0.0, g_st_wait = 0.0, g_st_copy = 0.0; static long g_st_n = 0;
 static int g_flag_poll = 1;      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
 static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
 static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
@@ -304,6 +306,11 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "flag_poll")) { g_flag_poll = value; return IBO_OK; }
     if (key && !strcmp(key, "small_inline")) { set_small_inline(value); return IBO_OK; }
     if (key && !strcmp(key, "small_local")) { set_small_local(value); return IBO_OK; }
+    if (key && !strcmp(key, "small_trace")) {
+        if (value == 2 && g_st_n) fprintf(stderr, "[ibo] small batches: %ld, staging + launches %.2f us, wait %.2f us, results %.2f us each\n", g_st_n, g_st_launch / g_st_n, g_st_wait / g_st_n, g_st_copy / g_st_n);
+        g_small_trace = value == 1; g_st_launch = g_st_wait = g_st_copy = 0.0; g_st_n = 0;
+        return IBO_OK;
+    }
     if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
     if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
@@ -1337,6 +1344,8 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     IBO_TRY(ensure_pinned(g, (size_t)M * (g->D + 3)));
     hipStream_t s = g->stream;
     double *pin_in = g->pin, *pin_out = g->pin + (size_t)M * g->D;
+    struct timespec tr0, tr1, tr2, tr3;
+    if (g_small_trace) clock_gettime(CLOCK_MONOTONIC, &tr0);
     memcpy(pin_in, Q_host, sizeof(double) * M * g->D);
     // Batches of at most 8192 points skip the copy launches altogether: pinned host memory is device-visible, the
     // kernels read the few KB of candidates from it and store the results into it (two ~10 us launches per batch).
@@ -1353,6 +1362,7 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     IBO_TRY(run_sweep(g, M, zero_copy ? pin_in : g->cand.p, acq, parm, erf_mode, clamp_lo, ymax, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
                       nullptr, nullptr, false, !zero_copy, zero_copy && g_flag_poll, zero_copy ? pin_in : nullptr));    // small batches: no kernel-time events either
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
+    if (g_small_trace) clock_gettime(CLOCK_MONOTONIC, &tr1);
     if (zero_copy) {
         // a batch of this size is back in tens of microseconds: spin for a moment before handing the thread to the runtime's
         // blocking wait (whose wake-up alone costs about as much as the batch) -- on the word small2.hip's last kernel stores
@@ -1374,10 +1384,16 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
             if ((w1.tv_sec - w0.tv_sec) * 1e6 + (w1.tv_nsec - w0.tv_nsec) * 1e-3 > 300.0) { HIP_TRY(hipStreamSynchronize(s)); break; }
         }
     } else HIP_TRY(hipStreamSynchronize(s));
+    if (g_small_trace) clock_gettime(CLOCK_MONOTONIC, &tr2);
     nout = 0;
     if (mu_host) memcpy(mu_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
     if (s2_host) memcpy(s2_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
     if (acq_host) memcpy(acq_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
+    if (g_small_trace && zero_copy) {
+        clock_gettime(CLOCK_MONOTONIC, &tr3);
+        auto us = [](const timespec &a, const timespec &b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+        g_st_launch += us(tr0, tr1); g_st_wait += us(tr1, tr2); g_st_copy += us(tr2, tr3); g_st_n++;
+    }
     return IBO_OK;
 }
 

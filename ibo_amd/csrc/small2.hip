@@ -281,7 +281,9 @@ __global__ __launch_bounds__(1024) void small_finish_kernel(SweepArgs a, const d
         // every lane's results (possibly in host memory) are out before this workgroup takes its ticket; the last ticket
         // publishes the sequence number the host is waiting for
         __threadfence_system();
-        if (lane == 0) {
+        if (gridDim.x == 1) {                            // at most 64 candidates: this wave IS the batch -- no ticket to take
+            if (lane == 0) *(volatile unsigned long long *)a.done_flag = a.done_seq;
+        } else if (lane == 0) {
             if (atomicAdd(a.done_count, 1u) == gridDim.x - 1) {
                 *a.done_count = 0;
                 __threadfence_system();
