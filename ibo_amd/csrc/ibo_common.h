@@ -191,7 +191,17 @@ struct SweepArgs {
     double *qpart;                       // gemv path scratch: rowchunks x M
     double *mupart;                      // gemv path scratch: 2 x M
     double *result_val; int64_t *result_idx;   // device, single element each
-    int rank1_row;                             // sweep2_rank1_kernel: the appended row of W being folded into the state
+    int rank1_row;                             // sweep2_rank1_kernel: the appended row of W being folded into the state (< 0: only the means are formed)
+    // Kept state of ibo_acq_sweep_incremental (state5 != 0): qpart = [q_a, aY.k*, a1.k*, zsum, q_b][M]; q = (q_a + q_b) + zsum.
+    // q_a: rows [0, h) of W; q_b: rows [h, Npad) -- 0 until the candidate's tile is complete; zsum: the squares the appended rows added.
+    // With q_b missing the candidate's variance is an UPPER bound (q can only grow), so EI / UCB computed from it bound its value.
+    int state5;
+    int part_lo, part_hi;                      // sweep2_kernel<.., PART>: the rows of W this launch covers (part_lo > 0: the second part)
+    int part_rows;                             // the model's rows when the state was formed: later rows never enter q_a / q_b (zsum has them)
+    int *tile_done;                            // per 32-candidate tile: 1 once q_b is in
+    double *tile_ub;                           // per tile: largest value (exact or bound) of its candidates (acq_bound_kernel)
+    unsigned long long *part_thresh;           // order-preserving bits of the value a tile's bound must reach to be completed (0: none)
+    unsigned long long *part_best;             // acq_bound_kernel: running maximum over the COMPLETE tiles, same encoding
     // small2.hip: when set, the last workgroup of the last kernel stores done_seq there (host-visible memory) after all
     // results are out -- the host spins on that word instead of going through an event
     unsigned long long *done_flag; unsigned long long done_seq; unsigned *done_count;
@@ -203,6 +213,14 @@ int launch_sweep_gemv(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent
 // large batches, dot form: 32-candidate tiles, 1024-row panels, exponent GEMM on the MFMA unit (sweep2.hip)
 int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int launch_sweep2_refresh(const SweepArgs &a, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+// first sweep of a kept state with the second part of W only where a tile's bound can still win (sweep2.hip); prune = false:
+// every tile is completed (same launches, same arithmetic -- the reference the pruned run is held to)
+int launch_sweep2_pruned(const SweepArgs &a, bool prune, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+// after launch_sweep2_refresh's rank-1 launches on such a state: complete the tiles whose bound has risen to the best complete value
+int launch_sweep2_complete(const SweepArgs &a, hipStream_t s);
+int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s);
+bool sweep2_part_fits(int Npad, int D);
+int sweep2_part_split(int Npad);
 bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);
 void set_small_inline(int v);

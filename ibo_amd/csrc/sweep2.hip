@@ -39,9 +39,28 @@ __host__ __device__ constexpr int s2_awin(int ka4) { return ka4 <= 5 ? 4096 : 30
 #include "sweep2_dev.h"
 
 // KA4 = ceil((D + 2) / 4): k4-steps of the exponent GEMM
-template <int FAM, int KA4, bool BIGN>          // BIGN: more than s2_awin(KA4) rows -- the alpha vectors' window moves
+// order-preserving encoding of a double as an unsigned integer (atomicMax over values); 0 decodes to a NaN: "no value yet"
+__device__ __forceinline__ unsigned long long s2_enc(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double s2_dec(unsigned long long e)
+{
+    return __longlong_as_double((long long)((e >> 63) ? (e & 0x7fffffffffffffffull) : ~e));
+}
+
+template <int FAM, int KA4, bool BIGN, bool PART = false>   // BIGN: more than s2_awin(KA4) rows -- the alpha vectors' window moves
+                                                            // PART: rows [a.part_lo, a.part_hi) of W only, no means (kept-state sweeps)
 __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 {
+    if (PART && a.part_lo > 0) {
+        // second part: only tiles that are not complete and whose bound reaches the threshold (a bound below it cannot win:
+        // the threshold is a value some complete candidate attains, or the cut that picks the first tiles to complete)
+        if (a.tile_done[blockIdx.x]) return;
+        const unsigned long long th = *a.part_thresh;
+        if (th != 0ull && a.tile_ub[blockIdx.x] < s2_dec(th)) return;
+    }
     constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4, S2_AWIN = s2_awin(KA4);
     static_assert(CBW == 2 && S2_NW * RBW * 16 == S2_PANEL && (S2_KCH / 16) * CBW == S2_NW, "tile geometry");
     __shared__ double lds_k[2][S2_KCH * TCAND];    // K* stages in B-fragment order: [k4-step][cand-block][lane]
@@ -63,9 +82,11 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     lds_tab[tid] = a.exp_tab[tid];
     lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
     const int AW = BIGN ? S2_AWIN : NA128;
-    for (int e = tid; e < AW; e += S2_NW * 64) {                    // both vectors are zero beyond N (abi.hip pads them)
-        lds_alpha[e] = a.alphaY[e];
-        lds_alpha[AW + e] = a.alpha1[e];
+    if (!PART) {
+        for (int e = tid; e < AW; e += S2_NW * 64) {                // both vectors are zero beyond N (abi.hip pads them)
+            lds_alpha[e] = a.alphaY[e];
+            lds_alpha[AW + e] = a.alpha1[e];
+        }
     }
     for (int e = tid; e < TCAND * KA; e += S2_NW * 64) {
         const int c = e / KA, col = e - c * KA;
@@ -144,8 +165,9 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 
     auto run_panel = [&](int p, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const int row0 = (rem == 0) ? p * S2_PANEL : (p == 0 ? 0 : rem + (p - 1) * S2_PANEL);
-        const int row1 = (rem == 0) ? row0 + S2_PANEL : (p == 0 ? rem : row0 + S2_PANEL);
+        // (PART: p counts 1024-row panels from a.part_lo)
+        const int row0 = PART ? a.part_lo + p * S2_PANEL : (rem == 0) ? p * S2_PANEL : (p == 0 ? 0 : rem + (p - 1) * S2_PANEL);
+        const int row1 = PART ? min(row0 + S2_PANEL, a.part_hi) : (rem == 0) ? row0 + S2_PANEL : (p == 0 ? rem : row0 + S2_PANEL);
         const int nstage = (row1 + S2_KCH - 1) / S2_KCH;
         // Row-blocks of this wave, ascending: g = row0/16 + pw + 16 e, e < ne (a short panel has fewer than RBW);
         // row-block g has non-zeros in 8-column steps j < 2g + 2.  They sit in the LAST ne slots, so that the slots
@@ -263,7 +285,11 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 #pragma unroll
             for (int i = 0; i < RBW; i++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) s = fma(acc[i][cb][r], acc[i][cb][r], s);
+                for (int r = 0; r < 4; r++) {
+                    // PART: rows appended to the model after the state was formed are zsum's, whenever this tile is completed
+                    if (PART && 16 * ((row0 >> 4) + pw + S2_NW * (i - (RBW - ne))) + (lane >> 4) + 4 * r >= a.part_rows) continue;
+                    s = fma(acc[i][cb][r], acc[i][cb][r], s);
+                }
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             if (lane < 16) lds_q[wave][cb * 16 + lane] += s;
@@ -276,6 +302,19 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     };
 
     // the last panel sees every k: it also forms the mean.  A short panel (N not a multiple of 1024) comes first.
+    if (PART) {
+        for (int p = 0; a.part_lo + p * S2_PANEL < a.part_hi; p++) run_panel(p, std::false_type{});
+        __syncthreads();
+        if (tid < TCAND) {
+            double q = 0.0;
+#pragma unroll
+            for (int w = 0; w < S2_NW; w++) q += lds_q[w][tid];
+            const int64_t li = tile0 + tid;
+            if (li < a.M) a.qpart[(a.part_lo > 0 ? 4 * a.M : 0) + li] = q;
+        }
+        if (a.part_lo > 0 && tid == 0) a.tile_done[blockIdx.x] = 1;
+        return;
+    }
     for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
     run_panel(npanel - 1, std::true_type{});
     __syncthreads();
@@ -304,7 +343,8 @@ __global__ __launch_bounds__(256) void acq_finish_kernel(SweepArgs a)
     const bool valid = li < a.M;
     const int64_t gi = valid ? li : a.M - 1;
     bool excl;
-    double val = s2_finish(a, a.cand + gi * a.kp.D, a.qpart[gi], a.qpart[a.M + gi], a.qpart[2 * a.M + gi], li, valid, excl);
+    const double q = a.state5 ? (a.qpart[gi] + a.qpart[4 * a.M + gi]) + a.qpart[3 * a.M + gi] : a.qpart[gi];
+    double val = s2_finish(a, a.cand + gi * a.kp.D, q, a.qpart[a.M + gi], a.qpart[2 * a.M + gi], li, valid, excl);
     int64_t idx = a.index_base + li;
     if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
     for (int o = 32; o > 0; o >>= 1) {
@@ -318,6 +358,54 @@ __global__ __launch_bounds__(256) void acq_finish_kernel(SweepArgs a)
         for (int w = 1; w < 4; w++)
             if (sv[w] > val || (sv[w] == val && si[w] < idx)) { val = sv[w]; idx = si[w]; }
         a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx;
+    }
+}
+
+// The kept state's values per TILE of 32 candidates (same arithmetic as acq_finish_kernel): tile_ub = the largest value of the
+// tile -- exact where the tile is complete, an upper bound where q_b is missing (EI and UCB grow with the variance) --, and the
+// maximum over the complete tiles into *part_best.  No arg-max: this only decides which tiles must be completed (the caller
+// passes no per-candidate output arrays).
+__global__ __launch_bounds__(256) void acq_bound_kernel(SweepArgs a)
+{
+    const int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = li < a.M;
+    const int64_t gi = valid ? li : a.M - 1;
+    bool excl;
+    const double q = (a.qpart[gi] + a.qpart[4 * a.M + gi]) + a.qpart[3 * a.M + gi];
+    double val = s2_finish(a, a.cand + gi * a.kp.D, q, a.qpart[a.M + gi], a.qpart[2 * a.M + gi], li, valid, excl);
+    if (!valid || excl || !(val == val)) val = -INFINITY;
+    for (int o = 16; o > 0; o >>= 1) val = fmax(val, __shfl_xor(val, o));          // the 32 candidates of a tile: half a wave
+    if ((threadIdx.x & 31) == 0 && valid) {
+        const int64_t tile = li >> 5;
+        a.tile_ub[tile] = val;
+        if (a.tile_done[tile] && val > -INFINITY) atomicMax(a.part_best, s2_enc(val));
+    }
+}
+
+// The cut that picks the FIRST tiles to complete, when no tile is complete yet: the bound of the tile ranked ~3 % from the top
+// among 1024 evenly spaced tiles (one workgroup, bitonic sort in LDS).  The tiles at or above it very likely hold the maximum,
+// and whatever value they reach is the threshold for everyone else.
+__global__ __launch_bounds__(1024) void part_select_kernel(const double *__restrict__ tile_ub, int64_t ntiles, unsigned long long *thresh)
+{
+    __shared__ double v[1024];
+    const int t = threadIdx.x;
+    const int64_t n = ntiles < 1024 ? ntiles : 1024;
+    v[t] = t < n ? tile_ub[(int64_t)t * ntiles / n] : -INFINITY;
+    __syncthreads();
+    for (int k = 2; k <= 1024; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int o = t ^ j;
+            if (o > t) {
+                const bool desc = (t & k) == 0;
+                const double x = v[t], y = v[o];
+                if (desc ? x < y : x > y) { v[t] = y; v[o] = x; }
+            }
+            __syncthreads();
+        }
+    if (t == 0) {
+        const int64_t k = n * 3 / 100;
+        const double cut = v[k];
+        *thresh = cut > -INFINITY ? s2_enc(cut) : 0ull;
     }
 }
 
@@ -344,7 +432,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
     for (int e = tid; e < NA128; e += S2_NW * 64) {
         lds_vec[e] = a.alphaY[e];
         lds_vec[NA128 + e] = a.alpha1[e];
-        lds_vec[2 * NA128 + e] = e <= row ? a.W[(size_t)row * Npad + e] : 0.0;
+        lds_vec[2 * NA128 + e] = (row >= 0 && e <= row) ? a.W[(size_t)row * Npad + e] : 0.0;
     }
     for (int e = tid; e < TCAND * KA; e += S2_NW * 64) {
         const int c = e / KA, col = e - c * KA;
@@ -369,7 +457,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
     const __amdgpu_buffer_rsrc_t rXA = s2_rsrc(a.XA, (size_t)(NA128 / 16) * KA4 * 64 * sizeof(double));
     const unsigned lane8 = lane * 8;
     const double *vq = lds_vec + (lane >> 4);
-    const int nstage = (row + 1 + S2_KCH - 1) / S2_KCH;
+    const int nstage = row >= 0 ? (row + 1 + S2_KCH - 1) / S2_KCH : NA128 / S2_KCH;      // (row < 0: only the means, over every row)
     double muY = 0.0, mu1 = 0.0, nu = 0.0;
     double xa[KA4], xn[KA4];
 #pragma unroll
@@ -413,7 +501,10 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
             my += lds_m[0][2 * w + (c >> 4)][c & 15]; m1 += lds_m[1][2 * w + (c >> 4)][c & 15]; v += lds_m[2][2 * w + (c >> 4)][c & 15];
         }
         const int64_t li = tile0 + c;
-        if (li < a.M) { a.qpart[li] = fma(v, v, a.qpart[li]); a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1; }
+        if (li < a.M) {
+            if (row >= 0) a.qpart[3 * a.M + li] = fma(v, v, a.qpart[3 * a.M + li]);
+            a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1;
+        }
     }
 }
 
@@ -518,6 +609,110 @@ static int launch_s2_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     }
 }
 
+// ---- kept-state sweeps that run the second part of W only where it can matter ---------------------------------------------
+template <int FAM, int KA4>
+static int launch_s2_part_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    hipLaunchKernelGGL((sweep2_kernel<FAM, KA4, false, true>), dim3((unsigned)ntiles), dim3(S2_NW * 64), 0, s, a);
+    return (int)hipGetLastError();
+}
+template <int FAM>
+static int launch_s2_part_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
+{
+    switch ((a.kp.D + 2 + 3) / 4) {
+    case 1: return launch_s2_part_one<FAM, 1>(a, ntiles, s);
+    case 2: return launch_s2_part_one<FAM, 2>(a, ntiles, s);
+    case 3: return launch_s2_part_one<FAM, 3>(a, ntiles, s);
+    case 4: return launch_s2_part_one<FAM, 4>(a, ntiles, s);
+    case 5: return launch_s2_part_one<FAM, 5>(a, ntiles, s);
+    case 6: return launch_s2_part_one<FAM, 6>(a, ntiles, s);
+    case 7: return launch_s2_part_one<FAM, 7>(a, ntiles, s);
+    case 8: return launch_s2_part_one<FAM, 8>(a, ntiles, s);
+    default: return launch_s2_part_one<FAM, 9>(a, ntiles, s);
+    }
+}
+static int launch_s2_part(const SweepArgs &a, int lo, int hi, unsigned long long *thresh, hipStream_t s)
+{
+    const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
+    SweepArgs b = a;
+    b.part_lo = lo; b.part_hi = hi; b.part_thresh = thresh;
+    if (a.kp.family == FAM_SE) return launch_s2_part_fam<FAM_SE>(b, ntiles, s);
+    if (a.kp.family == FAM_M3) return launch_s2_part_fam<FAM_M3>(b, ntiles, s);
+    return launch_s2_part_fam<FAM_M5>(b, ntiles, s);
+}
+static int launch_s2_means(const SweepArgs &a0, hipStream_t s)
+{
+    const int64_t ntiles = (a0.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
+    SweepArgs a = a0;
+    a.rank1_row = -1;
+    if (a.kp.family == FAM_SE) return launch_s2_rank1_fam<FAM_SE>(a, ntiles, s);
+    if (a.kp.family == FAM_M3) return launch_s2_rank1_fam<FAM_M3>(a, ntiles, s);
+    return launch_s2_rank1_fam<FAM_M5>(a, ntiles, s);
+}
+static int launch_s2_bound(const SweepArgs &a0, hipStream_t s)
+{
+    SweepArgs a = a0;
+    a.out_mu = a.out_s2 = a.out_acq = nullptr;
+    hipError_t e = hipMemsetAsync(a.part_best, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(acq_bound_kernel, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+// the part kernel has no moving alpha window and the means come from the refresh kernel: both must fit
+bool sweep2_part_fits(int Npad, int D) { return Npad >= 512 && ((Npad + 127) & ~127) <= s2_awin((D + 2 + 3) / 4) && sweep2_rank1_fits(Npad, D); }
+// rows of the first part: half of them, a quarter of the work (W is triangular)
+int sweep2_part_split(int Npad) { return ((Npad / 2 + 127) / 128) * 128; }
+
+// First sweep of a kept state (a.qpart = [q_a, aY.k*, a1.k*, zsum, q_b][M], zsum and q_b and a.tile_done zeroed by the caller;
+// a.part_best / a.part_thresh: two device words): rows [0, h) for everyone, the means, the bounds, then the second part for the
+// tiles at the top of the bound ranking, then -- against the best value THOSE reached -- for whoever's bound still reaches it.
+// A tile left incomplete has a bound below a value that a complete candidate attains: it cannot hold the maximum, and the
+// arg-max over (exact where complete, bound elsewhere) is the arg-max of the full sweep.  prune = false completes every tile.
+int launch_sweep2_pruned(const SweepArgs &a, bool prune, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int h = sweep2_part_split(a.Npad), hi = (a.part_rows + 15) & ~15;
+    const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
+    if (e0) (void)hipEventRecord(e0, s);
+    int rc = launch_s2_part(a, 0, h, a.part_thresh, s);
+    if (rc) return rc;
+    if ((rc = launch_s2_means(a, s))) return rc;
+    if (prune) {
+        if ((rc = launch_s2_bound(a, s))) return rc;                               // bounds; nothing complete yet
+        hipLaunchKernelGGL(part_select_kernel, dim3(1), dim3(1024), 0, s, (const double *)a.tile_ub, ntiles, a.part_thresh);
+        if ((rc = launch_s2_part(a, h, hi, a.part_thresh, s))) return rc;          // the top of the ranking
+        if ((rc = launch_s2_bound(a, s))) return rc;                               // best value among the complete
+        if ((rc = launch_s2_part(a, h, hi, a.part_best, s))) return rc;            // everyone who can still reach it
+    } else {
+        hipError_t e = hipMemsetAsync(a.part_thresh, 0, sizeof(unsigned long long), s);
+        if (e != hipSuccess) return (int)e;
+        if ((rc = launch_s2_part(a, h, hi, a.part_thresh, s))) return rc;
+    }
+    if (e1) (void)hipEventRecord(e1, s);
+    const int64_t nfin = (a.M + 255) / 256;
+    hipLaunchKernelGGL(acq_finish_kernel, dim3((unsigned)nfin), dim3(256), 0, s, a);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return launch_argmax_final(a, nfin, s);
+}
+
+// after the rank-1 launches of a refresh on such a state (zsum and the means are current): the tiles whose bound now reaches the
+// best complete value get their second part; to be followed by acq_finish_kernel (launch_sweep2_refresh does both)
+int launch_sweep2_complete(const SweepArgs &a, hipStream_t s)
+{
+    int rc = launch_s2_bound(a, s);
+    if (rc) return rc;
+    return launch_s2_part(a, sweep2_part_split(a.Npad), (a.part_rows + 15) & ~15, a.part_best, s);
+}
+
+// every incomplete tile of such a state gets its second part (a caller that needs each candidate's full variance)
+int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(a.part_thresh, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return (int)e;
+    return launch_s2_part(a, sweep2_part_split(a.Npad), (a.part_rows + 15) & ~15, a.part_thresh, s);
+}
+
 // rows [row_first, row_last] were appended to the model since a.qpart (the kept state [3][M]) was last brought up to
 // date: one refresh launch per row, then the acquisition as after a full sweep
 int launch_sweep2_refresh(const SweepArgs &a0, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
@@ -531,6 +726,10 @@ int launch_sweep2_refresh(const SweepArgs &a0, int row_first, int row_last, hipS
         if (a.kp.family == FAM_SE) rc = launch_s2_rank1_fam<FAM_SE>(a, ntiles, s);
         else if (a.kp.family == FAM_M3) rc = launch_s2_rank1_fam<FAM_M3>(a, ntiles, s);
         else rc = launch_s2_rank1_fam<FAM_M5>(a, ntiles, s);
+        if (rc) return rc;
+    }
+    if (a0.tile_done) {                              // a state with incomplete tiles: whoever's bound has caught up is completed first
+        int rc = launch_sweep2_complete(a0, s);
         if (rc) return rc;
     }
     if (e1) (void)hipEventRecord(e1, s);

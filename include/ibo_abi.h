@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IBO_ABI_VERSION 4   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation */
+#define IBO_ABI_VERSION 5   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info */
 
 /* status codes */
 #define IBO_OK              0
@@ -281,6 +281,16 @@ int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
  * array that was freed and reallocated at the same address, or overwritten through ibo_memcpy_h2d, is a different one,
  * and memory the library did not allocate is swept in full every time.  Contents changed behind the library's back (the
  * caller's own kernels or hipMemcpy) are the one thing it cannot see.
+ *
+ * When only the arg-max is asked for (mu_dev, s2_dev and acq_dev all NULL) and the acquisition grows with the variance
+ * (IBO_ACQ_EI, IBO_ACQ_UCB), the state is formed in two parts of W's rows: q_a over the first half (a quarter of the work: W
+ * is triangular) for every candidate; q_b over the rest only for the 32-candidate tiles whose BOUND -- the acquisition at
+ * the variance 1 + noise - q_a, which can only shrink as rows are added -- reaches a value that a complete candidate
+ * attains.  The returned (best_val, best_idx) are those of the full sweep: a tile left incomplete cannot hold the maximum.
+ * Later calls fold the appended rows in as before and complete whichever tiles' bounds have caught up with the best
+ * complete value; a call that wants per-candidate outputs (or IBO_ACQ_PI / IBO_ACQ_NONE) completes every tile first.
+ * 512 <= padded rows <= 4096; 40 bytes of state per candidate.  ibo_set_option("gallery_prune", 0) restores the one-kernel
+ * first sweep, 2 runs the two-part launches with every tile completed (what the pruned run is tested against, bit for bit).
  */
 int ibo_acq_sweep_incremental(ibo_gp_t *gp, int64_t M, const double *cand_dev,
                               int acq, double parm, int erf_mode, double clamp_lo, double ymax,
@@ -288,6 +298,10 @@ int ibo_acq_sweep_incremental(ibo_gp_t *gp, int64_t M, const double *cand_dev,
                               int64_t index_base,
                               double *mu_dev, double *s2_dev, double *acq_dev,
                               double *best_val, int64_t *best_idx);
+
+/* the kept state of ibo_acq_sweep_incremental: its 32-candidate tiles and how many of them carry their full variance
+ * (equal unless the state was formed in two parts); both 0 when the handle keeps no state */
+int ibo_sweep_state_info(ibo_gp_t *gp, int64_t *tiles, int64_t *complete);
 
 /* device-side duration (hipEvent, ms) of the dominant kernel of the last
  * ibo_acq_sweep / ibo_posterior_batch on this handle, and its name */

@@ -518,7 +518,8 @@ def test_incremental_sweep_state_equals_full_sweeps(ibo):
         assert sweep(GP, dc, incremental=True)["kernel"] == "sweep2_rank1_kernel"      # the row added in the last round
         assert sweep(GP, dc, incremental=True)["kernel"] == "acq_finish_kernel"        # nothing new: acquisition only
         other = DeviceArray.from_host(np.random.RandomState(72).rand(9001, D))
-        assert sweep(GP, other, incremental=True)["kernel"] == "sweep2_kernel"
+        # (another array: a new state -- arg-max only, so in two parts where the model has the 512 padded rows for it)
+        assert sweep(GP, other, incremental=True)["kernel"] == ("sweep2_kernel<part>" if N0 >= 500 else "sweep2_kernel")
     # the gallery is the caller: same picks with and without the kept state
     X, Y = synth(75, 600, 3)
     GP = GaussianProcess(K.GaussianKernel_ard([.25, .3, .35]), X, Y, noise=.1)
@@ -527,6 +528,65 @@ def test_incremental_sweep_state_equals_full_sweeps(ibo):
     g_inc = np.array(fastUCBGallery(GP, b, 6, candidates=cand))
     g_full = np.array(fastUCBGallery(GP, b, 6, lhc_per_round=[cand] * 6))
     np.testing.assert_array_equal(g_inc, g_full)
+
+
+def test_two_part_kept_state_finds_the_full_sweeps_maximum(ibo):
+    """ibo_acq_sweep_incremental, arg-max only, EI / UCB: the state is formed over the first half of W's rows, the second half
+    runs only for tiles whose bound can still win (gallery_prune = 1).  Every round of a gallery-like sequence returns the
+    (value, index) of the same launches with every tile completed (gallery_prune = 2) BIT FOR BIT, the index of the one-kernel
+    sweep (0) and of a freshly fitted model's full sweep, values at 1e-9; tiles really are left incomplete; a later call that
+    wants per-candidate outputs completes them and equals the full sweep's outputs."""
+    import ctypes
+    from ibo_amd import DeviceArray, _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.acquisition import sweep
+    opt = lambda v: _lib.check(_lib.lib.ibo_set_option(b"gallery_prune", v))
+    def state_info(GP):
+        t, c = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib.ibo_sweep_state_info(GP._handle(), ctypes.byref(t), ctypes.byref(c)))
+        return t.value, c.value
+    try:
+        for N0, D, kern, acq, kw in ((1000, 4, K.GaussianKernel_ard([.3] * 4), 'ei', dict(xi=.4, native=False)),
+                                      (2040, 8, K.MaternKernel5([.5, 1.0]), 'ucb', dict()),
+                                      (700, 2, K.MaternKernel3([.4, 1.0]), 'ei', dict(xi=.01))):
+            X, Y = synth(170 + D, N0, D)
+            cand = np.random.RandomState(171).rand(40000 + 7, D)
+            runs = {}
+            for mode in (1, 2, 0):
+                opt(mode)
+                GP = GaussianProcess(kern, X, Y, noise=.01)
+                dc = DeviceArray.from_host(cand)
+                out, shown = [], []
+                for rnd in range(6):
+                    excl = np.array(shown[:2]) if rnd >= 3 else None
+                    r = sweep(GP, dc, acq=acq, exclude=excl, exclude_radius=.05, incremental=True, **kw)
+                    tiles, done = state_info(GP)
+                    out.append((r["best_val"], r["best_idx"], r["kernel"], tiles, done))
+                    if mode == 1:        # against a freshly fitted model's full sweep
+                        ref = GaussianProcess(kern, GP.X, GP.Y, noise=.01)
+                        f = sweep(ref, dc, acq=acq, exclude=excl, exclude_radius=.05, **kw)
+                        assert f["best_idx"] == r["best_idx"]; close(r["best_val"], f["best_val"], rtol=1e-9)
+                    x = cand[r["best_idx"]]
+                    shown.append(x)
+                    GP.addData(x, GP.mu(x))                 # the gallery's hallucinated observation
+                if mode == 1:
+                    full = sweep(GP, dc, acq=acq, incremental=True, outputs=("mu", "s2", "acq"), **kw)     # outputs: every tile completed first
+                    assert state_info(GP)[0] == state_info(GP)[1]
+                    ref = GaussianProcess(kern, GP.X, GP.Y, noise=.01)
+                    f = sweep(ref, dc, acq=acq, outputs=("mu", "s2", "acq"), **kw)
+                    close(full["mu"], f["mu"], rtol=1e-9, atol=1e-10); close(full["s2"], f["s2"], rtol=1e-9); close(full["acq"], f["acq"], rtol=1e-9, atol=ACQ_ATOL)
+                    assert full["best_idx"] == f["best_idx"]
+                runs[mode] = out
+            for a, b, c in zip(runs[1], runs[2], runs[0]):
+                assert a[0] == b[0] and a[1] == b[1], (a, b)                 # pruned == complete, bit for bit
+                assert a[1] == c[1]; close(a[0], c[0], rtol=1e-9)
+            assert runs[1][0][2] == "sweep2_kernel<part>" and runs[0][0][2] == "sweep2_kernel" and runs[1][1][2] == "sweep2_rank1_kernel"
+            assert all(t == d for _, _, _, t, d in runs[2]) and all(t == d for _, _, _, t, d in runs[0])
+            assert runs[1][0][4] < runs[1][0][3] // 2, runs[1][0]            # more than half of the tiles never ran their second part
+            assert all(x[4] <= y[4] for x, y in zip(runs[1], runs[1][1:]))  # and completion only ever grows
+    finally:
+        opt(1)
 
 
 def test_incremental_state_cannot_alias_another_array(ibo):
