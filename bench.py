@@ -593,6 +593,27 @@ def worker(args):
                         del g
                     del cd
                 cfgs["sweep_by_dimension"] = {"workload": "N=1024, EI over 2^18 candidates, kernel time (HIP events)", "results": dims}
+                # The exact arg-max WITHOUT the per-candidate values (round-2 review, item 9) -- under its own key, never the headline:
+                # work is skipped.  ibo_acq_sweep_incremental on a fresh array forms its state over the first half of W's rows and runs
+                # the second half only for the 32-candidate tiles whose EI bound reaches the best complete value (what the gallery's
+                # first round does); the winner is the full sweep's.
+                import ctypes as _ct
+                am = []
+                for _ in range(4):
+                    ca = DeviceArray.from_host(cand_host, local_rank)        # a new array: no kept state
+                    _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
+                    t0 = time.perf_counter()
+                    ra = sweep(GP, ca, acq='ei', xi=.01, native=True, index_base=start, incremental=True)
+                    am.append((time.perf_counter() - t0) * 1e3)
+                    tl, dn = _ct.c_int64(), _ct.c_int64()
+                    _lib.check(_lib.lib.ibo_sweep_state_info(GP._handle(), _ct.byref(tl), _ct.byref(dn)))
+                    del ca
+                cfgs["argmax_only"] = {"workload": "C2 shape, arg-max of EI only: kept-state sweep in two parts of W's rows (first call on a new array)",
+                                       "ms": float(np.median(am[1:])), "full_sweep_ms": elapsed / args.steps * 1e3,
+                                       "tiles": int(tl.value), "tiles_with_second_part": int(dn.value),
+                                       "second_part_skipped_frac": 1.0 - dn.value / max(1, tl.value),
+                                       "same_index_as_full_sweep": bool(ra["best_idx"] == outs[-1][1]),
+                                       "value_rel_diff_to_full_sweep": float(abs(ra["best_val"] - outs[-1][0]) / abs(outs[-1][0]))}
             if rank == 0:
                 out["configs"] = cfgs
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
