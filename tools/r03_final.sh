@@ -11,6 +11,9 @@ python3 bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > profiles/$
 python3 bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > profiles/${TAG}_bench_c5_n1.json 2> $O/bench_c5.err
 python3 tools/run_configs.py c2 c3 c4 c5 > profiles/${TAG}_configs_c2_c5.jsonl 2> $O/configs.err
 { python3 tools/time_fit.py; python3 tools/time_direct.py; python3 tools/time_single_calls.py; python3 tools/time_learn.py; python3 tools/sweep_vs_dim.py; } > profiles/${TAG}_latencies.txt 2> $O/lat.err
+python3 tools/time_incremental.py > profiles/${TAG}_time_incremental.txt 2> $O/inc.err
+{ [ -x tools/launch_floor ] && tools/launch_floor; python3 tools/time_small_split.py 2>&1; } > profiles/${TAG}_direct_batch_floor.txt 2> $O/floor.err
+timeout 600 python3 tools/fuzz_nlml.py 60 7 > $O/fuzz_nlml.txt 2>&1; tail -4 $O/fuzz_nlml.txt > profiles/${TAG}_fuzz_nlml_summary.txt
 for n in 1024 2048 4096; do bash tools/fit_trace.sh $n > profiles/${TAG}_fit_trace_$n.txt 2>&1; done
 FUZZ_DIRECT_CASES=12 timeout 1500 python3 tools/fuzz_gpu.py 200 3 > $O/fuzz.txt 2>&1; { grep -c "rel err" $O/fuzz.txt; grep "FAIL" $O/fuzz.txt | head; grep "worst" $O/fuzz.txt; sort -t'e' -k1 $O/fuzz.txt | grep "rel err" | awk '{print}' | sort -k14 -g | tail -5; tail -4 $O/fuzz.txt; } > profiles/${TAG}_fuzz_summary.txt
 tail -3 profiles/${TAG}_latencies.txt; cat profiles/${TAG}_configs_c2_c5.jsonl | cut -c1-300
