@@ -234,30 +234,32 @@ __global__ __launch_bounds__(SM_NW * 64) void wkl_small_kernel(InlineCand ic, Sw
     }
 }
 
-// 64 candidates per workgroup of 1024 threads: sixteen threads per candidate each sum a contiguous sixteenth of the row-blocks'
-// q (all their loads in flight at once: one L2 round trip instead of nrb / 16 dependent ones -- the kernel was 7 of a DIRECT
-// batch's 22 us), the stages' mean parts likewise; the sixteen partial sums are added in index order by the candidate's first
+// 64 candidates per workgroup of 512 threads: eight threads per candidate each sum a contiguous eighth of the row-blocks'
+// q (all their loads in flight at once: one L2 round trip instead of nrb / 8 dependent ones -- the kernel was 7 of a DIRECT
+// batch's 22 us), the stages' mean parts likewise; the eight partial sums are added in index order by the candidate's first
 // thread, which then evaluates the acquisition.  Every sum has a fixed order: the result does not depend on scheduling.
-__global__ __launch_bounds__(1024) void small_finish_kernel(SweepArgs a, const double *__restrict__ qpart, const double *__restrict__ mupart, int Mp,
-                                                            int nrb, int nst)
+// (512 threads, not 1024: the acquisition's erf / exp chains want more than the 128 registers a 1024-thread workgroup leaves a lane.)
+#define SM_FIN_P 8
+__global__ __launch_bounds__(SM_FIN_P * 64) void small_finish_kernel(SweepArgs a, const double *__restrict__ qpart, const double *__restrict__ mupart, int Mp,
+                                                                     int nrb, int nst)
 {
-    __shared__ double lds_q[16][64], lds_y[16][64], lds_1[16][64];
+    __shared__ double lds_q[SM_FIN_P][64], lds_y[SM_FIN_P][64], lds_1[SM_FIN_P][64];
     const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
     const int64_t li = (int64_t)blockIdx.x * 64 + lane;
     const bool valid = li < a.M;
     const int64_t ci = valid ? li : a.M - 1;
     {
-        const int per = (nrb + 15) >> 4, g0 = p * per;
-        double v[8];
+        const int per = (nrb + SM_FIN_P - 1) / SM_FIN_P, g0 = p * per;
+        double v[16];
         double qs = 0.0;
-        for (int gb = 0; gb < per; gb += 8) {            // (per <= 8 up to N = 2048: one round)
+        for (int gb = 0; gb < per; gb += 16) {           // (per <= 16 up to N = 2048: one round)
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = (gb + u < per && g0 + gb + u < nrb) ? qpart[(size_t)(g0 + gb + u) * Mp + ci] : 0.0;
+            for (int u = 0; u < 16; u++) v[u] = (gb + u < per && g0 + gb + u < nrb) ? qpart[(size_t)(g0 + gb + u) * Mp + ci] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (gb + u < per && g0 + gb + u < nrb) qs += v[u];
+            for (int u = 0; u < 16; u++) if (gb + u < per && g0 + gb + u < nrb) qs += v[u];
         }
         lds_q[p][lane] = qs;
-        const int pers = (nst + 15) >> 4, t0 = p * pers;
+        const int pers = (nst + SM_FIN_P - 1) / SM_FIN_P, t0 = p * pers;
         double ys = 0.0, os = 0.0;
         for (int t = t0; t < t0 + pers && t < nst; t++) { ys += mupart[(size_t)(2 * t) * Mp + ci]; os += mupart[(size_t)(2 * t + 1) * Mp + ci]; }
         lds_y[p][lane] = ys; lds_1[p][lane] = os;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(1024) void small_finish_kernel(SweepArgs a, const d
     if (p != 0) return;
     double q = 0.0, my = 0.0, m1 = 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; u++) { q += lds_q[u][lane]; my += lds_y[u][lane]; m1 += lds_1[u][lane]; }
+    for (int u = 0; u < SM_FIN_P; u++) { q += lds_q[u][lane]; my += lds_y[u][lane]; m1 += lds_1[u][lane]; }
     bool excl;
     double val = s2_finish(a, a.cand + ci * a.kp.D, q, my, m1, li, valid, excl);
     int64_t idx = a.index_base + li;
@@ -328,16 +330,10 @@ static int launch_wkl_small(const SweepArgs &a, double *qpart, double *mupart, i
         memcpy(ic.v, a.cand_host, sizeof(double) * (size_t)(a.M * a.kp.D));
         inl = 1;
     }
-    switch ((a.kp.D + 2 + 3) / 4) {
+    switch ((a.kp.D + 2 + 3) / 4) {           // (up to 10 dimensions: beyond, the tile's X fragments push the kernel into scratch, and the two-kernel path runs)
     case 1: hipLaunchKernelGGL((wkl_small_kernel<FAM, 1>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
     case 2: hipLaunchKernelGGL((wkl_small_kernel<FAM, 2>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 3: hipLaunchKernelGGL((wkl_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 4: hipLaunchKernelGGL((wkl_small_kernel<FAM, 4>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 5: hipLaunchKernelGGL((wkl_small_kernel<FAM, 5>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 6: hipLaunchKernelGGL((wkl_small_kernel<FAM, 6>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 7: hipLaunchKernelGGL((wkl_small_kernel<FAM, 7>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    case 8: hipLaunchKernelGGL((wkl_small_kernel<FAM, 8>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
-    default: hipLaunchKernelGGL((wkl_small_kernel<FAM, 9>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
+    default: hipLaunchKernelGGL((wkl_small_kernel<FAM, 3>), grid, dim3(SM_NW * 64), 0, s, ic, a, qpart, mupart, Mp, inl); break;
     }
     return (int)hipGetLastError();
 }
@@ -362,7 +358,7 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     // 4.4 us at N = 64, but 15 us at N = 1024 and 28-34 us at N = 2048 against 6 + 8.6 / 6 + 16 for the two separate kernels --
     // its 14-instruction exp() chains are then the throughput of the 128 CUs it occupies.  (A stage-by-stage fusion through an
     // LDS stage and a barrier per 128 rows was measured too: 0.6 us per stage, slower from N = 512 on, and removed.)
-    if (g_small_local && ctiles <= 4 && (nrb <= 32 || g_small_local > 1)) {
+    if (g_small_local && ctiles <= 4 && (nrb <= 32 || g_small_local > 1) && a.kp.D <= 10) {
         const dim3 gl(ctiles, nrb);
         if (a.kp.family == FAM_SE) rc = launch_wkl_small<FAM_SE>(a, qpart, mupart, Mp, gl, s);
         else if (a.kp.family == FAM_M3) rc = launch_wkl_small<FAM_M3>(a, qpart, mupart, Mp, gl, s);
@@ -379,7 +375,7 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a.M + 63) / 64;
-    hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(1024), 0, s, a, qpart, mupart, Mp, nrb, nst_fin);
+    hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(SM_FIN_P * 64), 0, s, a, qpart, mupart, Mp, nrb, nst_fin);
     rc = (int)hipGetLastError();
     if (rc) return rc;
     return launch_argmax_final(a, nfin, s);
