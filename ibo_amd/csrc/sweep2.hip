@@ -661,8 +661,10 @@ static int launch_s2_bound(const SweepArgs &a0, hipStream_t s)
 
 // the part kernel has no moving alpha window and the means come from the refresh kernel: both must fit
 bool sweep2_part_fits(int Npad, int D) { return Npad >= 512 && ((Npad + 127) & ~127) <= s2_awin((D + 2 + 3) / 4) && sweep2_rank1_fits(Npad, D); }
-// rows of the first part: half of them, a quarter of the work (W is triangular)
-int sweep2_part_split(int Npad) { return ((Npad / 2 + 127) / 128) * 128; }
+// rows of the first part: half of them, a quarter of the work (W is triangular) -- the multiple of 128 NEAREST to half: rounding
+// up (640 of 1088 padded rows) cost 35 % of a sweep for the first part where 512 costs 22 % (CPU estimate of the total,
+// tools/argmax_bound_probe2.py: 41 % / 31 % / 36 % of a full sweep for h = 5/8, 1/2, 3/8 of the rows)
+int sweep2_part_split(int Npad) { return ((Npad / 2 + 64) / 128) * 128; }
 
 // First sweep of a kept state (a.qpart = [q_a, aY.k*, a1.k*, zsum, q_b][M], zsum and q_b and a.tile_done zeroed by the caller;
 // a.part_best / a.part_thresh: two device words): rows [0, h) for everyone, the means, the bounds, then the second part for the
