@@ -200,7 +200,8 @@ struct SweepArgs {
     int part_rows;                             // the model's rows when the state was formed: later rows never enter q_a / q_b (zsum has them)
     int *tile_done;                            // per 32-candidate tile: 1 once q_b is in
     double *tile_ub;                           // per tile: largest value (exact or bound) of its candidates (acq_bound_kernel)
-    unsigned long long *part_thresh;           // order-preserving bits of the value a tile's bound must reach to be completed (0: none)
+    unsigned long long *part_thresh;           // order-preserving bits of the value a tile's bound must reach to be completed (0: any finite bound)
+    int part_all;                              // complete every incomplete tile, whatever its bound
     unsigned long long *part_best;             // acq_bound_kernel: running maximum over the COMPLETE tiles, same encoding
     // small2.hip: when set, the last workgroup of the last kernel stores done_seq there (host-visible memory) after all
     // results are out -- the host spins on that word instead of going through an event

@@ -28,6 +28,7 @@
 // for the small-batch SPLIT / GEMV paths, sweep.hip's kernels run).
 #include "ibo_common.h"
 #include <type_traits>
+#include <cfloat>
 
 #define S2_NW 16
 #define S2_KCH 128                     // k* rows per LDS stage
@@ -58,8 +59,11 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
         // second part: only tiles that are not complete and whose bound reaches the threshold (a bound below it cannot win:
         // the threshold is a value some complete candidate attains, or the cut that picks the first tiles to complete)
         if (a.tile_done[blockIdx.x]) return;
-        const unsigned long long th = *a.part_thresh;
-        if (th != 0ull && a.tile_ub[blockIdx.x] < s2_dec(th)) return;
+        if (!a.part_all) {
+            // (no threshold yet: every tile with an admissible candidate; a tile whose candidates are all excluded never needs its variance)
+            const unsigned long long th = *a.part_thresh;
+            if (!(a.tile_ub[blockIdx.x] >= (th != 0ull ? s2_dec(th) : -DBL_MAX))) return;
+        }
     }
     constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4, S2_AWIN = s2_awin(KA4);
     static_assert(CBW == 2 && S2_NW * RBW * 16 == S2_PANEL && (S2_KCH / 16) * CBW == S2_NW, "tile geometry");
@@ -686,9 +690,9 @@ int launch_sweep2_pruned(const SweepArgs &a, bool prune, hipStream_t s, hipEvent
         if ((rc = launch_s2_bound(a, s))) return rc;                               // best value among the complete
         if ((rc = launch_s2_part(a, h, hi, a.part_best, s))) return rc;            // everyone who can still reach it
     } else {
-        hipError_t e = hipMemsetAsync(a.part_thresh, 0, sizeof(unsigned long long), s);
-        if (e != hipSuccess) return (int)e;
-        if ((rc = launch_s2_part(a, h, hi, a.part_thresh, s))) return rc;
+        SweepArgs b = a;
+        b.part_all = 1;
+        if ((rc = launch_s2_part(b, h, hi, a.part_thresh, s))) return rc;
     }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a.M + 255) / 256;
@@ -710,9 +714,9 @@ int launch_sweep2_complete(const SweepArgs &a, hipStream_t s)
 // every incomplete tile of such a state gets its second part (a caller that needs each candidate's full variance)
 int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(a.part_thresh, 0, sizeof(unsigned long long), s);
-    if (e != hipSuccess) return (int)e;
-    return launch_s2_part(a, sweep2_part_split(a.Npad), (a.part_rows + 15) & ~15, a.part_thresh, s);
+    SweepArgs b = a;
+    b.part_all = 1;
+    return launch_s2_part(b, sweep2_part_split(a.Npad), (a.part_rows + 15) & ~15, a.part_thresh, s);
 }
 
 // rows [row_first, row_last] were appended to the model since a.qpart (the kept state [3][M]) was last brought up to

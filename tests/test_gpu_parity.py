@@ -589,6 +589,56 @@ def test_two_part_kept_state_finds_the_full_sweeps_maximum(ibo):
         opt(1)
 
 
+def test_two_part_kept_state_edge_cases(ibo):
+    """the pruned state where its bookkeeping could slip: a candidate count that is no multiple of the tile, every candidate
+    duplicated in another tile (the LOWER index must win the tie, so the tile of the first copy may not be left incomplete), most
+    of the array inside exclusion balls, all of it inside them (nothing admissible), and PI on a pruned state (not monotone in the
+    variance: every tile is completed first)."""
+    import ctypes
+    from ibo_amd import DeviceArray, _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.acquisition import sweep
+    opt = lambda v: _lib.check(_lib.lib.ibo_set_option(b"gallery_prune", v))
+    def state_info(GP):
+        t, c = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib.ibo_sweep_state_info(GP._handle(), ctypes.byref(t), ctypes.byref(c)))
+        return t.value, c.value
+    X, Y = synth(181, 900, 3)
+    base = np.random.RandomState(182).rand(10000 + 13, 3)
+    cand = np.vstack([base, base])                                  # every point twice, 10013 rows apart: never in the same tile
+    kern = K.GaussianKernel_ard([.3] * 3)
+    try:
+        res = {}
+        for mode in (1, 0):
+            opt(mode)
+            GP = GaussianProcess(kern, X, Y, noise=.01)
+            dc = DeviceArray.from_host(cand)
+            out = []
+            r = sweep(GP, dc, acq='ei', xi=.1, native=False, incremental=True); out.append((r["best_idx"], r["best_val"]))
+            assert r["best_idx"] < len(base)                         # first of the two equal maxima
+            GP.addData(cand[r["best_idx"]], GP.mu(cand[r["best_idx"]]))
+            far = cand[np.linalg.norm(cand - cand[r["best_idx"]], axis=1) > .9][:1]
+            balls = np.vstack([cand[r["best_idx"]][None, :], far])
+            r = sweep(GP, dc, acq='ei', xi=.1, native=False, exclude=balls, exclude_radius=.6, incremental=True); out.append((r["best_idx"], r["best_val"]))
+            r = sweep(GP, dc, acq='ei', xi=.1, native=False, exclude=np.full((1, 3), .5), exclude_radius=5., incremental=True)
+            out.append((r["best_idx"], r["best_val"]))               # nothing admissible
+            if mode == 1:
+                t, d = state_info(GP); assert d < t
+            r = sweep(GP, dc, acq='pi', xi=.05, native=False, incremental=True); out.append((r["best_idx"], r["best_val"]))
+            if mode == 1:
+                t, d = state_info(GP); assert d == t                 # PI: everything completed
+            f = sweep(GaussianProcess(kern, GP.X, GP.Y, noise=.01), dc, acq='pi', xi=.05, native=False)
+            assert f["best_idx"] == r["best_idx"]; close(r["best_val"], f["best_val"], rtol=1e-9)
+            res[mode] = out
+        for a, b in zip(res[1], res[0]):
+            assert a[0] == b[0]
+            if np.isfinite(b[1]): close(a[1], b[1], rtol=1e-9)
+            else: assert a[1] == b[1]
+    finally:
+        opt(1)
+
+
 def test_incremental_state_cannot_alias_another_array(ibo):
     """the kept (q, alphaY.k*, alpha1.k*) state is keyed on the candidate array's GENERATION (ibo_dev_generation), not on its
     address: an array freed and reallocated at the same address, one overwritten in place through ibo_memcpy_h2d,
