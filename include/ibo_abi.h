@@ -94,7 +94,8 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * ibo_nlml_grid (same values whatever the setting, except "cov_fast", which changes the covariance entries by a rounding error):
  * "chol_left" (left-looking outer order from one packed copy of the factor), "nlml_groups" (sub-batches on their own streams),
  * "chol_panel_rows" 0..3 (which kernel takes the rows below a panel), "cov_fast".  Small batches: "small_local" 0/1/2 (the
- * wave-local k* kernel: never / up to 512 observations / always).
+ * wave-local k* kernel: never / up to 512 observations / always; up to 10 dimensions).  Kept-state sweeps: "gallery_prune" 0/1/2
+ * (see ibo_acq_sweep_incremental).  Diagnostics: "small_trace" 1 / 2 (start / print the host-side split of the small batches' time).
  * Env IBO_SWEEP_IMPL=gemv|mfma too.
  * Threading: handles are independent, but the per-device workspaces behind ibo_nlml_grid / ibo_nlml_grad, the option switches
  * and the allocation pool are process-wide and unsynchronised beyond the pool's mutex: use one thread per device. */
