@@ -17,9 +17,20 @@
 // no copy launches.
 #include "sweep2_dev.h"
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 static int g_small_inline = 1;                       // ibo_set_option("small_inline", 0/1)
 void set_small_inline(int v) { g_small_inline = v; }
+
+#ifdef IBO_STAMPS   // diagnostic build (tools/stamp_small.py): the GPU-side timeline of a small batch, 100 MHz s_memrealtime ticks
+__device__ unsigned long long g_sst[3][1024][4];
+#define SST(k, i) do { const unsigned sb_ = blockIdx.x + gridDim.x * blockIdx.y; \
+                       if (threadIdx.x == 0 && sb_ < 1024u) g_sst[k][sb_][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SST(k, i)
+#endif
 
 #define SM_TC 32                 // candidates per tile
 #define SM_NW 16
@@ -45,6 +56,7 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ctile = blockIdx.x, t = blockIdx.y;
     const int NA128 = (a.Npad + 127) & ~127;
+    SST(0, 0);
     // the X fragments do not depend on the candidates: their L2 round trip runs beside the staging below
     const int rt = wave >> 1, gcb = wave & 1;
     const int tile = t * 8 + rt;
@@ -63,6 +75,7 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, 
     d4_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < KA4; s++) y = mfma_f64(xav[s], cfrag[4 * s], y);
+    SST(0, 1);
     double muY = 0.0, mu1 = 0.0;
     double *dst = Kf + (((size_t)ctile * (NA128 / 4) + tile * 4) * 2 + gcb) * 64 + lane;
 #pragma unroll
@@ -76,6 +89,7 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, 
     muY += __shfl_xor(muY, 16); muY += __shfl_xor(muY, 32);
     mu1 += __shfl_xor(mu1, 16); mu1 += __shfl_xor(mu1, 32);
     if (lane < 16) { lds_m[0][wave][lane] = muY; lds_m[1][wave][lane] = mu1; }
+    SST(0, 2);
     __syncthreads();
     if (tid < 2 * SM_TC) {
         const int which = tid >> 5, c = tid & 31;
@@ -84,6 +98,7 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, 
         for (int w = 0; w < SM_NW / 2; w++) s += lds_m[which][2 * w + (c >> 4)][c & 15];
         mupart[(size_t)(t * 2 + which) * Mp + ctile * SM_TC + c] = s;
     }
+    SST(0, 3);
 }
 
 // grid (ctiles, Npad / 16); qpart[g Mp + c] = sum over the 16 rows of row-block g of (W K*)^2
@@ -95,6 +110,7 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ctile = blockIdx.x, g = gridDim.y - 1 - blockIdx.y;       // the longest rows of W first: the short ones fill the tail
     const int Npad = a.Npad, nk8 = Npad >> 3, NA128 = (Npad + 127) & ~127;
+    SST(1, 0);
     const int nsteps = 2 * g + 2;                    // 8-column steps in which row-block g has non-zeros
     const double2 *Wp2 = (const double2 *)a.Wp + (size_t)g * nk8 * 64 + lane;
     const double *Kb = Kf + (size_t)ctile * (NA128 / 4) * 128 + lane;
@@ -120,7 +136,9 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) { lds_v[wave][0][lane * 4 + r] = acc0[r]; lds_v[wave][1][lane * 4 + r] = acc1[r]; }
+    SST(1, 1);
     __syncthreads();
+    SST(1, 2);
     if (tid < 512) {
         // element e of candidate block cb: lane l = e >> 2, r = e & 3 -> row (l >> 4) + 4 r, candidate 16 cb + (l & 15)
         const int cb = tid >> 8, e = tid & 255, l = e >> 2, r = e & 3;
@@ -136,6 +154,7 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
         for (int rr = 0; rr < 16; rr++) q += lds_s[tid][rr];
         qpart[(size_t)g * Mp + ctile * SM_TC + tid] = q;
     }
+    SST(1, 3);
 }
 
 // WAVE-LOCAL k*: the exponent GEMM's output layout (lane l: row (l>>4) + 4 r, candidate l & 15) IS the B-fragment layout of the
@@ -248,6 +267,7 @@ __global__ __launch_bounds__(SM_FIN_P * 64) void small_finish_kernel(SweepArgs a
     const int64_t li = (int64_t)blockIdx.x * 64 + lane;
     const bool valid = li < a.M;
     const int64_t ci = valid ? li : a.M - 1;
+    SST(2, 0);
     {
         const int per = (nrb + SM_FIN_P - 1) / SM_FIN_P, g0 = p * per;
         double v[16];
@@ -266,6 +286,7 @@ __global__ __launch_bounds__(SM_FIN_P * 64) void small_finish_kernel(SweepArgs a
     }
     __syncthreads();
     if (p != 0) return;
+    SST(2, 1);
     double q = 0.0, my = 0.0, m1 = 0.0;
 #pragma unroll
     for (int u = 0; u < SM_FIN_P; u++) { q += lds_q[u][lane]; my += lds_y[u][lane]; m1 += lds_1[u][lane]; }
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(SM_FIN_P * 64) void small_finish_kernel(SweepArgs a
         if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
     }
     if (lane == 0) { a.part_val[blockIdx.x] = val; a.part_idx[blockIdx.x] = idx; }
+    SST(2, 2);
     if (a.done_flag) {
         // every lane's results (possibly in host memory) are out before this workgroup takes its ticket; the last ticket
         // publishes the sequence number the host is waiting for
@@ -293,6 +315,7 @@ __global__ __launch_bounds__(SM_FIN_P * 64) void small_finish_kernel(SweepArgs a
             }
         }
     }
+    SST(2, 3);
 }
 
 template <int FAM>
@@ -358,7 +381,8 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     // 4.4 us at N = 64, but 15 us at N = 1024 and 28-34 us at N = 2048 against 6 + 8.6 / 6 + 16 for the two separate kernels --
     // its 14-instruction exp() chains are then the throughput of the 128 CUs it occupies.  (A stage-by-stage fusion through an
     // LDS stage and a barrier per 128 rows was measured too: 0.6 us per stage, slower from N = 512 on, and removed.)
-    if (g_small_local && ctiles <= 4 && (nrb <= 32 || g_small_local > 1) && a.kp.D <= 10) {
+    const bool local = g_small_local && ctiles <= 4 && (nrb <= 32 || g_small_local > 1) && a.kp.D <= 10;
+    if (local) {
         const dim3 gl(ctiles, nrb);
         if (a.kp.family == FAM_SE) rc = launch_wkl_small<FAM_SE>(a, qpart, mupart, Mp, gl, s);
         else if (a.kp.family == FAM_M3) rc = launch_wkl_small<FAM_M3>(a, qpart, mupart, Mp, gl, s);
@@ -378,5 +402,16 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     hipLaunchKernelGGL(small_finish_kernel, dim3((unsigned)nfin), dim3(SM_FIN_P * 64), 0, s, a, qpart, mupart, Mp, nrb, nst_fin);
     rc = (int)hipGetLastError();
     if (rc) return rc;
+#ifdef IBO_STAMPS
+    if (getenv("IBO_STAMP_FILE") && !local) {        // one record per batch: header (8 words), then the stamps of the three kernels
+        static std::vector<unsigned long long> h(8 + 3 * 1024 * 4);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h.data() + 8, HIP_SYMBOL(g_sst), sizeof(unsigned long long) * 3 * 1024 * 4);
+        h[0] = (unsigned long long)a.M; h[1] = (unsigned long long)a.Npad; h[2] = (unsigned long long)ctiles; h[3] = (unsigned long long)nst;
+        h[4] = (unsigned long long)nrb; h[5] = (unsigned long long)nfin; h[6] = h[7] = 0;
+        FILE *f = fopen(getenv("IBO_STAMP_FILE"), "ab");
+        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+#endif
     return launch_argmax_final(a, nfin, s);
 }
