@@ -310,6 +310,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "flag_poll")) { g_flag_poll = value; return IBO_OK; }
     if (key && !strcmp(key, "small_inline")) { set_small_inline(value); return IBO_OK; }
     if (key && !strcmp(key, "small_local")) { set_small_local(value); return IBO_OK; }
+    if (key && !strcmp(key, "small_split")) { set_small_split(value); return IBO_OK; }
     if (key && !strcmp(key, "gallery_prune")) { g_gallery_prune = value; return IBO_OK; }
     if (key && !strcmp(key, "small_trace")) {
         if (value == 2 && g_st_n) fprintf(stderr, "[ibo] small batches: %ld, staging + launches %.2f us, wait %.2f us, results %.2f us each\n", g_st_n, g_st_launch / g_st_n, g_st_wait / g_st_n, g_st_copy / g_st_n);

@@ -225,6 +225,7 @@ int sweep2_part_split(int Npad);
 bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);
 void set_small_inline(int v);
+void set_small_split(int v);         // small batches of <= 8 tiles: one 16-candidate block per product workgroup (small2.hip)
 void set_small_local(int v);         // small batches: every wave makes the k* it multiplies, one launch for k* and W K* (small2.hip)
 // small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
 int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);

@@ -101,45 +101,62 @@ __global__ __launch_bounds__(SM_NW * 64) void kstar_small_kernel(InlineCand ic, 
     SST(0, 3);
 }
 
-// grid (ctiles, Npad / 16); qpart[g Mp + c] = sum over the 16 rows of row-block g of (W K*)^2
+// grid (ctiles * 2 / CBS, Npad / 16); qpart[g Mp + c] = sum over the 16 rows of row-block g of (W K*)^2
+// CBS = 2: a workgroup takes both 16-candidate blocks of its tile (batches of many tiles: W is read once per tile).
+// CBS = 1: one block per workgroup -- for the few-tile batches of DIRECT, whose time is the LAST row-block's workgroup pulling its
+// 2g + 2 steps x (1 KiB of W + 2 KiB of k*) through one CU (tools/stamp_small.py): half the k* bytes per CU, twice the workgroups
+// on a chip that was half empty; a block that is all padding leaves at once.  Every candidate's sums are the same terms in the
+// same order either way: identical bits.
+template <int CBS>
 __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const double *__restrict__ Kf, double *__restrict__ qpart, int Mp)
 {
-    __shared__ double lds_v[SM_NW][2][256];          // partial V tiles: [wave][cand-block][lane 64 x 4]
-    __shared__ double lds_s[SM_TC][17];              // squared sums [cand][row]
+    __shared__ double lds_v[SM_NW][CBS][256];        // partial V tiles: [wave][cand-block][lane 64 x 4]
+    __shared__ double lds_s[16 * CBS][17];           // squared sums [cand][row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ctile = blockIdx.x, g = gridDim.y - 1 - blockIdx.y;       // the longest rows of W first: the short ones fill the tail
+    const int ctile = CBS == 2 ? blockIdx.x : blockIdx.x >> 1, cb0 = CBS == 2 ? 0 : blockIdx.x & 1;
+    if (CBS == 1 && (int64_t)ctile * SM_TC + cb0 * 16 >= a.M) return;
+    const int g = gridDim.y - 1 - blockIdx.y;        // the longest rows of W first: the short ones fill the tail
     const int Npad = a.Npad, nk8 = Npad >> 3, NA128 = (Npad + 127) & ~127;
     SST(1, 0);
     const int nsteps = 2 * g + 2;                    // 8-column steps in which row-block g has non-zeros
     const double2 *Wp2 = (const double2 *)a.Wp + (size_t)g * nk8 * 64 + lane;
-    const double *Kb = Kf + (size_t)ctile * (NA128 / 4) * 128 + lane;
-    d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double *Kb = Kf + (size_t)ctile * (NA128 / 4) * 128 + cb0 * 64 + lane;
+    d4_t acc[CBS];
+#pragma unroll
+    for (int c = 0; c < CBS; c++) acc[c] = (d4_t){0.0, 0.0, 0.0, 0.0};
     // this wave's steps j = wave, wave + 16, ..: the operands of TWO steps are in flight while a step's MFMAs issue (one step
     // ahead left an L2 round trip per step on the chain of the longest row-blocks: 16 steps at N = 2048)
-    struct Ops { double2 av; double b00, b01, b10, b11; };
+    struct Ops { double2 av; double b0[CBS], b1[CBS]; };
     auto fetch = [&](int j) {
-        Ops o = {{0.0, 0.0}, 0.0, 0.0, 0.0, 0.0};
+        Ops o;
+        o.av = double2{0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < CBS; c++) o.b0[c] = o.b1[c] = 0.0;
         if (j < nsteps) {
             o.av = Wp2[(size_t)j * 64];
-            o.b00 = Kb[(size_t)(2 * j) * 128]; o.b01 = Kb[(size_t)(2 * j) * 128 + 64];
-            o.b10 = Kb[(size_t)(2 * j + 1) * 128]; o.b11 = Kb[(size_t)(2 * j + 1) * 128 + 64];
+#pragma unroll
+            for (int c = 0; c < CBS; c++) { o.b0[c] = Kb[(size_t)(2 * j) * 128 + 64 * c]; o.b1[c] = Kb[(size_t)(2 * j + 1) * 128 + 64 * c]; }
         }
         return o;
     };
     Ops c0 = fetch(wave), c1 = fetch(wave + SM_NW);
     for (int j = wave; j < nsteps; j += SM_NW) {
         const Ops c2 = fetch(j + 2 * SM_NW);
-        acc0 = mfma_f64(c0.av.x, c0.b00, acc0); acc1 = mfma_f64(c0.av.x, c0.b01, acc1);
-        acc0 = mfma_f64(c0.av.y, c0.b10, acc0); acc1 = mfma_f64(c0.av.y, c0.b11, acc1);
+#pragma unroll
+        for (int c = 0; c < CBS; c++) acc[c] = mfma_f64(c0.av.x, c0.b0[c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < CBS; c++) acc[c] = mfma_f64(c0.av.y, c0.b1[c], acc[c]);
         c0 = c1; c1 = c2;
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) { lds_v[wave][0][lane * 4 + r] = acc0[r]; lds_v[wave][1][lane * 4 + r] = acc1[r]; }
+    for (int c = 0; c < CBS; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds_v[wave][c][lane * 4 + r] = acc[c][r];
     SST(1, 1);
     __syncthreads();
     SST(1, 2);
-    if (tid < 512) {
+    if (tid < 256 * CBS) {
         // element e of candidate block cb: lane l = e >> 2, r = e & 3 -> row (l >> 4) + 4 r, candidate 16 cb + (l & 15)
         const int cb = tid >> 8, e = tid & 255, l = e >> 2, r = e & 3;
         double v = 0.0;
@@ -148,11 +165,11 @@ __global__ __launch_bounds__(SM_NW * 64) void wk_small_kernel(SweepArgs a, const
         lds_s[16 * cb + (l & 15)][(l >> 4) + 4 * r] = v * v;
     }
     __syncthreads();
-    if (tid < SM_TC) {
+    if (tid < 16 * CBS) {
         double q = 0.0;
 #pragma unroll
         for (int rr = 0; rr < 16; rr++) q += lds_s[tid][rr];
-        qpart[(size_t)g * Mp + ctile * SM_TC + tid] = q;
+        qpart[(size_t)g * Mp + ctile * SM_TC + cb0 * 16 + tid] = q;
     }
     SST(1, 3);
 }
@@ -341,6 +358,8 @@ static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, in
     return (int)hipGetLastError();
 }
 
+static int g_small_split = 1;                        // ibo_set_option("small_split", 0/1): one 16-candidate block per product workgroup where the batch has <= 8 tiles
+void set_small_split(int v) { g_small_split = v; }
 static int g_small_local = 1;                        // ibo_set_option("small_local", 0/1): wkl_small_kernel (wave-local k*)
 void set_small_local(int v) { g_small_local = v; }
 
@@ -395,7 +414,8 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
         else if (a.kp.family == FAM_M3) rc = launch_kstar_small<FAM_M3>(a, Kf, mupart, Mp, g1, s);
         else rc = launch_kstar_small<FAM_M5>(a, Kf, mupart, Mp, g1, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(wk_small_kernel, dim3(ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
+        if (ctiles <= 8 && g_small_split) hipLaunchKernelGGL(wk_small_kernel<1>, dim3(2 * ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
+        else hipLaunchKernelGGL(wk_small_kernel<2>, dim3(ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
     }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a.M + 63) / 64;
