@@ -1231,8 +1231,22 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         } else {
             IBO_TRY(g->qpart.ensure(3 * (size_t)M));    // (q, aY.k*, a1.k*) per candidate, finished by acq_finish_kernel
             a.qpart = g->qpart.p;
+#ifdef IBO_STAMPS
+            const size_t nt32s = (size_t)((M + IBO_S2_TCAND - 1) / IBO_S2_TCAND);
+            IBO_TRY(g->mupart.ensure(nt32s * 8 + 16));
+            a.mupart = g->mupart.p;
+#endif
             KERNEL_TRY(launch_sweep2(a, s, g->ev0, g->ev1));
             g->sweep_kernel = "sweep2_kernel";
+#ifdef IBO_STAMPS
+            if (getenv("IBO_STAMP_FILE")) {
+                std::vector<unsigned long long> h(nt32s * 8);
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(h.data(), g->mupart.p, h.size() * 8, hipMemcpyDeviceToHost));
+                FILE *f = fopen(getenv("IBO_STAMP_FILE"), "wb");
+                if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            }
+#endif
         }
     } else {
 #ifdef IBO_STAMPS

@@ -80,6 +80,10 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tile0 = (int64_t)blockIdx.x * TCAND;
     const int D = a.kp.D;
+#ifdef IBO_STAMPS   // diagnostic build (tools/stamp_sweep2.py): a tile's entry / prologue done / panels done / exit, and where it ran
+    unsigned long long st2[4];
+    st2[0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- candidates of this tile: c~ = c sqrt(w), then the two extra columns 1 and b_c
     const int NA128 = (a.Npad + 127) & ~127;
@@ -134,6 +138,9 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     const int pw = (wave & 8) | ((wave & 4) ? 11 - (wave & 7) : (wave & 7));
 
     if (lane < 16) { lds_q[wave][lane] = 0.0; lds_q[wave][16 + lane] = 0.0; }
+#ifdef IBO_STAMPS
+    st2[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // the exponent GEMM's A-fragments of the tile this wave generates in stage t (rows 128 t + 16 rt ..)
     auto load_xa = [&](int k0, double (&xa)[KA4]) {
@@ -321,6 +328,9 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     }
     for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
     run_panel(npanel - 1, std::true_type{});
+#ifdef IBO_STAMPS
+    st2[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
     // hand (q, aY.k*, a1.k*) of every candidate to acq_finish_kernel: the acquisition's erf/exp/sqrt chain on one
     // wave would keep the other fifteen (and the MFMA pipe) waiting at the end of every tile
@@ -334,6 +344,15 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
         const int64_t li = tile0 + c;
         if (li < a.M) { a.qpart[li] = q; a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1; }
     }
+#ifdef IBO_STAMPS
+    st2[3] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && a.mupart) {
+        unsigned long long *d = (unsigned long long *)a.mupart + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 4; i++) d[i] = st2[i];
+        d[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+        d[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));     // XCC_ID
+    }
+#endif
 }
 
 // second half of the sweep: mean prior, variance clamp, EI / PI / UCB, optional per-candidate outputs, exclusion
