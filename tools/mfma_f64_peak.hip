@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -53,6 +54,60 @@ void run(const char *name, int blocks, int iters)
         printf("%s blocks=%d iters=%d: %.3f ms  %.2f TFLOP/s  clock %.3f GHz  %.1f shader-cycles per MFMA per wave\n",
                name, blocks, iters, ms, flops / ms / 1e9, ghz, cyc_per_mfma);
     }
+}
+
+// The same pipe with operands that CHANGE from one MFMA to the next, as they do in a real kernel (the loop above multiplies the same
+// four a's and four b's for ever: little toggles, little power).  16 a's and 16 b's with full-entropy mantissas in registers; every
+// MFMA of an unrolled group of 64 takes another pair.  What the device sustains here -- clock included -- is the ceiling a kernel
+// fed with real data can reach; the nominal peak assumes the boost clock.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void kvar(const double *in, double *out, unsigned long long *clk, int iters)
+{
+    int l = threadIdx.x;
+    double a[16], b[16];
+    for (int i = 0; i < 16; i++) { a[i] = in[(l * 16 + i) & 4095]; b[i] = in[(l * 23 + i + 100) & 4095]; }
+    d4 acc[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) acc[i][j] = (d4){0, 0, 0, 0};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(4 * u + i) & 15], b[(4 * ((u + j) & 3) + ((i + j) & 3)) & 15], acc[i][j], 0, 0, 0);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int r = 0; r < 4; r++) s += acc[i][j][r];
+    out[blockIdx.x * blockDim.x + l] = s;
+    if (l == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+template <int WAVES>
+void runvar(const char *name, int blocks, int iters, bool zeros)
+{
+    double *in, *out; unsigned long long *clk;
+    std::vector<double> h(4096);
+    for (auto &v : h) {                                   // random sign, exponent around 1, 52 random mantissa bits
+        unsigned long long m = ((unsigned long long)rand() << 31) ^ ((unsigned long long)rand() << 10) ^ (unsigned long long)rand();
+        unsigned long long bits = ((unsigned long long)(rand() & 1) << 63) | ((1019ull + (rand() % 8)) << 52) | (m & 0xFFFFFFFFFFFFFull);
+        double d; memcpy(&d, &bits, 8); v = zeros ? 0.0 : d;
+    }
+    hipMalloc(&in, 4096 * 8); hipMalloc(&out, (size_t)blocks * WAVES * 64 * 8); hipMalloc(&clk, blocks * 16);
+    hipMemcpy(in, h.data(), 4096 * 8, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 4; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kvar<WAVES>, dim3(blocks), dim3(WAVES * 64), 0, 0, in, out, clk, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> c(2 * blocks);
+        hipMemcpy(c.data(), clk, blocks * 16, hipMemcpyDeviceToHost);
+        double flops = (double)blocks * WAVES * iters * 16 * 2048.0;
+        double ghz = 0; for (int b = 0; b < blocks; b++) ghz += (double)c[2 * b] / (double)c[2 * b + 1] * 0.1; ghz /= blocks;
+        printf("%s blocks=%d iters=%d: %.3f ms  %.2f TFLOP/s  mean clock %.3f GHz\n", name, blocks, iters, ms, flops / ms / 1e9, ghz);
+    }
+    hipFree(in); hipFree(out); hipFree(clk);
 }
 
 // does fp64 VALU work share the MFMA pipe?  Each SIMD runs 2 MFMA waves (a full pipe) and
@@ -219,6 +274,9 @@ int main()
     run<4>("1 wave/SIMD ", 256, 20000);
     run<8>("2 waves/SIMD", 256, 20000);
     run<8>("2 waves/SIMD x4 blocks", 1024, 10000);
+    runvar<8>("2 waves/SIMD, operands changing every MFMA, random mantissas, 17 ms", 256, 20000, false);
+    runvar<8>("2 waves/SIMD, operands changing every MFMA, random mantissas, 140 ms", 1024, 40000, false);
+    runvar<8>("2 waves/SIMD, the same loop on zeros, 140 ms", 1024, 40000, true);
     runmix<1>(0); runmix<1>(64); runmix<1>(256); runmix<2>(256);
     runops<0>("v_fma_f64", 128); runops<1>("v_fma_f32", 128); runops<2>("v_add+xor u32", 128);
     runops<3>("v_ldexp_f64", 128); runops<4>("v_rndne_f64", 128); runops<5>("v_cvt_i32_f64", 128);
