@@ -58,6 +58,7 @@ static int g_small_trace = 0;    // ibo_set_option("small_trace", 1: start / 2: 
 static double g_st_launch = 0.0, g_st_wait = 0.0, g_st_copy = 0.0; static long g_st_n = 0;
 static int g_gallery_prune = 1;  // ibo_set_option("gallery_prune", 0/1/2): kept-state sweeps in two parts of W's rows, the second only where a
                                  // tile's bound can still win (1); the same launches with every tile completed (2); the one-kernel sweep (0)
+static int g_gallery_lazy = 1;   // ibo_set_option("gallery_lazy", 0/1): a two-part state's later rounds refresh only the tiles whose bound can matter
 static int g_flag_poll = 1;      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
 static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
 static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
@@ -238,7 +239,7 @@ struct ibo_gp {
     DevBuf<int64_t> parti, res_i;
     // kept sweep state (ibo_acq_sweep_incremental): (q, aY.k*, a1.k*) per candidate of ONE device candidate array
     DevBuf<double> state;
-    DevBuf<int> tile_done; DevBuf<double> tile_ub; DevBuf<unsigned long long> part_words;   // kept state with incomplete tiles (st_pruned)
+    DevBuf<int> tile_done; DevBuf<double> tile_ub; DevBuf<unsigned long long> part_words; DevBuf<int> tile_rows, tile_sel;   // kept state with incomplete tiles (st_pruned)
     bool st_pruned = false; int st_N0 = 0;          // st_N0: the model's rows when the state was formed
     DevBuf<double> small_ws;        // small2.hip: k* in fragment order + partial sums of a small batch
     uint64_t st_gen = 0; size_t st_off = 0; int64_t st_M = 0; int st_N = 0; double st_sf2 = 0.0; unsigned st_epoch = 0;   // st_gen: generation of the candidate array's allocation (0: no state)
@@ -312,6 +313,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "small_local")) { set_small_local(value); return IBO_OK; }
     if (key && !strcmp(key, "small_split")) { set_small_split(value); return IBO_OK; }
     if (key && !strcmp(key, "gallery_prune")) { g_gallery_prune = value; return IBO_OK; }
+    if (key && !strcmp(key, "gallery_lazy")) { g_gallery_lazy = value; return IBO_OK; }
     if (key && !strcmp(key, "small_trace")) {
         if (value == 2 && g_st_n) fprintf(stderr, "[ibo] small batches: %ld, staging + launches %.2f us, wait %.2f us, results %.2f us each\n", g_st_n, g_st_launch / g_st_n, g_st_wait / g_st_n, g_st_copy / g_st_n);
         g_small_trace = value == 1; g_st_launch = g_st_wait = g_st_copy = 0.0; g_st_n = 0;
@@ -462,7 +464,7 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->T.release(); g->Wp.release(); g->diag64.release(); g->alphaY.release(); g->alpha1.release();
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release(); g->small_ws.release();
-    g->tile_done.release(); g->tile_ub.release(); g->part_words.release();
+    g->tile_done.release(); g->tile_ub.release(); g->part_words.release(); g->tile_rows.release(); g->tile_sel.release();
     g->done_count.release();
     g->pw.Rinv.release(); g->pw.A.release(); g->pw.Lh.release(); g->pw.E.release(); g->pw.Et.release(); g->pw.d64.release();
     g->pw.vec.release(); g->pw.tmp.release(); g->pw.val.release(); g->pw.lin.release(); g->pw.info.release();
@@ -1187,7 +1189,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
             size_t off = 0;
             const uint64_t gen = alloc_generation(g->device, cand_dev, sizeof(double) * (size_t)M * g->D, &off);
             const bool usable = gen != 0 && g->st_gen == gen && g->st_off == off && g->st_M == M && g->st_epoch == g->fit_epoch && g->st_sf2 == g->kp.sf2 &&
-                                g->st_N >= 1 && g->st_N <= g->N && g->N - g->st_N <= 8 && g->state.cap >= 5 * (size_t)M &&
+                                g->st_N >= 1 && g->st_N <= g->N && g->N - g->st_N <= 8 && (!g->st_pruned || g->N - g->st_N0 <= 16) && g->state.cap >= 5 * (size_t)M &&
                                 sweep2_rank1_fits(a.Npad, a.kp.D);
             IBO_TRY(g->state.ensure(5 * (size_t)M));     // [q_a, aY.k*, a1.k*, zsum, q_b]: q = (q_a + q_b) + zsum
             a.qpart = g->state.p;
@@ -1199,26 +1201,28 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
             const bool monotone = (acq == IBO_ACQ_EI || acq == IBO_ACQ_UCB) && !mu_dev && !s2_dev && !acq_dev;
             const int64_t nt32 = (M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
             a.part_rows = usable ? g->st_N0 : g->N;
+            a.rank_hi = g->N; a.wy = g->tmp.p;               // (g->tmp[0 .. Npad) is W y after every fit, extension and ibo_gp_set_y)
             if (usable && g->st_pruned) {
+                // a two-part state: its tiles fold the appended rows in lazily (launch_sweep2_refresh); a caller that needs every
+                // candidate's own numbers (outputs, PI, the plain mean), the A/B switch, or a mean prior (whose second vector W 1
+                // moves the means of stale tiles by more than any margin allows) has every tile refreshed and completed instead
                 a.tile_done = g->tile_done.p; a.tile_ub = g->tile_ub.p; a.part_best = g->part_words.p; a.part_thresh = g->part_words.p + 1;
-                if (!monotone || g_gallery_prune == 2) {         // this caller needs (or the A/B switch asks for) every candidate's full variance
-                    SweepArgs c = a;
-                    c.out_mu = c.out_s2 = c.out_acq = nullptr;
-                    KERNEL_TRY(launch_sweep2_pruned_finish_all(c, s));
-                    g->st_pruned = false;
-                    a.tile_done = nullptr;
-                }
+                a.tile_rows = g->tile_rows.p; a.tile_sel = g->tile_sel.p;
+                a.part_lazy = monotone && g_gallery_prune == 1 && g_gallery_lazy && g->nb == 0;
             }
             if (usable) {
                 KERNEL_TRY(launch_sweep2_refresh(a, g->st_N, g->N - 1, s, g->ev0, g->ev1));
                 g->sweep_kernel = g->N > g->st_N ? "sweep2_rank1_kernel" : "acq_finish_kernel";
             } else if (g_gallery_prune && monotone && sweep2_part_fits(a.Npad, a.kp.D)) {
                 IBO_TRY(g->tile_done.ensure((size_t)nt32)); IBO_TRY(g->tile_ub.ensure((size_t)nt32)); IBO_TRY(g->part_words.ensure(2));
+                IBO_TRY(g->tile_rows.ensure((size_t)nt32)); IBO_TRY(g->tile_sel.ensure((size_t)nt32));
                 HIP_TRY(hipMemsetAsync(g->tile_done.p, 0, sizeof(int) * (size_t)nt32, s));
+                HIP_TRY(hipMemsetAsync(g->tile_rows.p, 0, sizeof(int) * (size_t)nt32, s));
+                a.tile_rows = g->tile_rows.p;
                 HIP_TRY(hipMemsetAsync(g->state.p + 3 * (size_t)M, 0, sizeof(double) * 2 * (size_t)M, s));
                 a.tile_done = g->tile_done.p; a.tile_ub = g->tile_ub.p; a.part_best = g->part_words.p; a.part_thresh = g->part_words.p + 1;
                 KERNEL_TRY(launch_sweep2_pruned(a, g_gallery_prune == 1, s, g->ev0, g->ev1));
-                g->st_pruned = g_gallery_prune == 1;
+                g->st_pruned = true;
                 g->sweep_kernel = "sweep2_kernel<part>";
             } else {
                 HIP_TRY(hipMemsetAsync(g->state.p + 3 * (size_t)M, 0, sizeof(double) * 2 * (size_t)M, s));

@@ -202,6 +202,9 @@ struct SweepArgs {
     double *tile_ub;                           // per tile: largest value (exact or bound) of its candidates (acq_bound_kernel)
     unsigned long long *part_thresh;           // order-preserving bits of the value a tile's bound must reach to be completed (0: any finite bound)
     int part_all;                              // complete every incomplete tile, whatever its bound
+    // lazy refresh of such a state: per tile the appended rows already folded into zsum (and the means' age), the selection flags of
+    // the launch at hand, the model's rows now, W y (the drift margin's source), and whether tiles may be left stale at all
+    int *tile_rows; int *tile_sel; int rank_hi; const double *wy; int part_lazy;
     unsigned long long *part_best;             // acq_bound_kernel: running maximum over the COMPLETE tiles, same encoding
     // small2.hip: when set, the last workgroup of the last kernel stores done_seq there (host-visible memory) after all
     // results are out -- the host spins on that word instead of going through an event

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
         // second part: only tiles that are not complete and whose bound reaches the threshold (a bound below it cannot win:
         // the threshold is a value some complete candidate attains, or the cut that picks the first tiles to complete)
         if (a.tile_done[blockIdx.x]) return;
-        if (!a.part_all) {
+        if (a.tile_sel) { if (!a.tile_sel[blockIdx.x]) return; }
+        else if (!a.part_all) {
             // (no threshold yet: every tile with an admissible candidate; a tile whose candidates are all excluded never needs its variance)
             const unsigned long long th = *a.part_thresh;
             if (!(a.tile_ub[blockIdx.x] >= (th != 0ull ? s2_dec(th) : -DBL_MAX))) return;
@@ -395,13 +396,24 @@ __global__ __launch_bounds__(256) void acq_bound_kernel(SweepArgs a)
     const int64_t gi = valid ? li : a.M - 1;
     bool excl;
     const double q = (a.qpart[gi] + a.qpart[4 * a.M + gi]) + a.qpart[3 * a.M + gi];
-    double val = s2_finish(a, a.cand + gi * a.kp.D, q, a.qpart[a.M + gi], a.qpart[2 * a.M + gi], li, valid, excl);
+    // A tile that has not folded in every appended row (lazy refresh) carries means formed before those rows existed.  Row i moves a
+    // candidate's mean by nu_i (W y)_i with |nu_i| <= sigma <= sqrt(10) (the variance clamp), so its value is bounded by the
+    // acquisition at mean + sqrt(10) sum |(W y)_i| -- nothing when the appended observations sit on the posterior mean (the gallery's
+    // hallucinations), anything when they do not: then no tile is skipped.  (A mean prior multiplies a second vector, (W 1)_i, that is
+    // never small: the caller refreshes every tile then.)
+    const int64_t tile = gi >> 5;
+    const bool fresh = !a.tile_rows || a.part_rows + a.tile_rows[tile] >= a.rank_hi;
+    double margin = 0.0;
+    if (!fresh) {
+        for (int i = a.part_rows; i < a.rank_hi; i++) margin += fabs(a.wy[i]);
+        margin *= 3.1622776601683795;
+    }
+    double val = s2_finish(a, a.cand + gi * a.kp.D, q, a.qpart[a.M + gi] + margin, a.qpart[2 * a.M + gi], li, valid, excl);
     if (!valid || excl || !(val == val)) val = -INFINITY;
     for (int o = 16; o > 0; o >>= 1) val = fmax(val, __shfl_xor(val, o));          // the 32 candidates of a tile: half a wave
     if ((threadIdx.x & 31) == 0 && valid) {
-        const int64_t tile = li >> 5;
         a.tile_ub[tile] = val;
-        if (a.tile_done[tile] && val > -INFINITY) atomicMax(a.part_best, s2_enc(val));
+        if (a.tile_done[tile] && fresh && val > -INFINITY) atomicMax(a.part_best, s2_enc(val));
     }
 }
 
@@ -448,14 +460,22 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tile0 = (int64_t)blockIdx.x * TCAND;
-    const int D = a.kp.D, row = a.rank1_row, Npad = a.Npad;
+    const int D = a.kp.D, Npad = a.Npad;
     const int NA128 = (Npad + 127) & ~127;
+    // one row (a.rank1_row; < 0: the means only), or -- a kept state whose tiles are refreshed lazily (a.tile_rows) -- every appended
+    // row this tile has not folded in yet, in order: the squares enter zsum in row order whenever the tile catches up, so its bits
+    // do not depend on when that is; the last row's pass leaves the means formed from the current alpha vectors
+    int row0 = a.rank1_row, row1 = a.rank1_row;
+    if (a.tile_rows) {
+        if (a.tile_sel && !a.tile_sel[blockIdx.x]) return;
+        row0 = a.part_rows + a.tile_rows[blockIdx.x]; row1 = a.rank_hi - 1;
+        if (row0 > row1) return;
+    }
     lds_tab[tid] = a.exp_tab[tid];
     lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
     for (int e = tid; e < NA128; e += S2_NW * 64) {
         lds_vec[e] = a.alphaY[e];
         lds_vec[NA128 + e] = a.alpha1[e];
-        lds_vec[2 * NA128 + e] = (row >= 0 && e <= row) ? a.W[(size_t)row * Npad + e] : 0.0;
     }
     for (int e = tid; e < TCAND * KA; e += S2_NW * 64) {
         const int c = e / KA, col = e - c * KA;
@@ -480,6 +500,9 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
     const __amdgpu_buffer_rsrc_t rXA = s2_rsrc(a.XA, (size_t)(NA128 / 16) * KA4 * 64 * sizeof(double));
     const unsigned lane8 = lane * 8;
     const double *vq = lds_vec + (lane >> 4);
+    for (int row = row0; row <= row1; row++) {
+    for (int e = tid; e < NA128; e += S2_NW * 64) lds_vec[2 * NA128 + e] = (row >= 0 && e <= row) ? a.W[(size_t)row * Npad + e] : 0.0;
+    __syncthreads();
     const int nstage = row >= 0 ? (row + 1 + S2_KCH - 1) / S2_KCH : NA128 / S2_KCH;      // (row < 0: only the means, over every row)
     double muY = 0.0, mu1 = 0.0, nu = 0.0;
     double xa[KA4], xn[KA4];
@@ -526,9 +549,24 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
         const int64_t li = tile0 + c;
         if (li < a.M) {
             if (row >= 0) a.qpart[3 * a.M + li] = fma(v, v, a.qpart[3 * a.M + li]);
-            a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1;
+            if (row == row1) { a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1; }
         }
     }
+    __syncthreads();                                 // the row's vector and the partial sums are about to be rewritten
+    }
+    if (tid == 0 && a.tile_rows) a.tile_rows[blockIdx.x] = row1 + 1 - a.part_rows;
+}
+
+// which tiles the next refresh / completion launches take: those whose bound reaches the threshold and that are not yet exact
+__global__ void part_mark_kernel(const double *__restrict__ tile_ub, const int *__restrict__ tile_done, const int *__restrict__ tile_rows, int rows_all,
+                                 const unsigned long long *__restrict__ thresh, int64_t ntiles, int *__restrict__ tile_sel, int all)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const unsigned long long th = *thresh;
+    const bool exact = tile_done[t] && tile_rows[t] >= rows_all;
+    // all = 2: the complete tiles that lag behind (refreshing them is cheap and their values make the threshold)
+    tile_sel[t] = !exact && (all == 2 ? tile_done[t] != 0 : (all || tile_ub[t] >= (th != 0ull ? s2_dec(th) : -DBL_MAX)));
 }
 
 // XA: the observations as A-fragments of the exponent GEMM.  Row k of the augmented matrix is
@@ -668,6 +706,7 @@ static int launch_s2_means(const SweepArgs &a0, hipStream_t s)
     const int64_t ntiles = (a0.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
     SweepArgs a = a0;
     a.rank1_row = -1;
+    a.tile_rows = nullptr; a.tile_sel = nullptr;     // every tile, no row
     if (a.kp.family == FAM_SE) return launch_s2_rank1_fam<FAM_SE>(a, ntiles, s);
     if (a.kp.family == FAM_M3) return launch_s2_rank1_fam<FAM_M3>(a, ntiles, s);
     return launch_s2_rank1_fam<FAM_M5>(a, ntiles, s);
@@ -694,8 +733,10 @@ int sweep2_part_split(int Npad) { return ((Npad / 2 + 64) / 128) * 128; }
 // tiles at the top of the bound ranking, then -- against the best value THOSE reached -- for whoever's bound still reaches it.
 // A tile left incomplete has a bound below a value that a complete candidate attains: it cannot hold the maximum, and the
 // arg-max over (exact where complete, bound elsewhere) is the arg-max of the full sweep.  prune = false completes every tile.
-int launch_sweep2_pruned(const SweepArgs &a, bool prune, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+int launch_sweep2_pruned(const SweepArgs &a_in, bool prune, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
+    SweepArgs a = a_in;
+    a.tile_sel = nullptr;                            // (the first sweep selects by threshold; a_in.tile_rows is all zeros: everyone is fresh)
     const int h = sweep2_part_split(a.Npad), hi = (a.part_rows + 15) & ~15;
     const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
     if (e0) (void)hipEventRecord(e0, s);
@@ -734,14 +775,56 @@ int launch_sweep2_complete(const SweepArgs &a, hipStream_t s)
 int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s)
 {
     SweepArgs b = a;
-    b.part_all = 1;
+    b.part_all = 1; b.tile_sel = nullptr;
     return launch_s2_part(b, sweep2_part_split(a.Npad), (a.part_rows + 15) & ~15, a.part_thresh, s);
 }
 
 // rows [row_first, row_last] were appended to the model since a.qpart (the kept state [3][M]) was last brought up to
 // date: one refresh launch per row, then the acquisition as after a full sweep
+// The same for a state with incomplete tiles (a.tile_done, a.tile_rows, a.tile_sel set): nothing is refreshed that cannot matter.
+// The complete tiles -- few, and the best of earlier rounds -- fold in the rows they are missing; the best value they now reach is
+// the threshold: whoever else's bound (from its stale state: means widened by the drift margin, variance only too large) reaches it
+// folds its rows in and gets its second part; the arg-max then runs over everyone -- a tile left stale has a bound below a value
+// that an exact candidate attains.
+// lazy = false: every tile is refreshed and completed by the same launches (the reference the lazy run is held to, and the route
+// when a mean prior is set).
+static int launch_sweep2_refresh_lazy(const SweepArgs &a0, bool lazy, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int64_t ntiles = (a0.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
+    const int rows_all = a0.rank_hi - a0.part_rows, h = sweep2_part_split(a0.Npad), hi = (a0.part_rows + 15) & ~15;
+    const unsigned nmark = (unsigned)((ntiles + 255) / 256);
+    if (e0) (void)hipEventRecord(e0, s);
+    auto upgrade = [&](unsigned long long *thresh, int all) -> int {       // refresh + complete the tiles at or above *thresh
+        hipLaunchKernelGGL(part_mark_kernel, dim3(nmark), dim3(256), 0, s, (const double *)a0.tile_ub, (const int *)a0.tile_done, (const int *)a0.tile_rows,
+                           rows_all, (const unsigned long long *)thresh, ntiles, a0.tile_sel, all);
+        SweepArgs a = a0;
+        a.rank1_row = 0;
+        int rc;
+        if (a.kp.family == FAM_SE) rc = launch_s2_rank1_fam<FAM_SE>(a, ntiles, s);
+        else if (a.kp.family == FAM_M3) rc = launch_s2_rank1_fam<FAM_M3>(a, ntiles, s);
+        else rc = launch_s2_rank1_fam<FAM_M5>(a, ntiles, s);
+        if (rc) return rc;
+        return launch_s2_part(a, h, hi, thresh, s);
+    };
+    int rc;
+    if (!lazy) {
+        if ((rc = upgrade(a0.part_thresh, 1))) return rc;
+    } else {
+        if ((rc = upgrade(a0.part_thresh, 2))) return rc;
+        if ((rc = launch_s2_bound(a0, s))) return rc;
+        if ((rc = upgrade(a0.part_best, 0))) return rc;
+    }
+    if (e1) (void)hipEventRecord(e1, s);
+    const int64_t nfin = (a0.M + 255) / 256;
+    hipLaunchKernelGGL(acq_finish_kernel, dim3((unsigned)nfin), dim3(256), 0, s, a0);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return launch_argmax_final(a0, nfin, s);
+}
+
 int launch_sweep2_refresh(const SweepArgs &a0, int row_first, int row_last, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
+    if (a0.tile_done && a0.tile_rows) return launch_sweep2_refresh_lazy(a0, a0.part_lazy != 0, s, e0, e1);
     const int64_t ntiles = (a0.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
     if (e0) (void)hipEventRecord(e0, s);
     for (int r = row_first; r <= row_last; r++) {

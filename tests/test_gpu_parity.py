@@ -532,7 +532,7 @@ def test_incremental_sweep_state_equals_full_sweeps(ibo):
 
 def test_two_part_kept_state_finds_the_full_sweeps_maximum(ibo):
     """ibo_acq_sweep_incremental, arg-max only, EI / UCB: the state is formed over the first half of W's rows, the second half
-    runs only for tiles whose bound can still win (gallery_prune = 1).  Every round of a gallery-like sequence returns the
+    runs only for tiles whose bound can still win, and later rounds refresh only the tiles that can matter (gallery_prune = 1).  Every round of a gallery-like sequence returns the
     (value, index) of the same launches with every tile completed (gallery_prune = 2) BIT FOR BIT, the index of the one-kernel
     sweep (0) and of a freshly fitted model's full sweep, values at 1e-9; tiles really are left incomplete; a later call that
     wants per-candidate outputs completes them and equals the full sweep's outputs."""
@@ -569,7 +569,9 @@ def test_two_part_kept_state_finds_the_full_sweeps_maximum(ibo):
                         assert f["best_idx"] == r["best_idx"]; close(r["best_val"], f["best_val"], rtol=1e-9)
                     x = cand[r["best_idx"]]
                     shown.append(x)
-                    GP.addData(x, GP.mu(x))                 # the gallery's hallucinated observation
+                    # the gallery's hallucinated observation -- and once a real one, off the posterior mean: the stale tiles' means
+                    # are then no bound any more, the drift margin says so, and nothing may be skipped on their account
+                    GP.addData(x, GP.mu(x) + (0.3 if rnd == 2 else 0.0))
                 if mode == 1:
                     full = sweep(GP, dc, acq=acq, incremental=True, outputs=("mu", "s2", "acq"), **kw)     # outputs: every tile completed first
                     assert state_info(GP)[0] == state_info(GP)[1]
@@ -584,7 +586,7 @@ def test_two_part_kept_state_finds_the_full_sweeps_maximum(ibo):
             assert runs[1][0][2] == "sweep2_kernel<part>" and runs[0][0][2] == "sweep2_kernel" and runs[1][1][2] == "sweep2_rank1_kernel"
             assert all(t == d for _, _, _, t, d in runs[2]) and all(t == d for _, _, _, t, d in runs[0])
             assert runs[1][0][4] < runs[1][0][3] // 2, runs[1][0]            # more than half of the tiles never ran their second part
-            assert all(x[4] <= y[4] for x, y in zip(runs[1], runs[1][1:]))  # and completion only ever grows
+            assert all(x[4] <= y[4] for x, y in zip(runs[1], runs[1][1:]) if y[2] != "sweep2_kernel<part>")  # completion only grows (until a refit starts a new state)
     finally:
         opt(1)
 
