@@ -288,8 +288,11 @@ int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
  * is triangular) for every candidate; q_b over the rest only for the 32-candidate tiles whose BOUND -- the acquisition at
  * the variance 1 + noise - q_a, which can only shrink as rows are added -- reaches a value that a complete candidate
  * attains.  The returned (best_val, best_idx) are those of the full sweep: a tile left incomplete cannot hold the maximum.
- * Later calls fold the appended rows in as before and complete whichever tiles' bounds have caught up with the best
- * complete value; a call that wants per-candidate outputs (or IBO_ACQ_PI / IBO_ACQ_NONE) completes every tile first.
+ * Later calls are lazy too: the complete tiles fold in the rows appended since, the best value they reach is the threshold,
+ * and only tiles whose bound -- from their stale state, the means widened by sqrt(10) sum |(W y)_i| over the appended rows:
+ * nothing for observations on the posterior mean (the gallery's), everything for real ones -- reaches it are refreshed and
+ * completed.  A call that wants per-candidate outputs (or IBO_ACQ_PI / IBO_ACQ_NONE), or a model with a mean prior, refreshes
+ * and completes every tile first.  ibo_set_option("gallery_lazy", 0) refreshes every tile every time.
  * 512 <= padded rows <= 4096; 40 bytes of state per candidate.  ibo_set_option("gallery_prune", 0) restores the one-kernel
  * first sweep, 2 runs the two-part launches with every tile completed (what the pruned run is tested against, bit for bit).
  */
