@@ -292,7 +292,7 @@ int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
  * and only tiles whose bound -- from their stale state, the means widened by sqrt(10) sum |(W y)_i| over the appended rows:
  * nothing for observations on the posterior mean (the gallery's), everything for real ones -- reaches it are refreshed and
  * completed.  A call that wants per-candidate outputs (or IBO_ACQ_PI / IBO_ACQ_NONE), or a model with a mean prior, refreshes
- * and completes every tile first.  ibo_set_option("gallery_lazy", 0) refreshes every tile every time.
+ * and completes every tile first.  ibo_set_option("gallery_lazy", 0) refreshes and completes every tile on the first later call.
  * 512 <= padded rows <= 4096; 40 bytes of state per candidate.  ibo_set_option("gallery_prune", 0) restores the one-kernel
  * first sweep, 2 runs the two-part launches with every tile completed (what the pruned run is tested against, bit for bit).
  */
