@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised check of the kept-state sweeps (ibo_acq_sweep_incremental, arg-max only): the two-part, lazily refreshed state
+(gallery_prune = 1) against the same launches with every tile refreshed and completed (2) -- BIT FOR BIT -- and against the one-kernel
+state with every candidate refreshed (0) -- same index, value at 1e-9 -- over random models, candidate sets, acquisitions, exclusion
+balls, and rounds that add hallucinated observations, real ones, two at a time, with and without a mean prior.
+    python3 tools/fuzz_gallery.py [cases] [seed]"""
+import sys, os, time, ctypes
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ibo_amd import DeviceArray, _lib
+from ibo_amd.gaussianprocess import GaussianProcess
+from ibo_amd.gaussianprocess import kernel as K
+from ibo_amd.gaussianprocess.prior import RBFNMeanPrior
+from ibo_amd.acquisition import sweep
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+opt = lambda v: _lib.check(_lib.lib.ibo_set_option(b"gallery_prune", v))
+def state_info(GP):
+    t, c = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(_lib.lib.ibo_sweep_state_info(GP._handle(), ctypes.byref(t), ctypes.byref(c)))
+    return t.value, c.value
+fails = 0; t0 = time.time(); skipped = []
+for case in range(cases):
+    N = int(rs.choice([520, 700, 1000, 1024, 1500, 2048, 2500, 3000])); D = int(rs.randint(1, 11))
+    fam = int(rs.randint(0, 3)); noise = float(rs.choice([1e-3, 1e-2, 1e-1]))
+    ls = float(rs.uniform(.2, .6)) * np.sqrt(D / 3.)
+    kern = [K.GaussianKernel_ard(np.full(D, ls)), K.MaternKernel3([ls, 1.0]), K.MaternKernel5([ls, 1.0])][fam]
+    X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .05 * rs.randn(N)
+    M = int(rs.choice([9000, 20000, 50001, 120000])); cand = rs.rand(M, D)
+    acq = str(rs.choice(['ei', 'ucb'])); kw = dict(xi=float(rs.choice([.01, .1, .4])), native=bool(rs.randint(2))) if acq == 'ei' else {}
+    prior = None
+    if rs.rand() < .2:
+        k = 4; prior = RBFNMeanPrior(rs.rand(k, D), rs.randn(k) * .3, float(rs.uniform(1, 4)), np.zeros(D), np.ones(D))
+    rounds = int(rs.randint(4, 8)); radius = float(rs.choice([.02, .1, .3]))
+    plan = [(rs.rand() < .2, rs.rand() < .15) for _ in range(rounds)]          # (a real observation?, two points at once?)
+    runs = {}
+    for mode in (1, 2, 0):
+        opt(mode)
+        GP = GaussianProcess(kern, X, Y, noise=noise, prior=prior)
+        dc = DeviceArray.from_host(cand)
+        out, shown = [], []
+        for rnd in range(rounds):
+            r = sweep(GP, dc, acq=acq, exclude=np.array(shown) if shown else None, exclude_radius=radius, incremental=True, **kw)
+            out.append((r["best_val"], r["best_idx"]) + state_info(GP))
+            if r["best_idx"] < 0: break
+            x = cand[r["best_idx"]]; shown.append(x)
+            real, two = plan[rnd]
+            if two:
+                x2 = cand[(r["best_idx"] + 17) % M]
+                GP.addData(np.array([x, x2]), np.array([GP.mu(x) + (.3 if real else 0.), GP.mu(x2)]))
+            else:
+                GP.addData(x, GP.mu(x) + (.3 if real else 0.))
+        runs[mode] = out
+    ok = len(runs[1]) == len(runs[2]) == len(runs[0])
+    for a, b, c in zip(runs[1], runs[2], runs[0]):
+        ok = ok and a[0] == b[0] and a[1] == b[1] and a[1] == c[1] and (abs(a[0] - c[0]) <= 1e-9 * abs(c[0]) + 1e-300 or a[0] == c[0])
+    skipped.append(1 - runs[1][0][3] / max(1, runs[1][0][2]))
+    if not ok:
+        fails += 1
+        print("FAIL case %d: N=%d D=%d fam=%d noise=%g M=%d %s %s prior=%s\n   pruned %s\n   all    %s\n   plain  %s" %
+              (case, N, D, fam, noise, M, acq, kw, prior is not None, runs[1], runs[2], runs[0]))
+    else:
+        print("case %2d ok: N=%4d D=%2d fam=%d noise=%g M=%6d %-3s prior=%d rounds=%d  tiles without a second part after the first sweep: %.0f %%" %
+              (case, N, D, fam, noise, M, acq, prior is not None, len(runs[1]), 100 * skipped[-1]), flush=True)
+opt(1)
+print("%d cases, %d failures, %.0f s; median share of tiles left incomplete by the first sweep %.0f %%" % (cases, fails, time.time() - t0, 100 * np.median(skipped)))
+sys.exit(1 if fails else 0)

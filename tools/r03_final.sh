@@ -14,6 +14,7 @@ python3 tools/run_configs.py c2 c3 c4 c5 > profiles/${TAG}_configs_c2_c5.jsonl 2
 python3 tools/time_incremental.py > profiles/${TAG}_time_incremental.txt 2> $O/inc.err
 { [ -x tools/launch_floor ] && tools/launch_floor; python3 tools/time_small_split.py 2>&1; } > profiles/${TAG}_direct_batch_floor.txt 2> $O/floor.err
 timeout 600 python3 tools/fuzz_nlml.py 60 7 > $O/fuzz_nlml.txt 2>&1; tail -4 $O/fuzz_nlml.txt > profiles/${TAG}_fuzz_nlml_summary.txt
+timeout 900 python3 tools/fuzz_gallery.py 300 7 > $O/fuzz_gallery.txt 2>&1; { grep -c " ok:" $O/fuzz_gallery.txt; grep "FAIL" $O/fuzz_gallery.txt | head; tail -1 $O/fuzz_gallery.txt; } > profiles/${TAG}_fuzz_gallery_summary.txt
 for n in 1024 2048 4096; do bash tools/fit_trace.sh $n > profiles/${TAG}_fit_trace_$n.txt 2>&1; done
 FUZZ_DIRECT_CASES=12 timeout 1500 python3 tools/fuzz_gpu.py 200 3 > $O/fuzz.txt 2>&1; { grep -c "rel err" $O/fuzz.txt; grep "FAIL" $O/fuzz.txt | head; grep "worst" $O/fuzz.txt; sort -t'e' -k1 $O/fuzz.txt | grep "rel err" | awk '{print}' | sort -k14 -g | tail -5; tail -4 $O/fuzz.txt; } > profiles/${TAG}_fuzz_summary.txt
 tail -3 profiles/${TAG}_latencies.txt; cat profiles/${TAG}_configs_c2_c5.jsonl | cut -c1-300
