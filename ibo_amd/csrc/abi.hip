@@ -313,6 +313,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "small_local")) { set_small_local(value); return IBO_OK; }
     if (key && !strcmp(key, "small_split")) { set_small_split(value); return IBO_OK; }
     if (key && !strcmp(key, "gallery_prune")) { g_gallery_prune = value; return IBO_OK; }
+    if (key && !strcmp(key, "part_means")) { set_part_means(value); return IBO_OK; }
     if (key && !strcmp(key, "gallery_lazy")) { g_gallery_lazy = value; return IBO_OK; }
     if (key && !strcmp(key, "small_trace")) {
         if (value == 2 && g_st_n) fprintf(stderr, "[ibo] small batches: %ld, staging + launches %.2f us, wait %.2f us, results %.2f us each\n", g_st_n, g_st_launch / g_st_n, g_st_wait / g_st_n, g_st_copy / g_st_n);
@@ -1201,6 +1202,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
             const bool monotone = (acq == IBO_ACQ_EI || acq == IBO_ACQ_UCB) && !mu_dev && !s2_dev && !acq_dev;
             const int64_t nt32 = (M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
             a.part_rows = usable ? g->st_N0 : g->N;
+            a.part_slack = 1e-13 * (1.0 + fabs(a.ymax) + fabs(a.parm));
             a.rank_hi = g->N; a.wy = g->tmp.p;               // (g->tmp[0 .. Npad) is W y after every fit, extension and ibo_gp_set_y)
             if (usable && g->st_pruned) {
                 // a two-part state: its tiles fold the appended rows in lazily (launch_sweep2_refresh); a caller that needs every

@@ -202,6 +202,8 @@ struct SweepArgs {
     double *tile_ub;                           // per tile: largest value (exact or bound) of its candidates (acq_bound_kernel)
     unsigned long long *part_thresh;           // order-preserving bits of the value a tile's bound must reach to be completed (0: any finite bound)
     int part_all;                              // complete every incomplete tile, whatever its bound
+    double part_slack;                         // absolute part of the slack a bound is given against the threshold (s2_part_limit)
+    int part_means;                            // the first part also forms aY.k* and a1.k* (its launch carries the alpha vectors in LDS)
     // lazy refresh of such a state: per tile the appended rows already folded into zsum (and the means' age), the selection flags of
     // the launch at hand, the model's rows now, W y (the drift margin's source), and whether tiles may be left stale at all
     int *tile_rows; int *tile_sel; int rank_hi; const double *wy; int part_lazy;
@@ -224,6 +226,7 @@ int launch_sweep2_pruned(const SweepArgs &a, bool prune, hipStream_t s, hipEvent
 int launch_sweep2_complete(const SweepArgs &a, hipStream_t s);
 int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s);
 bool sweep2_part_fits(int Npad, int D);
+void set_part_means(int v);
 int sweep2_part_split(int Npad);
 bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);

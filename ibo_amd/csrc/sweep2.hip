@@ -40,6 +40,15 @@ __host__ __device__ constexpr int s2_awin(int ka4) { return ka4 <= 5 ? 4096 : 30
 #include "sweep2_dev.h"
 
 // KA4 = ceil((D + 2) / 4): k4-steps of the exponent GEMM
+// What a tile's bound must reach to be refreshed / completed, given the threshold word: the threshold less a slack.  The bound
+// argument is exact mathematics (fewer rows of W: larger variance; EI and UCB grow with it), but the reference's EI formula is not
+// monotone in floating point where it is tiny: Phi(z) = (1 + erf(z / sqrt 2)) / 2 carries ~1e-16 of absolute rounding noise, so an EI
+// below ~1e-14 (times the data's scale) is noise, and two candidates' order there is whatever the noise says.  With the slack --
+// 1e-9 of the threshold plus 1e-13 (1 + |ymax| + |parm|) -- a tile is never dropped on the strength of such digits; when the best value
+// itself is down there, every admissible tile is completed, as a full sweep would.  (tools/fuzz_gallery.py found the three cases
+// in 420 that taught this.)
+__device__ __forceinline__ double s2_part_limit(unsigned long long th, double slack_abs);
+
 // order-preserving encoding of a double as an unsigned integer (atomicMax over values); 0 decodes to a NaN: "no value yet"
 __device__ __forceinline__ unsigned long long s2_enc(double x)
 {
@@ -49,6 +58,13 @@ __device__ __forceinline__ unsigned long long s2_enc(double x)
 __device__ __forceinline__ double s2_dec(unsigned long long e)
 {
     return __longlong_as_double((long long)((e >> 63) ? (e & 0x7fffffffffffffffull) : ~e));
+}
+
+__device__ __forceinline__ double s2_part_limit(unsigned long long th, double slack_abs)
+{
+    if (th == 0ull) return -DBL_MAX;
+    const double t = s2_dec(th);
+    return t - (1e-9 * fabs(t) + slack_abs);
 }
 
 template <int FAM, int KA4, bool BIGN, bool PART = false>   // BIGN: more than s2_awin(KA4) rows -- the alpha vectors' window moves
@@ -62,8 +78,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
         if (a.tile_sel) { if (!a.tile_sel[blockIdx.x]) return; }
         else if (!a.part_all) {
             // (no threshold yet: every tile with an admissible candidate; a tile whose candidates are all excluded never needs its variance)
-            const unsigned long long th = *a.part_thresh;
-            if (!(a.tile_ub[blockIdx.x] >= (th != 0ull ? s2_dec(th) : -DBL_MAX))) return;
+            if (!(a.tile_ub[blockIdx.x] >= s2_part_limit(*a.part_thresh, a.part_slack))) return;
         }
     }
     constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4, S2_AWIN = s2_awin(KA4);
@@ -91,7 +106,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
     lds_tab[tid] = a.exp_tab[tid];
     lds_tab[tid + 1024] = a.exp_tab[tid + 1024];
     const int AW = BIGN ? S2_AWIN : NA128;
-    if (!PART) {
+    if (!PART || a.part_means) {
         for (int e = tid; e < AW; e += S2_NW * 64) {                // both vectors are zero beyond N (abi.hip pads them)
             lds_alpha[e] = a.alphaY[e];
             lds_alpha[AW + e] = a.alpha1[e];
@@ -290,6 +305,15 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
             range(n[2], n[3], std::integral_constant<int, 1>{});
             __syncthreads();
         }
+        if (PART && LAST) {
+            // the first part of a kept state also forms the means: its last panel has generated the k* rows below a.part_hi and added
+            // their terms; the rows from there on are generated here for the two dot products alone (no W, no barrier: the stage
+            // buffers they land in are not read again) -- half of what the separate means pass regenerated
+            for (int t = nstage; t < NA128 / S2_KCH; t++) {
+                load_xa(t * S2_KCH, xa);
+                gen(t * S2_KCH, t & 1, xa, muY, mu1, last_tag);
+            }
+        }
         // |V|^2 down the rows of this panel: acc[i][cb][r] is row 16 g_i + (lane>>4) + 4r, candidate 16 cb + (lane&15)
 #pragma unroll
         for (int cb = 0; cb < CBW; cb++) {
@@ -315,7 +339,13 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 
     // the last panel sees every k: it also forms the mean.  A short panel (N not a multiple of 1024) comes first.
     if (PART) {
-        for (int p = 0; a.part_lo + p * S2_PANEL < a.part_hi; p++) run_panel(p, std::false_type{});
+        const int np = (a.part_hi - a.part_lo + S2_PANEL - 1) / S2_PANEL;
+        if (a.part_means) {
+            for (int p = 0; p + 1 < np; p++) run_panel(p, std::false_type{});
+            run_panel(np - 1, std::true_type{});
+        } else {
+            for (int p = 0; p < np; p++) run_panel(p, std::false_type{});
+        }
         __syncthreads();
         if (tid < TCAND) {
             double q = 0.0;
@@ -323,6 +353,13 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
             for (int w = 0; w < S2_NW; w++) q += lds_q[w][tid];
             const int64_t li = tile0 + tid;
             if (li < a.M) a.qpart[(a.part_lo > 0 ? 4 * a.M : 0) + li] = q;
+            if (a.part_means) {
+                const int c = tid;
+                double my = 0.0, m1 = 0.0;
+#pragma unroll
+                for (int w = 0; w < S2_NW / 2; w++) { my += lds_m[0][2 * w + (c >> 4)][c & 15]; m1 += lds_m[1][2 * w + (c >> 4)][c & 15]; }
+                if (li < a.M) { a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1; }
+            }
         }
         if (a.part_lo > 0 && tid == 0) a.tile_done[blockIdx.x] = 1;
         return;
@@ -559,14 +596,14 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
 
 // which tiles the next refresh / completion launches take: those whose bound reaches the threshold and that are not yet exact
 __global__ void part_mark_kernel(const double *__restrict__ tile_ub, const int *__restrict__ tile_done, const int *__restrict__ tile_rows, int rows_all,
-                                 const unsigned long long *__restrict__ thresh, int64_t ntiles, int *__restrict__ tile_sel, int all)
+                                 const unsigned long long *__restrict__ thresh, int64_t ntiles, int *__restrict__ tile_sel, int all, double slack_abs)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles) return;
     const unsigned long long th = *thresh;
     const bool exact = tile_done[t] && tile_rows[t] >= rows_all;
     // all = 2: the complete tiles that lag behind (refreshing them is cheap and their values make the threshold)
-    tile_sel[t] = !exact && (all == 2 ? tile_done[t] != 0 : (all || tile_ub[t] >= (th != 0ull ? s2_dec(th) : -DBL_MAX)));
+    tile_sel[t] = !exact && (all == 2 ? tile_done[t] != 0 : (all || tile_ub[t] >= s2_part_limit(th, slack_abs)));
 }
 
 // XA: the observations as A-fragments of the exponent GEMM.  Row k of the augmented matrix is
@@ -674,7 +711,16 @@ static int launch_s2_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 template <int FAM, int KA4>
 static int launch_s2_part_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
-    hipLaunchKernelGGL((sweep2_kernel<FAM, KA4, false, true>), dim3((unsigned)ntiles), dim3(S2_NW * 64), 0, s, a);
+    const int dyn = a.part_means ? ((a.Npad + 127) & ~127) * 16 : 0;      // the alpha vectors, when this launch also forms the means
+    static int granted[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dyn > granted[dev & 15]) {
+        hipError_t e = hipFuncSetAttribute((const void *)sweep2_kernel<FAM, KA4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        if (e != hipSuccess) return (int)e;
+        granted[dev & 15] = dyn;
+    }
+    hipLaunchKernelGGL((sweep2_kernel<FAM, KA4, false, true>), dim3((unsigned)ntiles), dim3(S2_NW * 64), dyn, s, a);
     return (int)hipGetLastError();
 }
 template <int FAM>
@@ -692,11 +738,11 @@ static int launch_s2_part_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     default: return launch_s2_part_one<FAM, 9>(a, ntiles, s);
     }
 }
-static int launch_s2_part(const SweepArgs &a, int lo, int hi, unsigned long long *thresh, hipStream_t s)
+static int launch_s2_part(const SweepArgs &a, int lo, int hi, unsigned long long *thresh, hipStream_t s, int means = 0)
 {
     const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
     SweepArgs b = a;
-    b.part_lo = lo; b.part_hi = hi; b.part_thresh = thresh;
+    b.part_lo = lo; b.part_hi = hi; b.part_thresh = thresh; b.part_means = means;
     if (a.kp.family == FAM_SE) return launch_s2_part_fam<FAM_SE>(b, ntiles, s);
     if (a.kp.family == FAM_M3) return launch_s2_part_fam<FAM_M3>(b, ntiles, s);
     return launch_s2_part_fam<FAM_M5>(b, ntiles, s);
@@ -721,6 +767,8 @@ static int launch_s2_bound(const SweepArgs &a0, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+static int g_part_means = 1;                         // ibo_set_option("part_means", 0/1): the first part of a kept state forms the means itself
+void set_part_means(int v) { g_part_means = v; }
 // the part kernel has no moving alpha window and the means come from the refresh kernel: both must fit
 bool sweep2_part_fits(int Npad, int D) { return Npad >= 512 && ((Npad + 127) & ~127) <= s2_awin((D + 2 + 3) / 4) && sweep2_rank1_fits(Npad, D); }
 // rows of the first part: half of them, a quarter of the work (W is triangular) -- the multiple of 128 NEAREST to half: rounding
@@ -740,9 +788,9 @@ int launch_sweep2_pruned(const SweepArgs &a_in, bool prune, hipStream_t s, hipEv
     const int h = sweep2_part_split(a.Npad), hi = (a.part_rows + 15) & ~15;
     const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
     if (e0) (void)hipEventRecord(e0, s);
-    int rc = launch_s2_part(a, 0, h, a.part_thresh, s);
+    int rc = launch_s2_part(a, 0, h, a.part_thresh, s, g_part_means);        // (the means ride along with the first part)
     if (rc) return rc;
-    if ((rc = launch_s2_means(a, s))) return rc;
+    if (!g_part_means && (rc = launch_s2_means(a, s))) return rc;
     if (prune) {
         if ((rc = launch_s2_bound(a, s))) return rc;                               // bounds; nothing complete yet
         hipLaunchKernelGGL(part_select_kernel, dim3(1), dim3(1024), 0, s, (const double *)a.tile_ub, ntiles, a.part_thresh);
@@ -796,7 +844,7 @@ static int launch_sweep2_refresh_lazy(const SweepArgs &a0, bool lazy, hipStream_
     if (e0) (void)hipEventRecord(e0, s);
     auto upgrade = [&](unsigned long long *thresh, int all) -> int {       // refresh + complete the tiles at or above *thresh
         hipLaunchKernelGGL(part_mark_kernel, dim3(nmark), dim3(256), 0, s, (const double *)a0.tile_ub, (const int *)a0.tile_done, (const int *)a0.tile_rows,
-                           rows_all, (const unsigned long long *)thresh, ntiles, a0.tile_sel, all);
+                           rows_all, (const unsigned long long *)thresh, ntiles, a0.tile_sel, all, a0.part_slack);
         SweepArgs a = a0;
         a.rank1_row = 0;
         int rc;
