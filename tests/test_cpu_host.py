@@ -407,3 +407,51 @@ def test_every_analytic_test_function_against_the_reference_values():
     assert abs(tfs.Schubert1(maximize=False).f([-0.195]) + 8.5178) < 2e-3
     found = tfs.checkMinimum([tfs.Zakharov(2, maximize=False)], samples=20, seed=3)
     assert found[0][0] == "Zakharov 2" and found[0][1] < 1e-8
+
+
+def test_prefix_variance_bounds_the_reference_acquisitions(oracle):
+    """What the two-part kept state (sweep2.hip: launch_sweep2_pruned) rests on, checked on the oracle's own arithmetic: with W = L^-1,
+    q = |W k*|^2 summed over a PREFIX of W's rows is a lower bound of q, so 1 + noise - q_prefix bounds the variance from above; EI
+    (libm and NR erf) and UCB evaluated there bound the candidate's value from above -- up to the rounding noise of the reference's EI
+    where it is ~1e-16, which the slack of s2_part_limit covers; and the selection the device performs (the top of the bound ranking
+    first, their best value as the threshold for the rest) never leaves the true maximiser incomplete."""
+    orc = oracle
+    rs = np.random.RandomState(41)
+    for kind, hyper, D, noise in (("ard", [.3, .35, .4], 3, .01), ("m5", [.5, 1.0], 4, .001), ("m3", [.4, 1.0], 2, .1)):
+        N, M = 192, 960
+        X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .05 * rs.randn(N)
+        kern = orc.Kern(kind, np.array(hyper, float))
+        gp = orc.GP(kern, X, Y, noise=noise)
+        Q = rs.rand(M, D)
+        mu, s2 = gp.posteriors(Q)
+        XQ = np.ascontiguousarray(np.vstack([X, Q]))                # the correlation matrix of all points holds K(X, Q) off the diagonal
+        Rb = np.empty((N + M, N + M))
+        orc.lib().orc_build_R(kern.ktype, N + M, D, XQ.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                              kern.oracle_hyper().ctypes.data_as(ctypes.POINTER(ctypes.c_double)), kern.sf2_py, noise,
+                              Rb.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        Ks = Rb[:N, N:]
+        V = np.linalg.solve(gp.L, Ks)                     # W k* per candidate (columns)
+        q_rows = V * V
+        q = q_rows.sum(0)
+        s2_raw = 1.0 + noise - q
+        ok = (s2_raw > 1e-7) & (s2_raw < 10)
+        np.testing.assert_allclose(s2[ok], s2_raw[ok], rtol=1e-8, atol=1e-12)   # the oracle's variance IS 1 + noise - |W k*|^2
+        h = N // 2
+        q_a = q_rows[:h].sum(0)
+        assert np.all(q_a <= q * (1 + 1e-15))
+        s2_ub = np.clip(1.0 + noise - q_a, 1e-7, 10.0)
+        ymax = float(Y.max())
+        for acq, erf_mode, parm in ((orc.ACQ_EI, orc.ERF_LIBM, .01), (orc.ACQ_EI, orc.ERF_NR, .4), (orc.ACQ_UCB, orc.ERF_LIBM, 1.7)):
+            exact = orc.acq_value(acq, erf_mode, mu, np.sqrt(np.clip(s2_raw, 1e-7, 10.0)), ymax, parm)
+            bound = orc.acq_value(acq, erf_mode, mu, np.sqrt(s2_ub), ymax, parm)
+            slack = 1e-9 * np.abs(exact) + 1e-13 * (1 + abs(ymax) + abs(parm))
+            assert np.all(bound >= exact - slack), float(np.min(bound - exact))
+            # the device's selection on 32-candidate tiles
+            tb = bound.reshape(-1, 32).max(1); te = exact.reshape(-1, 32).max(1)
+            cut = np.sort(tb)[::-1][max(0, len(tb) * 3 // 100)]
+            done = tb >= cut
+            best = te[done].max()
+            lim = best - (1e-9 * abs(best) + 1e-13 * (1 + abs(ymax) + abs(parm)))
+            done |= tb >= lim
+            assert done[int(np.argmax(exact)) // 32]
+            assert te[done].max() == exact.max()
