@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised check of the kept-state sweeps (ibo_acq_sweep_incremental, arg-max only): the two-part, lazily refreshed state
 (gallery_prune = 1) against the same launches with every tile refreshed and completed (2) -- BIT FOR BIT -- and against the one-kernel
-state with every candidate refreshed (0) -- same index, value at 1e-9 -- over random models, candidate sets, acquisitions, exclusion
+state with every candidate refreshed (0) -- same index, value at 1e-7 (the bar is 1e-6; another association of the same sums moves an EI of 1e-8, deep in
+its tail, by 1e-9 of itself) -- over random models, candidate sets, acquisitions, exclusion
 balls, and rounds that add hallucinated observations, real ones, two at a time, with and without a mean prior.
     python3 tools/fuzz_gallery.py [cases] [seed]"""
 import sys, os, time, ctypes
@@ -54,7 +55,7 @@ for case in range(cases):
         runs[mode] = out
     ok = len(runs[1]) == len(runs[2]) == len(runs[0])
     for a, b, c in zip(runs[1], runs[2], runs[0]):
-        ok = ok and a[0] == b[0] and a[1] == b[1] and a[1] == c[1] and (abs(a[0] - c[0]) <= 1e-9 * abs(c[0]) + 1e-300 or a[0] == c[0])
+        ok = ok and a[0] == b[0] and a[1] == b[1] and a[1] == c[1] and (abs(a[0] - c[0]) <= 1e-7 * abs(c[0]) + 1e-300 or a[0] == c[0])
     skipped.append(1 - runs[1][0][3] / max(1, runs[1][0][2]))
     if not ok:
         fails += 1
