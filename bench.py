@@ -522,7 +522,8 @@ def worker(args):
                 else:
                     gal = sharded_gallery(GP3, [[0., 1.]] * C3_D, 8, cand3, start3, comm)
                 gms_all.append(max_over_ranks((time.perf_counter() - t0) * 1e3))
-            gms = gms_all[1]
+            # "ms": the first call, as rounds 1 and 2 reported it (the only call then); "warm_ms": a second call on the same model
+            gms, gms_warm = gms_all[0], gms_all[1]
             if rank == 0:
                 k3 = float(np.mean([o[2] for o in o3])) * 1e-3
                 gal = np.array(gal)
@@ -536,7 +537,7 @@ def worker(args):
                                            "c3", float(C3_SHARD))}
                 cfgs["c3_gallery8"] = {"workload": "fastUCBGallery(N=8) on the same GP and shard(s): 7 rounds of DIRECT + "
                                                    "sharded sweep + exchange + hallucinated addData",
-                                       "ms": gms, "first_call_ms": gms_all[0], "min_pairwise_distance": float(min(
+                                       "ms": gms, "warm_ms": gms_warm, "min_pairwise_distance": float(min(
                                            np.linalg.norm(gal[i] - gal[j]) for i in range(8) for j in range(i)))}
             del GP3, cand3
             # C5: 64 theta-points per GPU
@@ -575,7 +576,7 @@ def worker(args):
                     g4.append((time.perf_counter() - t0) * 1e3)
                 cfgs["c4_prefgp"] = {"workload": "PrefGaussianProcess, 512 pairs -> 1024 points, D=6; gallery of 8 over 2^20 candidates",
                                      "addPreferences_ms": pms, "addPreferences_first_call_ms": pref_ms[0],
-                                     "gallery8_ms": g4[1], "gallery8_first_call_ms": g4[0]}
+                                     "gallery8_ms": g4[0], "gallery8_warm_ms": g4[1]}
                 del PG, cand4
                 # the sweep kernel against the input dimension (N = 1024, 2^18 candidates: a quarter of the headline batch, so the
                 # tail of the tile rounds weighs more): D = 17..32 take a 32-coordinate row layout and 6..9 k4-steps of the exponent GEMM

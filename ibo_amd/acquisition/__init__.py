@@ -96,11 +96,12 @@ def _ucb_parm(model, bounds, delta, scale):
     return float(np.sqrt(scale * 2.0 * np.log(t ** (NA // 2 + 2) * np.pi ** 2 / (3.0 * delta))))
 
 
-def gpuDirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc=None, xi=-1, scale=-1, delta=-1, compat=True,
-                return_samples=False, **kwargs):
-    """replacement of cdirectGP (:307-468): same enum mapping and `parm`, then DIRECT
-    on the GPU objective.  The model is already factored on the device, so the
-    per-call linalg.inv(R) of the reference disappears."""
+def cdirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc=None, xi=-1, beta=-1, scale=-1, delta=-1, compat=True,
+              return_samples=False, **kwargs):
+    """cdirectGP (ego/acquisition/__init__.py:307-468), same name, positional order and defaults (`beta` is accepted and
+    unused, as in the reference): same enum mapping and `parm`, then DIRECT on the GPU objective.  The model is already
+    factored on the device, so the per-call linalg.inv(R) of the reference disappears.  `compat` / `return_samples` are
+    additions (the dimension-0 stall switch, the sample count)."""
     if acqfunc == 'ei' or acqfunc == 'pi':
         parm = xi
     elif acqfunc == 'ucb':
@@ -128,6 +129,9 @@ def gpuDirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc=None, xi=-1,
     return opt.value, optx
 
 
+gpuDirectGP = cdirectGP          # the name earlier rounds of this package used
+
+
 def maximizeUCB(model, bounds, delta=0.1, scale=0.2, useCDIRECT=True, maxiter=50, maxtime=30, maxsample=10000,
                 **kwargs):
     """maximise the GP-UCB of [Srinivas 2009] (:78-96)"""
@@ -138,7 +142,7 @@ def maximizeUCB(model, bounds, delta=0.1, scale=0.2, useCDIRECT=True, maxiter=50
         opt, optx = direct(ucb.negf, bounds, maxiter=maxiter, maxtime=maxtime, maxsample=maxsample)
         return -opt, optx
     if isinstance(model, GaussianProcess):
-        return gpuDirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc='ucb', delta=delta, scale=scale,
+        return cdirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc='ucb', delta=delta, scale=scale,
                            **kwargs)
     raise ValueError
 
@@ -151,7 +155,7 @@ def maximizePI(model, bounds, xi=0.01, maxiter=50, maxtime=30, maxsample=10000, 
         opt, optx = direct(pi.negf, bounds, maxiter=maxiter, maxtime=maxtime, maxsample=maxsample)
         return -opt, optx
     if isinstance(model, GaussianProcess):
-        return gpuDirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc='pi', xi=xi, **kwargs)
+        return cdirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc='pi', xi=xi, **kwargs)
     raise ValueError
 
 
@@ -163,7 +167,7 @@ def maximizeEI(model, bounds, useCDIRECT=True, xi=0.01, maxiter=50, maxtime=30, 
         opt, optx = direct(ei.negf, bounds, maxiter=maxiter, maxtime=maxtime, maxsample=maxsample)
         return -opt, optx
     if isinstance(model, GaussianProcess):
-        return gpuDirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc='ei', xi=xi, **kwargs)
+        return cdirectGP(model, bounds, maxiter, maxtime, maxsample, acqfunc='ei', xi=xi, **kwargs)
     raise ValueError
 
 

@@ -78,12 +78,24 @@ def _prior_centres(model, bounds, members, floor):
     return (float(score[k]), pts[k]) if score[k] > floor else None
 
 
+def _state_info(model):
+    """(tiles, complete) of the sweep state kept on the model's handle (ibo_sweep_state_info)"""
+    import ctypes
+    t, c = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(_lib.lib.ibo_sweep_state_info(model._handle(), ctypes.byref(t), ctypes.byref(c)))
+    return t.value, c.value
+
+
 def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, candidates=None, seed=None,
-                   lhc_per_round=None, comm=None, index_base=0):
+                   lhc_per_round=None, comm=None, index_base=0, maxiter=50, maxsample=10000, trace=None):
     """N points to show a user (gallery.py:42-136).  Each round proposes (1) the DIRECT maximiser of
     EI(xi=.3), (2) the best of a sample set under EI(xi=.4, NR erf) -- one fused sweep, distance rule applied
     in the kernel -- and (3) the prior's centres; the highest admissible proposal joins the gallery and is
-    added to the model with its own posterior mean as a hallucinated observation."""
+    added to the model with its own posterior mean as a hallucinated observation.
+
+    maxiter / maxsample   the DIRECT step's budgets (the reference's maximizeEI defaults)
+    trace                 a list that receives one dict per round: the DIRECT proposal (opt, optx), the sweep's
+                          (value, global index), which proposal won, the sweep kernel and the kept state's (tiles, complete)"""
     gallery, model = _start(GP, bounds, useBest, rounds=N)
     # a fixed candidate array is swept every round while the model grows by one hallucinated point: it goes to
     # HBM once, and from the second round on the device folds the model's new row into the per-candidate state it
@@ -94,9 +106,10 @@ def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, ca
     rnd = 0
     while len(gallery) < N:
         pick_val, pick = -np.inf, None
-        opt, optx = maximizeEI(model, bounds, xi=.3, useCDIRECT=useCDIRECT)
+        opt, optx = maximizeEI(model, bounds, xi=.3, useCDIRECT=useCDIRECT, maxiter=maxiter, maxsample=maxsample)
+        source = None
         if _separated(optx, gallery):
-            pick_val, pick = opt, optx
+            pick_val, pick, source = opt, optx, "direct"
 
         if lhc_per_round is not None:
             S = np.asarray(lhc_per_round[rnd], dtype=float)
@@ -111,20 +124,26 @@ def fastUCBGallery(GP, bounds, N, useBest=True, samples=300, useCDIRECT=True, ca
             r = sharded_sweep(model, S, index_base, comm, acq='ei', xi=.4, native=False, exclude=shown,
                               exclude_radius=MIN_SEPARATION, incremental=fixed)
             if r["best_idx"] >= 0 and r["best_val"] > pick_val:
-                pick_val, pick = r["best_val"], np.array(r["best_x"])
+                pick_val, pick, source = r["best_val"], np.array(r["best_x"]), "sweep"
         else:
             r = sweep(model, S, acq='ei', xi=.4, native=False, exclude=shown, exclude_radius=MIN_SEPARATION,
                       incremental=fixed)
             if r["best_idx"] >= 0 and r["best_val"] > pick_val:
                 k = r["best_idx"]
-                pick_val = r["best_val"]
+                pick_val, source = r["best_val"], "sweep"
                 pick = S.view_rows(k, k + 1).to_host()[0] if isinstance(S, _lib.DeviceArray) else np.array(S[k])
 
         if model.prior is not None:
             extra = _prior_centres(model, bounds, gallery, pick_val)
             if extra is not None:
-                pick_val, pick = extra
+                (pick_val, pick), source = extra, "prior"
 
+        if trace is not None:
+            local = r.get("local", r)
+            tiles, complete = _state_info(model) if fixed else (0, 0)
+            trace.append(dict(round=rnd, opt=opt, optx=np.array(optx), sweep_val=r["best_val"], sweep_idx=r["best_idx"],
+                              source=source, value=pick_val, kernel=local["kernel"], tiles=tiles, complete=complete,
+                              n_model=len(model.X)))
         gallery.append(pick)
         model.addData(pick, model.mu(pick))
         rnd += 1

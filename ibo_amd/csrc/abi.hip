@@ -710,6 +710,11 @@ extern "C" int ibo_gp_extend(ibo_gp_t *g, int n, const double *Xnew, const doubl
             if (n2 > 1e5) g->dot_form = 0;
         }
     }
+    // the kept sweep state's stale tiles carry means formed with the OLD alpha vectors, and the lazy refresh's drift margin only
+    // covers the appended rows' (W y)_i: a caller that changed an earlier target along the way (GaussianProcess.Y is a public
+    // attribute) gets a full sweep next time, as after ibo_gp_set_y
+    for (int i = 0; i < N0; i++)
+        if (!(Yall[i] == g->Yhost[i])) { g->st_gen = 0; break; }
     g->N = N1; g->maxY = my;
     g->Yhost.assign(Yall, Yall + N1);
     g->L_upper_dirty = true;
@@ -1199,18 +1204,27 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
             // the arg-max is wanted, the second half of W's rows (three quarters of the work) runs only for tiles whose bound can
             // still reach the best complete value (sweep2.hip: launch_sweep2_pruned).  PI and the plain mean, per-candidate
             // outputs, or a model the part kernels do not take: every tile complete, as before.
-            const bool monotone = (acq == IBO_ACQ_EI || acq == IBO_ACQ_UCB) && !mu_dev && !s2_dev && !acq_dev;
+            // (UCB = mu + parm sigma grows with sigma only for parm >= 0: a caller's negative coefficient -- a lower confidence bound --
+            // takes the complete-every-tile route)
+            const bool monotone = (acq == IBO_ACQ_EI || (acq == IBO_ACQ_UCB && parm >= 0.0)) && !mu_dev && !s2_dev && !acq_dev;
             const int64_t nt32 = (M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
             a.part_rows = usable ? g->st_N0 : g->N;
             a.part_slack = 1e-13 * (1.0 + fabs(a.ymax) + fabs(a.parm));
             a.rank_hi = g->N; a.wy = g->tmp.p;               // (g->tmp[0 .. Npad) is W y after every fit, extension and ibo_gp_set_y)
+            // Drift margin of the lazy refresh: an appended row i moves a stale candidate's mean by nu_i (W y)_i, nu = W k*.  With
+            // R = sf2_fit P + (1 + noise - sf2_fit) I (P: the correlation matrix, unit diagonal -- the reference's diagonal rule) and
+            // k* = sf2_k p*, R >= sf2_fit P whenever sf2_fit <= 1 + noise, hence |nu_i|^2 <= q = k*^T R^-1 k* <= sf2_k^2 / sf2_fit
+            // (p*^T P^-1 p* <= 1 for a valid kernel).  1 for the squared exponentials, magnitude^2-dependent for the SV / Matern
+            // kernels and under ibo_gp_set_kstar_sf2.  A model fitted with sf2_fit > 1 + noise has no such bound: never lazy.
+            const bool nu_bounded = g->kp_fit.sf2 > 0.0 && g->kp_fit.sf2 <= 1.0 + g->noise;
+            a.nu_max = nu_bounded ? (g->kp.sf2 / sqrt(g->kp_fit.sf2)) * (1.0 + 1e-9) : INFINITY;
             if (usable && g->st_pruned) {
                 // a two-part state: its tiles fold the appended rows in lazily (launch_sweep2_refresh); a caller that needs every
                 // candidate's own numbers (outputs, PI, the plain mean), the A/B switch, or a mean prior (whose second vector W 1
                 // moves the means of stale tiles by more than any margin allows) has every tile refreshed and completed instead
                 a.tile_done = g->tile_done.p; a.tile_ub = g->tile_ub.p; a.part_best = g->part_words.p; a.part_thresh = g->part_words.p + 1;
                 a.tile_rows = g->tile_rows.p; a.tile_sel = g->tile_sel.p;
-                a.part_lazy = monotone && g_gallery_prune == 1 && g_gallery_lazy && g->nb == 0;
+                a.part_lazy = monotone && g_gallery_prune == 1 && g_gallery_lazy && g->nb == 0 && nu_bounded;
             }
             if (usable) {
                 KERNEL_TRY(launch_sweep2_refresh(a, g->st_N, g->N - 1, s, g->ev0, g->ev1));

@@ -296,6 +296,11 @@ void make_division(const Pool &pool, size_t j, Division &dv)      // dv is reuse
 // only involves, per distinct size, the smallest y of that size (a slope to a fixed size is monotone in y, in
 // floating point too): same decisions, same floating-point values, in two passes over the living rectangles --
 // O(R + candidates x sizes) instead of O(R^2), with no sort (the size classes are kept by the pool).
+// FINITE objective values are assumed for "same decisions": the reference's all-pairs scan selects a rectangle whose
+// value is NaN (every comparison with it is false) and lets equal +/-inf values through a NaN slope, while here a NaN
+// never becomes a class minimum and equal infinities are rejected by the suffix-minimum test.  The GP acquisitions
+// this search is run on are finite by construction (clamped variance, finite means); a host callback that returns
+// NaN or inf gets a well-defined search, not the reference's trajectory.
 void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out)
 {
     const double eps = 10e-10;

@@ -202,11 +202,12 @@ struct SweepArgs {
     double *tile_ub;                           // per tile: largest value (exact or bound) of its candidates (acq_bound_kernel)
     unsigned long long *part_thresh;           // order-preserving bits of the value a tile's bound must reach to be completed (0: any finite bound)
     int part_all;                              // complete every incomplete tile, whatever its bound
-    double part_slack;                         // absolute part of the slack a bound is given against the threshold (s2_part_limit)
     int part_means;                            // the first part also forms aY.k* and a1.k* (its launch carries the alpha vectors in LDS)
+    double part_slack;                         // absolute part of the slack a bound is given against the threshold (s2_part_limit)
     // lazy refresh of such a state: per tile the appended rows already folded into zsum (and the means' age), the selection flags of
     // the launch at hand, the model's rows now, W y (the drift margin's source), and whether tiles may be left stale at all
     int *tile_rows; int *tile_sel; int rank_hi; const double *wy; int part_lazy;
+    double nu_max;                             // bound on |(W k*)_i| for any candidate: sf2_k / sqrt(sf2_fit) (abi.hip: run_sweep); the drift margin's factor
     unsigned long long *part_best;             // acq_bound_kernel: running maximum over the COMPLETE tiles, same encoding
     // small2.hip: when set, the last workgroup of the last kernel stores done_seq there (host-visible memory) after all
     // results are out -- the host spins on that word instead of going through an event

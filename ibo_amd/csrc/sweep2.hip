@@ -434,8 +434,10 @@ __global__ __launch_bounds__(256) void acq_bound_kernel(SweepArgs a)
     bool excl;
     const double q = (a.qpart[gi] + a.qpart[4 * a.M + gi]) + a.qpart[3 * a.M + gi];
     // A tile that has not folded in every appended row (lazy refresh) carries means formed before those rows existed.  Row i moves a
-    // candidate's mean by nu_i (W y)_i with |nu_i| <= sigma <= sqrt(10) (the variance clamp), so its value is bounded by the
-    // acquisition at mean + sqrt(10) sum |(W y)_i| -- nothing when the appended observations sit on the posterior mean (the gallery's
+    // candidate's mean by nu_i (W y)_i, nu = W k*, and |nu_i| <= sqrt(q) <= a.nu_max = sf2_k / sqrt(sf2_fit) -- the PRIOR standard
+    // deviation in units of the fitted matrix (1 for the squared exponentials; the magnitude for SV / Matern kernels; run_sweep
+    // derives it and switches the lazy mode off where no bound exists).  So the tile's value is bounded by the acquisition at
+    // mean + nu_max sum |(W y)_i| -- nothing when the appended observations sit on the posterior mean (the gallery's
     // hallucinations), anything when they do not: then no tile is skipped.  (A mean prior multiplies a second vector, (W 1)_i, that is
     // never small: the caller refreshes every tile then.)
     const int64_t tile = gi >> 5;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void acq_bound_kernel(SweepArgs a)
     double margin = 0.0;
     if (!fresh) {
         for (int i = a.part_rows; i < a.rank_hi; i++) margin += fabs(a.wy[i]);
-        margin *= 3.1622776601683795;
+        margin = margin > 0.0 ? margin * a.nu_max : 0.0;        // (rows with (W y)_i = 0 exactly move nothing, whatever nu is)
     }
     double val = s2_finish(a, a.cand + gi * a.kp.D, q, a.qpart[a.M + gi] + margin, a.qpart[2 * a.M + gi], li, valid, excl);
     if (!valid || excl || !(val == val)) val = -INFINITY;

@@ -10,8 +10,10 @@ largest value, ties to the lowest global index (numpy.argmax order).
 
 The transport is any object with .world_size, .rank, .argmax(val, idx, payload) and
 .allreduce_sum(buf): `RcclArgmax` is libibo_hip's RCCL path over xGMI (csrc/comm.hip);
-the CPU tests drive the identical slot protocol (fill_slot / reduce_slots) over gloo
-with a transport of their own (tests/gloo_transport.py).
+`SocketComm` carries the same slot protocol over a Unix-domain socket on one host -- for
+worlds RCCL cannot form (several ranks on ONE device: RCCL refuses two ranks per GPU) and
+for debugging, never the fast path; the CPU tests drive the identical protocol
+(fill_slot / reduce_slots) over gloo with a transport of their own (tests/gloo_transport.py).
 """
 import ctypes
 
@@ -99,6 +101,104 @@ class RcclArgmax(object):
         if getattr(self, "h", None):
             _lib.lib.ibo_comm_destroy(self.h)
             self.h = None
+
+
+class SocketComm(object):
+    """The slot protocol and the sum over a Unix-domain socket, host memory only: rank 0 listens on `address`
+    (a filesystem path), gathers every rank's fp64 buffer, adds them IN RANK ORDER and sends the sum back to all.
+    Every slot of the arg-max exchange is non-zero on exactly one rank, so the sum there is exact and every rank
+    applies the same final reduction as after ncclAllReduce (csrc/comm.hip: slot_argmax).  What it is for: running
+    the sharded paths with more than one rank where RCCL cannot -- two rank processes on the ONE GPU of a build box
+    (tests/test_gpu_two_ranks.py) -- with no second GPU runtime and no torch in the process."""
+
+    def __init__(self, world_size, rank, address, timeout_s=300.0):
+        import socket
+        import struct
+        import time
+        self.world_size, self.rank, self.address = int(world_size), int(rank), address
+        self._peers, self._listener = {}, None
+        if self.world_size == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(address)
+            srv.listen(self.world_size)
+            srv.settimeout(timeout_s)
+            self._listener = srv
+            while len(self._peers) < self.world_size - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout_s)
+                r = struct.unpack("<q", self._recv_exact(c, 8))[0]
+                if not (0 < r < self.world_size) or r in self._peers:
+                    raise RuntimeError("SocketComm: unexpected rank %d on %s" % (r, address))
+                self._peers[r] = c
+        else:
+            t0 = time.time()
+            while True:
+                c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    c.connect(address)
+                    break
+                except OSError:
+                    c.close()
+                    if time.time() - t0 > timeout_s:
+                        raise RuntimeError("SocketComm: rank 0 never listened on %s" % address)
+                    time.sleep(0.01)
+            c.settimeout(timeout_s)
+            c.sendall(struct.pack("<q", self.rank))
+            self._peers[0] = c
+
+    @staticmethod
+    def _recv_exact(sock, n):
+        chunks, got = [], 0
+        while got < n:
+            b = sock.recv(min(n - got, 1 << 20))
+            if not b:
+                raise RuntimeError("SocketComm: peer closed the connection")
+            chunks.append(b)
+            got += len(b)
+        return b"".join(chunks)
+
+    def allreduce_sum(self, buf):
+        a = np.ascontiguousarray(buf, dtype=np.float64).reshape(-1).copy()
+        if self.world_size == 1:
+            return a
+        if self.rank == 0:
+            for r in range(1, self.world_size):
+                a += np.frombuffer(self._recv_exact(self._peers[r], a.nbytes), dtype=np.float64)
+            raw = a.tobytes()
+            for r in range(1, self.world_size):
+                self._peers[r].sendall(raw)
+            return a
+        self._peers[0].sendall(a.tobytes())
+        return np.frombuffer(self._recv_exact(self._peers[0], a.nbytes), dtype=np.float64).copy()
+
+    def argmax(self, val, idx, payload=()):
+        payload = np.asarray(payload, dtype=float).reshape(-1)
+        out = self.allreduce_sum(fill_slot(self.world_size, self.rank, val, idx, payload))
+        return reduce_slots(out, self.world_size, len(payload))
+
+    def barrier(self):
+        self.allreduce_sum(np.zeros(1))
+
+    def nranks(self):
+        return self.world_size
+
+    def close(self):
+        import os
+        for c in self._peers.values():
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers = {}
+        if self._listener is not None:
+            self._listener.close()
+            self._listener = None
+            try:
+                os.unlink(self.address)
+            except OSError:
+                pass
 
 
 def _rendezvous_path():

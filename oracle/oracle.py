@@ -635,9 +635,12 @@ def pref_fit(kern, prefs, noise=.1, prior=None, Y_map=None):
 # --------------------------------------------------------------------------
 # gallery (ego/acquisition/gallery.py:42-136) with the LHC samples injected
 # --------------------------------------------------------------------------
-def fast_gallery(gp, bounds, N, lhc_per_round, use_best=True, maxiter=50, maxsample=10000):
+def fast_gallery(gp, bounds, N, lhc_per_round, use_best=True, maxiter=50, maxsample=10000, fast=False):
     """gp: GP or pref GP with data.  lhc_per_round: list of (S,D) arrays, one per round.
-    Returns (gallery list, trace list of dict(opt, optx, best_lhc))."""
+    Returns (gallery list, trace list of dict(opt, optx, best_lhc)).
+    fast=True evaluates the sample step with sweep_fast (all cores, alpha cached, triangular L^-1: the same
+    posterior + NR-erf EI, pinned against the per-point path by tests/test_oracle_golden.py) -- what makes
+    20 000-candidate rounds on 2000-point models affordable for the GPU parity tests; no prior mean."""
     gallery = []
     if use_best:
         bestY = -np.inf; bestX = None
@@ -655,11 +658,23 @@ def fast_gallery(gp, bounds, N, lhc_per_round, use_best=True, maxiter=50, maxsam
         if len(gallery) == 0 or min(np.linalg.norm(optx - g) for g in gallery) > .5:
             bestU, bestX = opt, optx
         S = _f64(lhc_per_round[rnd])
-        mu, s2 = h.posteriors(S)
-        u = acq_value(ACQ_EI, ERF_NR, mu, np.sqrt(s2), np.max(h.Y), .4)
-        for x, ux in zip(S, u):
-            if ux > bestU and min(np.linalg.norm(x - g) for g in gallery) > .5:
-                bestU, bestX = ux, x
+        if fast:
+            # (the scan below in vector form: first index of the largest admissible value, and only if it beats DIRECT's)
+            assert h.kern.sf2_native == h.kern.sf2_py
+            u = sweep_fast(h, S, ACQ_EI, .4, ERF_NR, CLAMP_PY)["acq"]
+            if len(gallery):
+                G = np.array(gallery)
+                dmin = np.min(np.sqrt(np.sum((S[:, None, :] - G[None, :, :]) ** 2, axis=2)), axis=1)
+                u = np.where(dmin > .5, u, -np.inf)
+            k = int(np.argmax(u))
+            if u[k] > bestU:
+                bestU, bestX = u[k], S[k]
+        else:
+            mu, s2 = h.posteriors(S)
+            u = acq_value(ACQ_EI, ERF_NR, mu, np.sqrt(s2), np.max(h.Y), .4)
+            for x, ux in zip(S, u):
+                if ux > bestU and min(np.linalg.norm(x - g) for g in gallery) > .5:
+                    bestU, bestX = ux, x
         gallery.append(np.array(bestX))
         trace.append(dict(opt=opt, optx=np.array(optx), chosen=np.array(bestX), u=bestU))
         h = GP(h.kern, np.vstack([h.X, bestX]), np.r_[h.Y, h.mu(bestX)], prior=h.prior)

@@ -23,9 +23,44 @@ def _ensure_built():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
+_LAUNCHER = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     _ensure_built()
+    # the helper that starts rank processes for the GPU tests: created NOW, while this process has not touched the GPU
+    # (tests/rank_launcher.py says why); idle unless a test asks
+    global _LAUNCHER
+    import subprocess
+    _LAUNCHER = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rank_launcher.py")], stdin=subprocess.PIPE,
+                                 stdout=subprocess.PIPE, cwd=ROOT)
+
+
+def pytest_unconfigure(config):
+    global _LAUNCHER
+    if _LAUNCHER is not None:
+        try:
+            _LAUNCHER.stdin.close()                      # EOF ends it
+            _LAUNCHER.wait(10)
+        except Exception:
+            _LAUNCHER.kill()
+        _LAUNCHER = None
+
+
+@pytest.fixture(scope="session")
+def launch_ranks():
+    """launch_ranks(argv, world, env=None, timeout=600) -> dict(rc, out, err): `world` fresh python processes running argv,
+    started by a helper that never touched the GPU"""
+    import json
+
+    def launch(argv, world, env=None, timeout=600):
+        assert _LAUNCHER is not None and _LAUNCHER.poll() is None, "the rank launcher is not running"
+        job = {"argv": list(argv), "world": int(world), "env": env or {}, "timeout": timeout}
+        _LAUNCHER.stdin.write((json.dumps(job) + "\n").encode())
+        _LAUNCHER.stdin.flush()
+        return json.loads(_LAUNCHER.stdout.readline().decode())
+    return launch
 
 
 def load_golden(name):

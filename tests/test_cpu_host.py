@@ -291,7 +291,7 @@ def test_install_as_ego_aliases_every_module():
                  "ego.gaussianprocess.trainhyper", "ego.acquisition", "ego.acquisition.gallery", "ego.utils.optimize",
                  "ego.utils.latinhypercube"):
         assert importlib.import_module(name) is importlib.import_module(name.replace("ego", "ibo_amd", 1))
-    from ego.acquisition import maximizeEI, maximizePI, maximizeUCB, EI, PI, UCB      # noqa: F401
+    from ego.acquisition import maximizeEI, maximizePI, maximizeUCB, EI, PI, UCB, cdirectGP      # noqa: F401
     from ego.acquisition.gallery import fastUCBGallery                                 # noqa: F401
     from ego.gaussianprocess import GaussianProcess, PrefGaussianProcess, CDF, PDF     # noqa: F401
     from ego.utils.optimize import direct, cdirect                                     # noqa: F401
@@ -300,6 +300,11 @@ def test_install_as_ego_aliases_every_module():
     assert [p for p in sig.parameters][:6] == ["model", "bounds", "useCDIRECT", "xi", "maxiter", "maxtime"]
     assert sig.parameters["maxsample"].default == 10000 and sig.parameters["xi"].default == 0.01
     assert inspect.signature(fastUCBGallery).parameters["samples"].default == 300
+    # cdirectGP: the reference's positional order and defaults (ego/acquisition/__init__.py:307), `beta` included
+    sig = inspect.signature(cdirectGP)
+    assert [p for p in sig.parameters][:10] == ["model", "bounds", "maxiter", "maxtime", "maxsample", "acqfunc", "xi", "beta",
+                                                "scale", "delta"]
+    assert [sig.parameters[k].default for k in ("acqfunc", "xi", "beta", "scale", "delta")] == [None, -1, -1, -1, -1]
     sig = inspect.signature(GaussianProcess.__init__)
     assert sig.parameters["noise"].default == .1 and sig.parameters["gnoise"].default == 1e-4
 

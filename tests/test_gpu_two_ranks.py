@@ -1,0 +1,84 @@
+"""
+The sharded paths with MORE THAN ONE RANK on the one GPU of the box (ego/acquisition/gallery.py:93-134 is the
+loop they shard).  RCCL refuses two ranks on one device, so the ranks talk through ibo_amd.multigpu.SocketComm -- the same
+slot protocol, the same final reduction -- and everything else is the product path: per-rank handles, candidate blocks with
+index_base != 0, the kept sweep state per shard, lock-step hallucination, the theta blocks of the NLML grid.
+
+The rank processes are fresh interpreters started by tests/rank_launcher.py (a helper that never touches the GPU; this
+pytest process has).  Every rank must return the same result, and that result must equal the single-process run BIT FOR
+BIT.  A failing rank exits non-zero and the launcher terminates the others.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+@pytest.mark.parametrize("world,shape", [(2, "c3"), (3, "small")])
+def test_sharded_paths_with_several_ranks_on_one_gpu(launch_ranks, world, shape):
+    import two_rank_worker as W
+    from ibo_amd import DeviceArray, _lib
+    from ibo_amd.acquisition import sweep
+    from ibo_amd.acquisition.gallery import fastUCBGallery
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid
+    from ibo_amd.multigpu import shard_bounds
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible: the product has no CPU fallback")
+    with tempfile.TemporaryDirectory(prefix="ibo_ranks_") as tmp:
+        out = os.path.join(tmp, "res")
+        res = launch_ranks([os.path.join(ROOT, "tests", "two_rank_worker.py"), os.path.join(tmp, "sock"), out, shape], world,
+                           timeout=900)
+        assert res["rc"] == [0] * world, "\n".join("rank %d rc %s\n%s" % (r, rc, e[-3000:]) for r, (rc, e) in enumerate(zip(res["rc"], res["err"])))
+        ranks = [dict(np.load(out + ".rank%d.npz" % r)) for r in range(world)]
+    sh = W.shapes(shape)
+    # the blocks tile the array, rank 1's block does not start at row 0
+    for r in range(world):
+        assert (int(ranks[r]["start"]), int(ranks[r]["stop"])) == shard_bounds(sh["M"], world, r)
+    assert int(ranks[1]["start"]) > 0
+    # every rank returns the same result ...
+    for r in range(1, world):
+        for key in ("sweep", "gallery", "nlml", "argmin"):
+            np.testing.assert_array_equal(ranks[r][key], ranks[0][key], err_msg="rank %d differs in %s" % (r, key))
+    # ... and it is the single-process result, bit for bit
+    GP, cand = W.model_and_candidates(sh)
+    dc = DeviceArray.from_host(cand)
+    one = sweep(GP, dc, acq='ei', xi=.3, native=True)
+    sw = ranks[0]["sweep"]
+    assert sw[0] == one["best_val"] and int(sw[1]) == one["best_idx"]
+    owner = [r for r in range(world) if ranks[r]["start"] <= one["best_idx"] < ranks[r]["stop"]][0]
+    assert int(sw[2]) == owner
+    np.testing.assert_array_equal(sw[3:], cand[one["best_idx"]])
+    trace = []
+    gal = np.array(fastUCBGallery(GP, [[0., 1.]] * sh["D"], sh["picks"], candidates=dc, maxiter=sh["maxiter"], trace=trace))
+    np.testing.assert_array_equal(ranks[0]["gallery"], gal)
+    # the per-shard machinery was the kept state (two-part first sweep, refreshes afterwards), with GLOBAL indices in the
+    # exchange, and at least one round was decided by a candidate of a block that does not start at row 0 or by DIRECT on every rank alike
+    for r in range(world):
+        k = list(ranks[r]["kernels"])
+        assert k[0] == "sweep2_kernel<part>" and all(x == "sweep2_rank1_kernel" for x in k[1:]), (r, k)
+        np.testing.assert_array_equal(ranks[r]["sources"], np.array([t["source"] for t in trace]))
+        np.testing.assert_array_equal(ranks[r]["sweep_idx"], np.array([t["sweep_idx"] for t in trace], dtype=np.int64))
+    assert np.all(ranks[0]["tiles"][:, 1] < ranks[0]["tiles"][:, 0])            # pruning was active on the shard
+    X, Y, th, nz = W.grid_problem(sh)
+    vals, am = nlml_grid(GaussianKernel_ard, th, X, Y, noise=nz)
+    np.testing.assert_array_equal(ranks[0]["nlml"], vals)
+    assert int(ranks[0]["argmin"]) == am and np.isnan(vals[sh["bad"]]) and np.isfinite(vals).sum() == sh["T"] - 1
+
+
+def test_a_failing_rank_fails_the_launch(launch_ranks):
+    """rank 1 exits non-zero right away; rank 0, waiting for it, is terminated by the launcher -- no hang, both codes reported"""
+    code = ("import os, sys, time\n"
+            "if os.environ['RANK'] == '1': sys.exit(3)\n"
+            "time.sleep(600)\n")
+    res = launch_ranks(["-c", code], 2, timeout=60)
+    assert res["rc"][1] == 3 and res["rc"][0] not in (0, None), res["rc"]
+    assert res["seconds"] < 30

@@ -1,6 +1,6 @@
 #!/bin/bash
-# every r03 artefact under profiles/ from one GPU-box session (run from the repo root):  bash tools/r03_final.sh [tag]
-TAG=${1:-r03}
+# every rNN artefact under profiles/ from one GPU-box session (run from the repo root):  bash tools/profile_all.sh rNN
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/final_$TAG profiles
 O=gpurun_out/final_$TAG
