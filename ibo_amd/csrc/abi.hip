@@ -6,6 +6,7 @@
 #include "../../include/ibo_abi.h"
 #include "ibo_common.h"
 #include "direct_host.h"
+#include "legacy.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -48,30 +50,36 @@ void ibo_internal_set_error(const char *msg)
     } while (0)
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
-extern int g_sweep_variant;     // sweep.hip
-static int g_host_pipeline = 1;  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
-static int g_chol_fused = 1;     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
-static int g_fused2_min_nb = 33;  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
-static int g_chol_fused2 = 1;    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
-static int g_zero_copy = 1;      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
-static int g_small_trace = 0;    // ibo_set_option("small_trace", 1: start / 2: print to stderr): host-side split of the zero-copy small batches
+extern std::atomic<int> g_sweep_variant;     // sweep.hip
+static std::atomic<int> g_host_pipeline{1};  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
+static std::atomic<int> g_chol_fused{1};     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
+static std::atomic<int> g_fused2_min_nb{33};  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
+static std::atomic<int> g_chol_fused2{1};    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
+static std::atomic<int> g_zero_copy{1};      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
+static std::atomic<int> g_small_trace{0};    // ibo_set_option("small_trace", 1: start / 2: print to stderr): host-side split of the zero-copy small batches
 static double g_st_launch = 0.0, g_st_wait = 0.0, g_st_copy = 0.0; static long g_st_n = 0;
-static int g_gallery_prune = 1;  // ibo_set_option("gallery_prune", 0/1/2): kept-state sweeps in two parts of W's rows, the second only where a
+static std::atomic<int> g_gallery_prune{1};  // ibo_set_option("gallery_prune", 0/1/2): kept-state sweeps in two parts of W's rows, the second only where a
                                  // tile's bound can still win (1); the same launches with every tile completed (2); the one-kernel sweep (0)
-static int g_gallery_lazy = 1;   // ibo_set_option("gallery_lazy", 0/1): a two-part state's later rounds refresh only the tiles whose bound can matter
-static int g_flag_poll = 1;      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
-static int g_gemv_max = 0;       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
-static int g_small2 = 1;         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
-static int g_chol_ride = 1;      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
-static int g_nlml_batch = 0;     // 0 = choose (memory-bounded), else matrices per batched factorisation
-static int g_cov_fast = 1;       // ibo_set_option("cov_fast", 0/1): ibo_nlml_grid's covariance pass with scaled coordinates and the sweep's exp (see cov_matrix_kernel)
-static int g_chol_left = 1;      // ibo_set_option("chol_left", 0/1): ibo_nlml_grid factors in the left-looking outer order (update3.hip)
-static int g_nlml_groups = 2;    // ibo_set_option("nlml_groups", g): a batch of theta-points runs as g sub-batches on g streams (the latency-bound
+static std::atomic<int> g_gallery_lazy{1};   // ibo_set_option("gallery_lazy", 0/1): a two-part state's later rounds refresh only the tiles whose bound can matter
+static std::atomic<int> g_flag_poll{1};      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
+static std::atomic<int> g_gemv_max{0};       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
+static std::atomic<int> g_small2{1};         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
+static std::atomic<int> g_chol_ride{1};      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
+static std::atomic<int> g_nlml_batch{0};     // 0 = choose (memory-bounded), else matrices per batched factorisation
+static std::atomic<int> g_cov_fast{1};       // ibo_set_option("cov_fast", 0/1): ibo_nlml_grid's covariance pass with scaled coordinates and the sweep's exp (see cov_matrix_kernel)
+static std::atomic<int> g_chol_left{1};      // ibo_set_option("chol_left", 0/1): ibo_nlml_grid factors in the left-looking outer order (update3.hip)
+static std::atomic<int> g_nlml_groups{2};    // ibo_set_option("nlml_groups", g): a batch of theta-points runs as g sub-batches on g streams (the latency-bound
                                  // in-panel chain and the launch tails of one overlap the MFMA-bound updates of the other); values do not depend on it
-static int g_dot_override = -1;  // -1 auto, 0/1 force (tests)
-static int g_force_path = 0;   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
+static std::atomic<int> g_dot_override{-1};  // -1 auto, 0/1 force (tests)
+static std::atomic<int> g_legacy_exact{1};  // ibo_set_option("legacy_exact", 0/1): acqmaxGP evaluates libego's formulas in libego's operation order (legacy.hip)
+static std::atomic<int> g_force_path{0};   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
 
-static size_t g_pool_limit = (size_t)2 << 30;    // ibo_set_option("pool_limit_mb", n) / env IBO_POOL_LIMIT_MB
+// The option switches above are process-wide configuration (atomics: setting one while another thread computes is a defined,
+// if unspecified-moment, change); the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad, the exp table and ibo_trim are
+// serialised by g_dev_mu; handles are independent of each other (own stream, events, buffers) -- two threads may drive two
+// handles on one device at once.  ONE handle is for one thread at a time.  (small_trace's counters are a single-threaded diagnostic.)
+static std::mutex g_dev_mu[16];
+static std::atomic<size_t> g_pool_limit{(size_t)2 << 30};    // ibo_set_option("pool_limit_mb", n) / env IBO_POOL_LIMIT_MB
 
 static int use_device(int device)
 {
@@ -82,15 +90,14 @@ static int use_device(int device)
                     e == hipSuccess ? "count=0" : hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(IBO_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
     HIP_TRY(hipSetDevice(device));
-    static bool env_read = false;
-    if (!env_read) {
+    static std::once_flag env_read;
+    std::call_once(env_read, [] {
         const char *s = getenv("IBO_SWEEP_IMPL");
         if (s && !strcmp(s, "gemv")) g_force_path = 1;
         if (s && !strcmp(s, "mfma")) g_force_path = 2;
         const char *pl = getenv("IBO_POOL_LIMIT_MB");
         if (pl && atoll(pl) >= 0) g_pool_limit = (size_t)atoll(pl) << 20;
-        env_read = true;
-    }
+    });
     return IBO_OK;
 }
 
@@ -315,6 +322,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "gallery_prune")) { g_gallery_prune = value; return IBO_OK; }
     if (key && !strcmp(key, "part_means")) { set_part_means(value); return IBO_OK; }
     if (key && !strcmp(key, "gallery_lazy")) { g_gallery_lazy = value; return IBO_OK; }
+    if (key && !strcmp(key, "legacy_exact")) { g_legacy_exact = value; return IBO_OK; }
     if (key && !strcmp(key, "small_trace")) {
         if (value == 2 && g_st_n) fprintf(stderr, "[ibo] small batches: %ld, staging + launches %.2f us, wait %.2f us, results %.2f us each\n", g_st_n, g_st_launch / g_st_n, g_st_wait / g_st_n, g_st_copy / g_st_n);
         g_small_trace = value == 1; g_st_launch = g_st_wait = g_st_copy = 0.0; g_st_n = 0;
@@ -1097,6 +1105,7 @@ extern "C" int ibo_spd_inverse(int device, int N, const double *A_host, double *
 static double *g_exp_tab[16];
 static int exp_table(int device, const double **out)
 {
+    std::lock_guard<std::mutex> lk(g_dev_mu[device & 15]);      // created once per device, by whichever handle sweeps first
     double *&p = g_exp_tab[device & 15];
     if (!p) {
         std::vector<double> h(2048);
@@ -1122,7 +1131,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     SweepArgs a;
     memset(&a, 0, sizeof(a));
     a.kp = g->kp; a.N = g->N; a.Npad = g->Npad; a.DP = g->DP; a.M = M;
-    a.Xs = g->Xs.p; a.ak = g->ak.p; a.XA = g->XA.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = (g_dot_override >= 0 && g->D <= IBO_DDOT) ? g_dot_override : g->dot_form;
+    a.Xs = g->Xs.p; a.ak = g->ak.p; a.XA = g->XA.p; a.log_sf2 = log(g->kp.sf2); a.dot_form = (g_dot_override >= 0 && g->D <= IBO_DDOT) ? g_dot_override.load() : g->dot_form;
     a.Xp = g->Xp.p; a.W = g->W.p; a.Wp = g->Wp.p; a.alphaY = g->alphaY.p; a.alpha1 = g->alpha1.p;
     a.cand = cand_dev; a.cand_host = cand_host;
     a.prior.nb = g->nb; a.prior.theta = g->ptheta; a.prior.means = g->pmeans.p; a.prior.beta = g->pbeta.p;
@@ -1573,6 +1582,7 @@ static GradWorkspace g_grad_ws[16];
 extern "C" int ibo_trim(int device)
 {
     IBO_TRY(use_device(device));
+    std::lock_guard<std::mutex> lk(g_dev_mu[device & 15]);
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
     ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release(); ws.dkp.release();
     ws.padded = nullptr;
@@ -1590,6 +1600,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
 {
     if (!X || !Y || !thetas || !nlml_host || N < 1 || n_theta < 1) return fail(IBO_ERR_ARG, "bad argument");
     IBO_TRY(use_device(device));
+    std::lock_guard<std::mutex> lk(g_dev_mu[device & 15]);      // the batch workspace is per device: concurrent grids take turns
     const int Np = round_up(N + 1, 64);            // room for the appended y row (see aug_row_kernel)
     // theta-points are independent and one factorisation is a latency-bound chain of small kernels:
     // B matrices sit side by side in HBM (B x 8 Np^2 bytes -- 4.4 GB for 32 x N=4096, nothing on a 288 GB
@@ -1602,7 +1613,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         size_t fit = budget / (nn * sizeof(double));
         if (fit < 1) fit = 1;
         if (fit > 256) fit = 256;                   // N = 4096: 64 matrices side by side 0.617 ms per theta, 32: 0.655, 16: 0.72; N = 1024: 256: 45 us, 32: 69 us
-        B = g_nlml_batch > 0 ? g_nlml_batch : (int)fit;
+        B = g_nlml_batch > 0 ? g_nlml_batch.load() : (int)fit;
         if (B > n_theta) B = n_theta;
     }
     // the workspace is kept between calls (hyper-parameter learning calls this in a loop and allocating and
@@ -1638,7 +1649,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         const int nb = n_theta - t0 < B ? n_theta - t0 : B;
         // sub-batches of at least 8 matrices, each on its own stream: one's in-panel chain (64 workgroups at a time, latency)
         // and launch tails run beside the other's long-K updates
-        int G = left ? g_nlml_groups : 1;
+        int G = left ? g_nlml_groups.load() : 1;
         while (G > 1 && nb / G < 8) G--;
         for (int g = 0; g < G; g++) {
             if (G > 1 && !ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
@@ -1675,6 +1686,7 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     if (!X || !Y || !hyper || !modes || !dims || !nlml_host || !grad_host || N < 1) return fail(IBO_ERR_ARG, "bad argument");
     if (ngrad < 1 || ngrad > IBO_GRAD_MAX) return fail(IBO_ERR_ARG, "ngrad=%d unsupported (1..%d)", ngrad, IBO_GRAD_MAX);
     IBO_TRY(use_device(device));
+    std::lock_guard<std::mutex> lk(g_dev_mu[device & 15]);      // (its workspace too)
     KParams kp;
     IBO_TRY(make_kparams(ktype, D, hyper, nhyper, sf2, &kp));
     GradSpec gs;
@@ -1738,6 +1750,75 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     return IBO_OK;
 }
 
+// ------------------------------------------------------------------------ libego's arithmetic in libego's order (legacy.hip)
+struct LegacyModel {
+    int ndim, nx, acqfunc, kerneltype, npbases;
+    const double *X, *Y, *hyper, *pmeans, *pbeta, *plowerb, *pwidth;
+    double sf2, ptheta, parm, noise;
+};
+
+// DIRECT (same host search as every other entry point, libego's dimension-0 quirk on) over an objective whose every number is
+// libego's: k*, the prior mean and the acquisition on the host's libm, the two N^2 contractions per point on the device in
+// libego's summation order.  Without a prior the first contraction's inner vector inv(R) Y is the same for every point:
+// formed once.  Buffers: the handle's (MT in g->W, vectors in g->cand / g->outs / g->tmp, pinned staging).
+static int legacy_direct(ibo_gp *g, const LegacyModel &m, const double *invR_host, const double *lb, const double *ub,
+                         int maxiter, int maxtime, int maxsample, double *fmin, double *xmin)
+{
+    IBO_TRY(use_device(g->device));
+    const int N = m.nx, D = m.ndim;
+    if (N < 1 || D < 1 || !invR_host || !m.X || !m.Y || !m.hyper) return fail(IBO_ERR_ARG, "bad argument");
+    hipStream_t s = g->stream;
+    const size_t nn = (size_t)N * N;
+    IBO_TRY(g->A.ensure(nn)); IBO_TRY(g->W.ensure(nn)); IBO_TRY(g->Y.ensure(2 * (size_t)N));
+    HIP_TRY(hipMemcpyAsync(g->A.p, invR_host, sizeof(double) * nn, hipMemcpyHostToDevice, s));
+    KERNEL_TRY(launch_legacy_transpose(g->A.p, g->W.p, N, s));
+    double maxY = m.Y[0];
+    for (int i = 0; i < N; i++) if (m.Y[i] > maxY) maxY = m.Y[i];                       // cpp/optimizeGP.cpp:316-321
+    double *MbY = g->Y.p + N;                                                            // inv(R) Y in libego's order (no prior)
+    if (m.npbases <= 0) {
+        HIP_TRY(hipMemcpyAsync(g->Y.p, m.Y, sizeof(double) * N, hipMemcpyHostToDevice, s));
+        IBO_TRY(g->outs.ensure(1));
+        // (the matvec half of aMb; its dot half runs per point against that point's r)
+        KERNEL_TRY(launch_legacy_aMb(g->W.p, g->Y.p, g->Y.p, MbY, g->outs.p, N, 1, s));
+    }
+    std::vector<double> pmu;
+    ibo::batch_eval_t ev = [&](const double *pts, int n, double *vals) -> int {
+        // per point: r (and Y - m under a prior) from the host; vectors B = [r | ymu], A = [r | r]
+        const int nvec = m.npbases > 0 ? 2 * n : n;
+        const size_t vb = (size_t)nvec * N;
+        IBO_TRY(ensure_pinned(g, vb + 2 * (size_t)n));
+        IBO_TRY(g->cand.ensure(vb)); IBO_TRY(g->tmp.ensure(vb + (size_t)n * N)); IBO_TRY(g->outs.ensure(2 * (size_t)n + 1));
+        double *hB = g->pin, *hout = g->pin + vb;
+        pmu.assign(n, 0.0);
+        for (int p = 0; p < n; p++) {
+            const double *x = pts + (size_t)p * D;
+            legacy_kstar(m.kerneltype, D, N, m.X, m.hyper, m.sf2, x, hB + (size_t)p * N);
+            if (m.npbases > 0) {
+                pmu[p] = legacy_prior_mean(D, x, m.npbases, m.pmeans, m.pbeta, m.ptheta, m.plowerb, m.pwidth);
+                double *ymu = hB + (size_t)(n + p) * N;
+                for (int i = 0; i < N; i++) ymu[i] = m.Y[i] - pmu[p];
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(g->cand.p, hB, sizeof(double) * vb, hipMemcpyHostToDevice, s));
+        double *dB = g->cand.p, *dMb = g->tmp.p, *dout = g->outs.p + 1;
+        // x2 = aMb(r, invR, r) for every point; x1 = aMb(r, invR, ymu) under a prior, else the dot of r with the cached inv(R) Y
+        KERNEL_TRY(launch_legacy_aMb(g->W.p, dB, dB, dMb, dout + n, N, n, s));
+        if (m.npbases > 0) KERNEL_TRY(launch_legacy_aMb(g->W.p, dB + (size_t)n * N, dB, dMb + (size_t)n * N, dout, N, n, s));
+        else KERNEL_TRY(launch_legacy_dots(MbY, dB, dout, N, n, s));
+        HIP_TRY(hipMemcpyAsync(hout, dout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int p = 0; p < n; p++) vals[p] = legacy_neg_acq(m.acqfunc, pmu[p], hout[p], hout[n + p], m.noise, maxY, m.parm);
+        return 0;
+    };
+    ibo::DirectOptions o;
+    o.maxiter = maxiter; o.maxtime = maxtime; o.maxsample = maxsample; o.compat = true; o.per_rectangle = false;
+    ibo::DirectResult r = ibo::direct_minimize(ev, D, lb, ub, o);
+    if (r.status) return r.status;
+    *fmin = r.fmin;
+    for (int i = 0; i < D; i++) xmin[i] = r.xmin[i];
+    return IBO_OK;
+}
+
 // ------------------------------------------------------------------------ legacy libego symbols
 extern "C" const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR, double *X, double *Y, int nx,
                                   int acqfunc, int kerneltype, double *hyperparams, int npbases,
@@ -1761,7 +1842,26 @@ extern "C" const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR
     int nh = (kerneltype == IBO_K_SE_ARD) ? ndim : 1;
     if (kerneltype == IBO_K_MATERN5) sf2 = hyperparams[1] * hyperparams[1];
     double *res = nullptr;
-    int rc = fit_from_inverse(g, kerneltype, nx, ndim, X, Y, hyperparams, nh, sf2, noise, invR);
+    int rc;
+    if (g_legacy_exact) {
+        LegacyModel m;
+        m.ndim = ndim; m.nx = nx; m.acqfunc = acqfunc; m.kerneltype = kerneltype; m.X = X; m.Y = Y; m.hyper = hyperparams;
+        m.sf2 = kerneltype == IBO_K_MATERN5 ? exp(2.0 * log(hyperparams[1])) : 1.0;      // (cpp/optimizeGP.cpp:303-314)
+        m.npbases = npbases; m.pmeans = pbasismeans; m.pbeta = pbasisbeta; m.ptheta = pbasistheta; m.plowerb = pbasislowerb; m.pwidth = pbasiswidth;
+        m.parm = parm; m.noise = noise;
+        std::vector<double> xo(ndim);
+        double fmin = 0.0;
+        rc = legacy_direct(g, m, invR, lb, ub, maxiter, maxtime, maxsample, &fmin, xo.data());
+        if (rc == IBO_OK) {
+            res = (double *)malloc(sizeof(double) * (ndim + 1));
+            res[0] = fmin;
+            for (int i = 0; i < ndim; i++) res[i + 1] = xo[i];
+        }
+        if (rc != IBO_OK) fprintf(stderr, "[libibo_hip] acqmaxGP failed: %s\n", g_err);
+        ibo_gp_destroy(g);
+        return res;
+    }
+    rc = fit_from_inverse(g, kerneltype, nx, ndim, X, Y, hyperparams, nh, sf2, noise, invR);
     if (rc == IBO_OK && npbases > 0)
         rc = ibo_gp_set_prior(g, npbases, pbasismeans, pbasisbeta, pbasistheta, pbasislowerb, pbasiswidth);
     if (rc == IBO_OK) {

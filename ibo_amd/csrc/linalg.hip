@@ -11,6 +11,7 @@
 // (a multiple of 64) so that all tile kernels run without bounds checks; the
 // pad is the identity for matrices that get factored and zero for W.
 #include "ibo_common.h"
+#include <atomic>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -1255,13 +1256,13 @@ static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, i
 // factored by the same launches (blockIdx.z).  panel = 1 is the plain right-looking order (shortest chain:
 // one matrix, small N); panel = P > 1 keeps the per-column updates inside a P-block panel and applies the
 // panel to the rest of the matrix once, with K = 64 P (fewer passes over the trailing matrix: large N, batches).
-static int g_chol_panel = 0;                         // 0 = choose; ibo_set_option("chol_panel", P)
+static std::atomic<int> g_chol_panel{0};                         // 0 = choose; ibo_set_option("chol_panel", P)
 void set_chol_panel(int p) { g_chol_panel = p; }
-static int g_panel_rows = 3;                         // ibo_set_option("chol_panel_rows", 0/1/2): chol_panel_rows_kernel on four waves / chol_panel_rows8_kernel on eight / 3: chol_panel_rows8r_kernel, right-looking inside the workgroup, two workgroups per CU
+static std::atomic<int> g_panel_rows{3};                         // ibo_set_option("chol_panel_rows", 0/1/2): chol_panel_rows_kernel on four waves / chol_panel_rows8_kernel on eight / 3: chol_panel_rows8r_kernel, right-looking inside the workgroup, two workgroups per CU
 void set_chol_panel_rows(int v) { g_panel_rows = v; }
-static int g_update2 = 1;                            // ibo_set_option("chol_update2", 0/1): packed-panel trailing update (update2.hip)
+static std::atomic<int> g_update2{1};                            // ibo_set_option("chol_update2", 0/1): packed-panel trailing update (update2.hip)
 void set_chol_update2(int v) { g_update2 = v; }
-static int g_update2_min_tiles = 1024;               // ibo_set_option("update2_min_tiles"): 128 x 128 tiles (over the batch) from which the packed-panel kernel takes the update
+static std::atomic<int> g_update2_min_tiles{1024};               // ibo_set_option("update2_min_tiles"): 128 x 128 tiles (over the batch) from which the packed-panel kernel takes the update
 void set_chol_update2_min_tiles(int v) { g_update2_min_tiles = v; }
 
 // The panel's (64 P)^2 DIAGONAL block in one launch, one workgroup per matrix: for each of its P block columns the diagonal
@@ -1330,9 +1331,9 @@ void chol_panel_diag_kernel(double *L, int Npad, int p0, int P, double *__restri
     }
 }
 
-static int g_chol_tail = 20;                         // ibo_set_option("chol_tail", blocks): block columns of the left-looking order's right-looking tail (0: none)
+static std::atomic<int> g_chol_tail{20};                         // ibo_set_option("chol_tail", blocks): block columns of the left-looking order's right-looking tail (0: none)
 void set_chol_tail(int v) { g_chol_tail = v; }
-static int g_panel_diag = 1;                         // ibo_set_option("chol_panel_diag", 0/1): chol_panel_diag_kernel
+static std::atomic<int> g_panel_diag{1};                         // ibo_set_option("chol_panel_diag", 0/1): chol_panel_diag_kernel
 void set_chol_panel_diag(int v) { g_panel_diag = v; }
 
 // the block columns [p0, pend) of a panel whose columns are up to date: diagonal blocks, row blocks, K = 64 updates inside the panel
@@ -1379,7 +1380,7 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
     const int nb = Npad / 64;
     // the panel width fixes the order of the floating-point sums, so it may depend on the matrix size and
     // on the entry point but never on how many matrices share the launches
-    const int P = g_chol_panel > 0 ? g_chol_panel : panel;
+    const int P = g_chol_panel > 0 ? g_chol_panel.load() : panel;
     HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
     for (int p0 = 0; p0 < nb; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
@@ -1389,7 +1390,7 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
             const int nI2 = (Npad - 64 * pend + 127) / 128;
             // (a batch keeps the packed-panel kernel down to a quarter of the tiles one matrix needs: its late, small updates are many
             // short launches of the 64 x 64 kernel otherwise -- C5 0.626 -> 0.60 ms per theta)
-            if (ws && g_update2 && (size_t)nI2 * (nI2 + 1) / 2 * batch >= (size_t)(batch >= 8 ? g_update2_min_tiles / 4 : g_update2_min_tiles)) {
+            if (ws && g_update2 && (size_t)nI2 * (nI2 + 1) / 2 * batch >= (size_t)(batch >= 8 ? g_update2_min_tiles / 4 : g_update2_min_tiles.load())) {
                 int rc = launch_chol_update2(L, Npad, p0, pend, batch, lstride, ws, wstride, s);
                 if (rc) return rc;
             } else launch_update(L, Npad, p0, pend, pend, nb, batch, lstride, s);
@@ -1409,7 +1410,7 @@ int launch_cholesky_batched_left(double *L, int Npad, double *diag64, int *info_
                                  hipStream_t s, double *Pk, size_t pstride, int nlive, int nfactor, int rm_from)
 {
     const int nb = Npad / 64;
-    const int P = g_chol_panel > 0 ? g_chol_panel : panel;
+    const int P = g_chol_panel > 0 ? g_chol_panel.load() : panel;
     if (nfactor <= 0 || nfactor > nb) nfactor = nb;
     HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
     // THE TAIL.  Left-looking, the last panels have few tiles (17 .. 5 per matrix over the last 1024 columns) and a long K: the
@@ -1575,10 +1576,10 @@ void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npa
             for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL_TRI(n)] = acc[mm][n][r];
 }
 
-static int g_chol_pipe = 1;         // ibo_set_option("chol_pipe", 0/1)
+static std::atomic<int> g_chol_pipe{1};         // ibo_set_option("chol_pipe", 0/1)
 void set_chol_pipe(int v) { g_chol_pipe = v; }
 
-static int g_step_split = 256;      // ibo_set_option("step_split"): tiles of a block column from which rows and updates are separate launches
+static std::atomic<int> g_step_split{256};      // ibo_set_option("step_split"): tiles of a block column from which rows and updates are separate launches
 void set_step_split(int v) { g_step_split = v; }
 
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s, double *Ework,
@@ -1876,7 +1877,7 @@ void trinv_W_kernel(double *__restrict__ W, const double *__restrict__ T, int Np
             for (int q = 0; q < 4; q++) C[(size_t)TNN_ROW(m, q) * Npad + TNN_COL(n)] = -acc[m][n][q];
 }
 
-static int g_trinv_wide = 1;                          // ibo_set_option("trinv_wide", 0/1): eight-wave tiles where a level has at most 512 of them
+static std::atomic<int> g_trinv_wide{1};                          // ibo_set_option("trinv_wide", 0/1): eight-wave tiles where a level has at most 512 of them
 void set_trinv_wide(int v) { g_trinv_wide = v; }
 
 int launch_trinv(const double *L, int Npad, const double *diag64, double *W, double *T, hipStream_t s, bool zero_fill)

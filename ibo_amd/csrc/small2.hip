@@ -15,13 +15,14 @@
 // All sums run in a fixed order (no atomics): the result does not depend on scheduling.  Candidates are read from,
 // and results written to, wherever the caller's pointers lead -- abi.hip passes pinned host memory, so a batch costs
 // no copy launches.
+#include <atomic>
 #include "sweep2_dev.h"
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
-static int g_small_inline = 1;                       // ibo_set_option("small_inline", 0/1)
+static std::atomic<int> g_small_inline{1};                       // ibo_set_option("small_inline", 0/1)
 void set_small_inline(int v) { g_small_inline = v; }
 
 #ifdef IBO_STAMPS   // diagnostic build (tools/stamp_small.py): the GPU-side timeline of a small batch, 100 MHz s_memrealtime ticks
@@ -358,9 +359,9 @@ static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, in
     return (int)hipGetLastError();
 }
 
-static int g_small_split = 1;                        // ibo_set_option("small_split", 0/1): one 16-candidate block per product workgroup where the batch has <= 8 tiles
+static std::atomic<int> g_small_split{1};                        // ibo_set_option("small_split", 0/1): one 16-candidate block per product workgroup where the batch has <= 8 tiles
 void set_small_split(int v) { g_small_split = v; }
-static int g_small_local = 1;                        // ibo_set_option("small_local", 0/1): wkl_small_kernel (wave-local k*)
+static std::atomic<int> g_small_local{1};                        // ibo_set_option("small_local", 0/1): wkl_small_kernel (wave-local k*)
 void set_small_local(int v) { g_small_local = v; }
 
 template <int FAM>

@@ -20,6 +20,7 @@
 //     does a wave-level (max, lowest index) reduction -> one partial per tile.
 // Small batches (M <= 16) go through a row-parallel GEMV kernel instead.
 #include "ibo_common.h"
+#include <atomic>
 #include <type_traits>
 
 #define TC 64          // candidates per workgroup
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
     }
 }
 
-int g_sweep_variant = 4;     // 4 (default): sweep2_kernel (sweep2.hip) where the dot form is admissible and the alpha vectors fit its LDS;
+std::atomic<int> g_sweep_variant{4};     // 4 (default): sweep2_kernel (sweep2.hip) where the dot form is admissible and the alpha vectors fit its LDS;
                              // anything else: sweep_mfma_kernel<16,2,4,64> for every large batch  (ibo_set_option("sweep_variant"))
 
 template <int FAM, int NW, int RBW, int CBW, int KCH, bool DOT>

@@ -27,6 +27,7 @@
 // Used for batches > 8192 candidates when the dot form is admissible (ibo_gp.dot_form; otherwise, and
 // for the small-batch SPLIT / GEMV paths, sweep.hip's kernels run).
 #include "ibo_common.h"
+#include <atomic>
 #include <type_traits>
 #include <cfloat>
 
@@ -644,7 +645,7 @@ static int launch_s2_var(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     const int na128 = (a.Npad + 127) & ~127;
     const int dyn = (BIGN ? s2_awin(KA4) : na128) * 16;
-    static int granted[16];                          // per instantiation AND device (the attribute is per device): largest dynamic size already allowed
+    static std::atomic<int> granted[16];                          // per instantiation AND device (the attribute is per device): largest dynamic size already allowed
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dyn > granted[dev & 15]) {
@@ -665,7 +666,7 @@ template <int FAM, int KA4>
 static int launch_s2_rank1_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     const int dyn = ((a.Npad + 127) & ~127) * 24;
-    static int granted[16];
+    static std::atomic<int> granted[16];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dyn > granted[dev & 15]) {
@@ -714,7 +715,7 @@ template <int FAM, int KA4>
 static int launch_s2_part_one(const SweepArgs &a, int64_t ntiles, hipStream_t s)
 {
     const int dyn = a.part_means ? ((a.Npad + 127) & ~127) * 16 : 0;      // the alpha vectors, when this launch also forms the means
-    static int granted[16];
+    static std::atomic<int> granted[16];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dyn > granted[dev & 15]) {
@@ -769,7 +770,7 @@ static int launch_s2_bound(const SweepArgs &a0, hipStream_t s)
     return (int)hipGetLastError();
 }
 
-static int g_part_means = 1;                         // ibo_set_option("part_means", 0/1): the first part of a kept state forms the means itself
+static std::atomic<int> g_part_means{1};                         // ibo_set_option("part_means", 0/1): the first part of a kept state forms the means itself
 void set_part_means(int v) { g_part_means = v; }
 // the part kernel has no moving alpha window and the means come from the refresh kernel: both must fit
 bool sweep2_part_fits(int Npad, int D) { return Npad >= 512 && ((Npad + 127) & ~127) <= s2_awin((D + 2 + 3) / 4) && sweep2_rank1_fits(Npad, D); }

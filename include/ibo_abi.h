@@ -97,8 +97,14 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * wave-local k* kernel: never / up to 512 observations / always; up to 10 dimensions).  Kept-state sweeps: "gallery_prune" 0/1/2
  * (see ibo_acq_sweep_incremental).  Diagnostics: "small_trace" 1 / 2 (start / print the host-side split of the small batches' time).
  * Env IBO_SWEEP_IMPL=gemv|mfma too.
- * Threading: handles are independent, but the per-device workspaces behind ibo_nlml_grid / ibo_nlml_grad, the option switches
- * and the allocation pool are process-wide and unsynchronised beyond the pool's mutex: use one thread per device. */
+ * Threading (the reference's library keeps its whole model in process-wide statics, cpp/optimizeGP.cpp:36-55,240-259, and is not
+ * re-entrant; this one is): handles are independent of each other -- each has its own stream, events, staging and buffers --
+ * so several threads may drive several handles on one device at the same time (one handle belongs to one thread at a time);
+ * the buffer pool and the allocation table are mutexed; the per-device workspaces behind ibo_nlml_grid / ibo_nlml_grad, the
+ * sweep's exp table and ibo_trim are serialised by a per-device mutex (concurrent grids on one device take turns); the last
+ * error is thread-local.  The option switches are process-wide CONFIGURATION held in atomics: changing one while another
+ * thread computes is defined but takes effect at an unspecified call boundary -- set them before the threads start.
+ * (tests/test_gpu_gallery_oracle.py::test_two_threads_two_handles_one_device.) */
 int         ibo_set_option(const char *key, int value);
 
 /* ---------------------------------------------------------------- device memory */

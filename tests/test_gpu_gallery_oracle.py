@@ -275,47 +275,119 @@ def test_c5_all_sixty_four_thetas_in_one_batch(ibo, oracle):
 
 
 def test_legacy_acqmaxGP_reproduces_libego_where_conditioning_is_worst(ibo, oracle):
-    """The legacy symbol is handed the caller's inv(R) (ego/acquisition/__init__.py:385-388), so it contracts with the same
-    matrix libego does (cpp/optimizeGP.cpp:141-170): on the clustered noise-1e-4 data where libego's explicit inverse is
-    itself 3e-6 .. 6e-6 off the truth, same invR in -> same numbers out, at 1e-6, against the reference's OWN
-    compiled library (oracle/_ref/libego.so): per-point values (every dimension fixed, maxiter 0: one objective evaluation,
-    cpp/direct.cpp:116-117,355) and a DIRECT run."""
+    """The legacy symbol is handed the caller's inv(R) (ego/acquisition/__init__.py:385-388) and contracts with it as libego
+    does (cpp/optimizeGP.cpp:141-190).  On clustered noise-1e-4 data inv(R)'s entries reach 1e4 and cancel to O(1): the value
+    carries ~1e-9 of rounding noise against a variance of 1e-4, and any OTHER evaluation order lands 1e-5 .. 3e-2 away
+    (tools/legacy_probe.py measured round 3's Cholesky-of-inv(R) route at that).  csrc/legacy.hip therefore evaluates in
+    libego's operation order -- k* and the acquisition with the host's libm, the N^2 contractions on the device with
+    sequential, separately rounded sums -- and the test asks for what that buys: libego's numbers BIT FOR BIT, per point
+    (every dimension fixed, maxiter 0: one objective evaluation, cpp/direct.cpp:116-117,355) and over DIRECT runs, against the
+    reference's own compiled library (oracle/_ref/libego.so).  SE-ARD, SE-iso, Matern-3/2, with and without a mean prior;
+    Matern-5/2 is left out: the compiled reference reads its magnitude out of bounds there.  The fast route
+    (legacy_exact = 0) is held to the 1e-6 bar where the data are benign (noise 0.1)."""
     from ibo_amd import _lib
     if not oracle.RefLib.available():
         pytest.skip("oracle/_ref/libego.so not present on this box")
     ref = oracle.RefLib()
-    DP = ctypes.POINTER(ctypes.c_double)
     libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
     f64, dp = _lib.f64, _lib.dp
-    N, D, noise = 1000, 2, 1e-4
-    worst = 0.0
-    for kind, hyp in (("ard", [.3, .3]), ("m5", [.5, 1.0])):
-        rs = np.random.RandomState(77)
-        c = rs.rand(3, D)
-        X = np.clip(np.vstack([c[i] + 0.02 * rs.randn(N // 4, D) for i in range(3)] + [rs.rand(N - 3 * (N // 4), D)]), 0, 1)
-        Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
-        ogp = oracle.GP(oracle.Kern(kind, hyp), X, Y, noise=noise)
-        invR = f64(np.linalg.inv(ogp.R))
-        Xc, Yc, hy = f64(X), f64(Y), f64(ogp.kern.c_hyper)
-        z = np.zeros(1)
+    N, D = 1000, 2
+    rs = np.random.RandomState(77)
+    c = rs.rand(3, D)
+    X = np.clip(np.vstack([c[i] + 0.02 * rs.randn(N // 4, D) for i in range(3)] + [rs.rand(N - 3 * (N // 4), D)]), 0, 1)
+    Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
+    prior = oracle.Prior(rs.rand(5, D), rs.randn(5) * .3, 2.0, np.zeros(D), np.ones(D))
 
-        def ours(lb, ub, acq, parm, maxiter):
-            lb, ub = f64(lb), f64(ub)
-            r = _lib.lib.acqmaxGP(D, dp(lb), dp(ub), dp(invR), dp(Xc), dp(Yc), N, acq, int(ogp.kern.ktype), dp(hy), 0, dp(z), dp(z), 0.0,
-                                  dp(z), dp(z), float(parm), float(noise), maxiter, 30, 10000)
-            assert bool(r)
-            res = np.array([r[i] for i in range(D + 1)])
-            libc.free(r)
-            return -res[0], res[1:]
-        probes = np.vstack([rs.rand(6, D), np.clip(X[rs.randint(0, N, 6)] + 1e-3 * rs.randn(6, D), 0, 1)])
-        for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_UCB, 1.3)):
+    def ours(ogp, invR, lb, ub, acq, parm, maxiter):
+        lb, ub = f64(lb), f64(ub)
+        Xc, Yc, hy = f64(ogp.X), f64(ogp.Y), f64(ogp.kern.c_hyper)
+        pa = oracle._prior_cargs(ogp.prior)
+        r = _lib.lib.acqmaxGP(D, dp(lb), dp(ub), dp(invR), dp(Xc), dp(Yc), len(Yc), acq, int(ogp.kern.ktype), dp(hy), *pa,
+                              float(parm), float(ogp.noise), maxiter, 30, 10000)
+        assert bool(r)
+        res = np.array([r[i] for i in range(D + 1)])
+        libc.free(r)
+        return -res[0], res[1:]
+    n_bits = 0
+    for kind, hyp, pr, noise in (("ard", [.3, .3], None, 1e-4), ("iso", [.3], None, 1e-4), ("m3", [.5, 1.0], None, 1e-4),
+                                 ("ard", [.3, .25], prior, 1e-4), ("ard", [.3, .3], None, .1)):
+        ogp = oracle.GP(oracle.Kern(kind, hyp), X, Y, noise=noise, prior=pr)
+        invR = f64(np.linalg.inv(ogp.R))
+        probes = np.vstack([rs.rand(5, D), np.clip(X[rs.randint(0, N, 5)] + 1e-3 * rs.randn(5, D), 0, 1)])
+        for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_PI, .05), (oracle.ACQ_UCB, 1.3)):
             for x in probes:
-                a, _ = ours(x, x, acq, parm, 0)
+                a, _ = ours(ogp, invR, x, x, acq, parm, 0)
                 b, _ = ref.acqmax(ogp, [[v, v] for v in x], acq, parm, maxiter=0, invR=invR)
-                if abs(b) > ACQ_ATOL:
-                    worst = max(worst, abs(a - b) / abs(b))
-                close(a, b, atol=ACQ_ATOL)
-            a, ax = ours([0.] * D, [1.] * D, acq, parm, 10)
+                assert a == b, (kind, acq, x, a, b)
+                n_bits += 1
+            a, ax = ours(ogp, invR, [0.] * D, [1.] * D, acq, parm, 10)
+            b, bx = ref.acqmax(ogp, [[0., 1.]] * D, acq, parm, maxiter=10, invR=invR)
+            assert a == b and np.array_equal(ax, bx), (kind, acq, a, b, ax, bx)
+    print("legacy acqmaxGP == libego bit for bit: %d point evaluations, 15 DIRECT runs" % n_bits)
+    # the fast route: Cholesky of inv(R) + the MFMA sweep kernels; within the bar of libego where conditioning is benign
+    _lib.check(_lib.lib.ibo_set_option(b"legacy_exact", 0))
+    try:
+        ogp = oracle.GP(oracle.Kern("ard", [.3, .3]), X, Y, noise=.1)
+        invR = f64(np.linalg.inv(ogp.R))
+        for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_UCB, 1.3)):
+            a, ax = ours(ogp, invR, [0.] * D, [1.] * D, acq, parm, 10)
             b, bx = ref.acqmax(ogp, [[0., 1.]] * D, acq, parm, maxiter=10, invR=invR)
             close(a, b, atol=ACQ_ATOL); close(ax, bx, rtol=1e-9, atol=1e-12)
-    print("legacy acqmaxGP vs libego on clustered noise-1e-4 data: worst relative difference %.2e" % worst)
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"legacy_exact", 1))
+
+
+def test_two_threads_two_handles_one_device(ibo):
+    """The ABI's re-entrancy claim (include/ibo_abi.h, ibo_set_option's note; the reference keeps its model in process-wide
+    statics, cpp/optimizeGP.cpp:36-55): two Python threads on device 0 -- ctypes releases the GIL for the duration of every
+    library call -- one looping a candidate sweep and a DIRECT maximisation on its own handle, the other looping fit +
+    posterior + ibo_nlml_grid (+ gradient) on its own data.  Every iteration's results equal the serial run's, bit for bit."""
+    import threading
+    from ibo_amd import DeviceArray
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard, MaternKernel5
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid, marginalLikelihood
+    from ibo_amd.acquisition import sweep, maximizeEI
+    XA, YA = synth(601, 1024, 4)
+    candA = DeviceArray.from_host(np.random.RandomState(602).rand(60000, 4))
+    XB, YB = synth(603, 700, 3)
+    probeB = np.random.RandomState(604).rand(200, 3)
+    thB = np.exp(np.random.RandomState(605).uniform(np.log(.3), np.log(2), size=(12, 3)))
+
+    def work_a(GP):
+        r = sweep(GP, candA, acq='ei', xi=.01, native=True)
+        o, ox = maximizeEI(GP, [[0., 1.]] * 4, maxiter=8)
+        return (r["best_val"], r["best_idx"], o, tuple(ox))
+
+    def work_b(i):
+        GP = GaussianProcess(MaternKernel5([.5, 1.0]), XB[:600 + 10 * (i % 5)], YB[:600 + 10 * (i % 5)], noise=.05)
+        mu, s2 = GP.posteriors(probeB)
+        vals = nlml_grid(GaussianKernel_ard, thB, XB, YB, noise=1e-3)[0]
+        v, g = marginalLikelihood(GaussianKernel_ard(thB[i % 12]), XB, YB, 3, True, noise=1e-3)
+        return (mu.tobytes(), s2.tobytes(), vals.tobytes(), float(v), np.asarray(g).tobytes())
+    GPA = GaussianProcess(GaussianKernel_ard([.3] * 4), XA, YA, noise=.1)
+    iters = 12
+    serial_a = [work_a(GPA) for _ in range(2)]
+    assert serial_a[0] == serial_a[1]
+    serial_b = [work_b(i) for i in range(iters)]
+    got_a, got_b, errs = [], [], []
+
+    def thread_a():
+        try:
+            for _ in range(3 * iters):
+                got_a.append(work_a(GPA))
+        except Exception as e:                           # surfaced below: an exception in a thread must fail the test
+            errs.append(("a", repr(e)))
+
+    def thread_b():
+        try:
+            for i in range(iters):
+                got_b.append(work_b(i))
+        except Exception as e:
+            errs.append(("b", repr(e)))
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start(); ta.join(600); tb.join(600)
+    assert not errs, errs
+    assert len(got_a) == 3 * iters and len(got_b) == iters
+    assert all(x == serial_a[0] for x in got_a)
+    assert got_b == serial_b

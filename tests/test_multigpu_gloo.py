@@ -188,3 +188,49 @@ def test_sharded_nlml_grid_gather_two_ranks_gloo():
     for r in range(world):
         np.testing.assert_array_equal(np.array(res[r][0]), ref)
         assert res[r][1] == int(np.nanargmin(ref))
+
+
+def test_socket_transport_three_ranks_in_threads():
+    """ibo_amd.multigpu.SocketComm (the transport of tests/test_gpu_two_ranks.py): sum in rank order, the slot protocol's
+    tie rule (lowest global index), a rank with nothing admissible, indices beyond 2^32 -- three ranks as three threads"""
+    import tempfile
+    import threading
+    from ibo_amd.multigpu import SocketComm
+    world = 3
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        addr = os.path.join(d, "sock")
+
+        def run(rank):
+            c = SocketComm(world, rank, addr, timeout_s=60)
+            out = [c.allreduce_sum([rank + 1.0, 0.25, -rank])]
+            out.append(c.argmax(2.0, (1 << 33) + 10 - rank, [float(rank), 7.0]))                 # a three-way tie: the lowest index wins
+            out.append(c.argmax(float('nan') if rank == 2 else -1.0 - rank, -1 if rank == 2 else rank, [0.0]))
+            out.append(c.argmax(0.0, -1, []))                                                     # nobody has anything
+            c.barrier()
+            assert c.nranks() == world
+            c.close()
+            res[rank] = out
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not os.path.exists(addr)                    # rank 0 removed its socket
+    assert sorted(res) == [0, 1, 2]
+    for r in range(world):
+        np.testing.assert_array_equal(res[r][0], [6.0, 0.75, -3.0])
+        v, i, p, who = res[r][1]
+        assert (v, i, who) == (2.0, (1 << 33) + 8, 2) and list(p) == [2.0, 7.0]
+        v, i, p, who = res[r][2]
+        assert (v, i, who) == (-1.0, 0, 0)
+        assert res[r][3][1] == -1 and res[r][3][3] == -1
+
+
+def test_rank_launcher_starts_ranks_and_reports_failures(launch_ranks):
+    """tests/rank_launcher.py (the GPU-clean parent of the GPU tests' rank processes): RANK / WORLD_SIZE per child, outputs
+    back, and a failing rank takes the launch down instead of hanging it"""
+    ok = launch_ranks(["-c", "import os; print(os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'])"], 3, timeout=60)
+    assert ok["rc"] == [0, 0, 0] and [o.split() for o in ok["out"]] == [[str(r), "3", str(r)] for r in range(3)]
+    bad = launch_ranks(["-c", "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(600)\n"], 2, timeout=60)
+    assert bad["rc"][1] == 3 and bad["rc"][0] not in (0, None) and bad["seconds"] < 30

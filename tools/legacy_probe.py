@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """legacy acqmaxGP (invR handed in) against the reference's compiled libego on clustered, badly conditioned data:
-per-point differences over many probes, and where a DIRECT run forks.   python3 tools/legacy_probe.py [noise]"""
+per-point differences over many probes, and where a DIRECT run forks.   python3 tools/legacy_probe.py [noise] [legacy_exact 1|0]"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,10 @@ ref = oracle.RefLib()
 libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
 f64, dp = _lib.f64, _lib.dp
 N, D = 1000, 2
-for kind, hyp in (("ard", [.3, .3]), ("m5", [.5, 1.0])):
+exact = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_lib.check(_lib.lib.ibo_set_option(b"legacy_exact", exact))
+print("legacy_exact = %d" % exact)
+for kind, hyp in (("ard", [.3, .3]), ("m3", [.5, 1.0])):
     rs = np.random.RandomState(77)
     c = rs.rand(3, D)
     X = np.clip(np.vstack([c[i] + 0.02 * rs.randn(N // 4, D) for i in range(3)] + [rs.rand(N - 3 * (N // 4), D)]), 0, 1)
