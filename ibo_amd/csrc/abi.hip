@@ -308,6 +308,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "update2_min_tiles")) { set_chol_update2_min_tiles(value); return IBO_OK; }
     if (key && !strcmp(key, "trinv_wide")) { set_trinv_wide(value); return IBO_OK; }
     if (key && !strcmp(key, "step_split")) { set_step_split(value); return IBO_OK; }
+    if (key && !strcmp(key, "step_waves")) { set_step_waves(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_pipe")) { set_chol_pipe(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_diag")) { set_chol_panel_diag(value); return IBO_OK; }

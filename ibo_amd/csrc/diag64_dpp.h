@@ -163,7 +163,7 @@ __device__ __forceinline__ void diag64_update_tile(double *S, int o, int it, int
 
 // S: the 64x64 block (row stride SD), V: zeros, T: a 16x16 identity in its first 16 rows (diag64_load leaves them
 // so).  On return S holds the factor (lower triangle; the strict upper
-// part of the off-diagonal 16-blocks is scratch), V its inverse.  T is scratch.  Called by all 256 threads; ends
+// part of the off-diagonal 16-blocks is scratch), V its inverse.  T is scratch.  Called by all threads of the workgroup (waves 0..3 work); ends
 // with a barrier.  With 16-blocks L_ij of the factor and V_i = L_ii^-1:
 //   [L11 0; L21 L22]^-1 = [V11 0; -V22 L21 V11, V22]   at the 32- and at the 64-level.
 __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info)
@@ -174,6 +174,8 @@ __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, doubl
         if (wv == 0) {
             diag64_panel(S, V, T, o, pivot0, info);
             CSTAMP(2 + 5 * b);
+        } else if (wv > 3) {
+            // (an eight-wave workgroup -- chol_step8_kernel: waves 4..7 only keep the barriers' count)
         } else if (b == 1) {
             // the tiles of panel 0's update that panel 1 does not read: (1,1), (2,1), (2,2)
             diag64_update_tile(S, 0, wv == 1 ? 1 : 2, wv == 3 ? 2 : 1);

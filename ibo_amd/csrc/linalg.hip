@@ -692,6 +692,182 @@ void chol_step_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npa
     }
 }
 
+// ---- the same step on EIGHT waves (round 4).  The chain is one wave's work whatever the workgroup's size, but the three
+// products after it are MFMA-issue bound on four waves -- one wave per SIMD issues an fp64 MFMA every ~100-139 cycles where
+// the pipe takes one per 64 (tools/mfma_f64_peak) -- so with two waves per SIMD the X_i / X_k products and the update take
+// ~4.5 k + 3 k cycles instead of 8.0 k + 5.3 k of a 42 k-cycle step.  Wave w owns the 16 x 32 strip (row block w >> 1,
+// column half w & 1) of every product: each output element is the same chain of MFMAs over ascending k as in the four-wave
+// kernel -- identical bits (test_split_steps_equal_fused_steps runs both).  Only the HAVE_V = false form (the step that
+// carries the chain); tiles that overflow a launch keep the four-wave kernel.
+#define S8_ROW(r) (wr8 * 16 + (lane >> 4) + 4 * (r))
+#define S8_COL(n) (wc8 * 32 + (n) * 16 + (lane & 15))
+#define S8_CB(n) (wc8 ? ((n) ? 2 : 1) : ((n) ? 3 : 0))
+#define S8_COL_TRI(n) (S8_CB(n) * 16 + (lane & 15))
+__device__ __forceinline__ void s8_fetch(const double *__restrict__ A, int lda, d2_t (&v)[4])
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = *(const d2_t *)(A + (size_t)(16 * u + (t >> 5)) * lda + (t & 31) * 2);
+}
+__device__ __forceinline__ void s8_stash(double *As, const d2_t (&v)[4])
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        double *dst = As + (16 * u + (t >> 5)) * SD + (t & 31) * 2;
+        dst[0] = v[u].x; dst[1] = v[u].y;
+    }
+}
+// acc[n] += A(strip wr8) B^T(column block 32 wc8 + 16 n), K = 64, k ascending
+__device__ __forceinline__ void s8_mma_nt(const double *As, const double *Bs, d4_t (&acc)[2], int wr8, int wc8, int lane)
+{
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4++) {
+        const double a = As[(wr8 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+        double b[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++) b[n] = Bs[(wc8 * 32 + n * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[n] = mfma_f64(a, b[n], acc[n]);
+    }
+}
+// two products with the same lower-triangular B (tile64_mma_nt_tri2's arithmetic): column block cb needs k < 16 (cb + 1)
+template <int CB0, int CB1>
+__device__ __forceinline__ void s8_mma_nt_tri2_body(const double *As1, const double *As2, const double *Bs, d4_t (&acc1)[2], d4_t (&acc2)[2],
+                                                    int wr8, int lane)
+{
+    double a1[4 * (CB1 + 1)], a2[4 * (CB1 + 1)], b0[4 * (CB0 + 1)], b1[4 * (CB1 + 1)];
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+        a1[k4] = As1[(wr8 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+        a2[k4] = As2[(wr8 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+        if (k4 < 4 * (CB0 + 1)) b0[k4] = Bs[(CB0 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+        b1[k4] = Bs[(CB1 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 4 * (CB1 + 1); k4++) {
+        if (k4 < 4 * (CB0 + 1)) { acc1[0] = mfma_f64(a1[k4], b0[k4], acc1[0]); acc2[0] = mfma_f64(a2[k4], b0[k4], acc2[0]); }
+        acc1[1] = mfma_f64(a1[k4], b1[k4], acc1[1]); acc2[1] = mfma_f64(a2[k4], b1[k4], acc2[1]);
+    }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void chol_step8_kernel(double *__restrict__ L, double *__restrict__ Lout, int Npad, int jb,
+                       double *__restrict__ diag64, int *info, int nchol, double *__restrict__ Ework,
+                       double *__restrict__ Eout, int ntiles)
+{
+    __shared__ double S[64 * SD];
+    __shared__ double V[64 * SD];
+    __shared__ double T[64 * SD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr8 = wv >> 1, wc8 = wv & 1;
+    const int nb = Npad / 64, m = nb - jb - 1;
+    struct Tile { int k; const double *Ai, *Ak; double *Xi, *C; };
+    auto decode = [&](int t) {
+        Tile q;
+        int i;
+        if (t < nchol) {
+            q.k = jb + 1;
+            int rem = t;
+            while (rem >= nb - q.k) { rem -= nb - q.k; q.k++; }
+            i = q.k + rem;
+            q.Ai = L + (size_t)i * 64 * Npad + jb * 64;
+            q.Xi = Lout + (size_t)i * 64 * Npad + jb * 64;
+            q.C = L + (size_t)i * 64 * Npad + q.k * 64;
+        } else {
+            const int e = t - nchol;
+            i = e / m; q.k = jb + 1 + e % m;
+            q.Ai = Ework + (size_t)i * 64 * Npad + jb * 64;
+            q.Xi = Eout + (size_t)i * 64 * Npad + jb * 64;
+            q.C = Ework + (size_t)i * 64 * Npad + q.k * 64;
+        }
+        q.Ak = L + (size_t)q.k * 64 * Npad + jb * 64;
+        return q;
+    };
+    auto fetch = [&](const Tile &q, d2_t (&va)[4], d2_t (&vb)[4], d4_t (&c)[2]) {
+        s8_fetch(q.Ai, Npad, va);
+        s8_fetch(q.Ak, Npad, vb);
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) c[n][r] = q.C[(size_t)S8_ROW(r) * Npad + S8_COL(n)];
+    };
+    const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
+    int t = blockIdx.x;
+    Tile cur = decode(t);
+    // the diagonal block first (the chain starts when it is back), then this tile's operands
+    double vd[8];
+    {
+        const int tt = threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 8; u++) vd[u] = L[doff + (size_t)(8 * u + (tt >> 6)) * Npad + (tt & 63)];
+    }
+    d2_t va[4], vb[4];
+    d4_t c[2];
+    fetch(cur, va, vb, c);
+    {
+        const int tt = threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            S[(8 * u + (tt >> 6)) * SD + (tt & 63)] = vd[u];
+            V[(8 * u + (tt >> 6)) * SD + (tt & 63)] = 0.0;
+        }
+        if (tt < 256) T[(tt >> 4) * SD + (tt & 15)] = ((tt >> 4) == (tt & 15)) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    diag64_factor_invert(S, V, T, jb * 64, blockIdx.x == 0 ? info : nullptr);
+    if (blockIdx.x == 0) {
+        const int tt = threadIdx.x;
+        double *Lb = Lout + doff, *Db = diag64 + (size_t)jb * 4096;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int r = 8 * u + (tt >> 6), cc = tt & 63;
+            Lb[(size_t)r * Npad + cc] = (cc <= r) ? S[r * SD + cc] : 0.0;
+            Db[r * 64 + cc] = V[r * SD + cc];
+        }
+    }
+    for (;;) {
+        __syncthreads();                                   // S (and T) are about to be reused
+        s8_stash(S, va);
+        s8_stash(T, vb);
+        const int tn = t + gridDim.x;
+        const bool more = tn < ntiles;
+        Tile nxt = cur;
+        d4_t cn[2];
+        if (more) {
+            nxt = decode(tn);
+            fetch(nxt, va, vb, cn);
+        }
+        __syncthreads();
+        d4_t xi[2] = {}, xk[2] = {};
+        if (wc8) s8_mma_nt_tri2_body<1, 2>(S, T, V, xi, xk, wr8, lane);
+        else s8_mma_nt_tri2_body<0, 3>(S, T, V, xi, xk, wr8, lane);
+        __syncthreads();
+        if (cur.k == jb + 1) {                             // first trailing column: this row block of L is final
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) cur.Xi[(size_t)S8_ROW(r) * Npad + S8_COL_TRI(n)] = xi[n][r];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                S[S8_ROW(r) * SD + S8_COL_TRI(n)] = -xi[n][r];
+                T[S8_ROW(r) * SD + S8_COL_TRI(n)] = xk[n][r];
+            }
+        __syncthreads();
+        s8_mma_nt(S, T, c, wr8, wc8, lane);
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) cur.C[(size_t)S8_ROW(r) * Npad + S8_COL(n)] = c[n][r];
+        if (!more) break;
+        t = tn; cur = nxt;
+#pragma unroll
+        for (int n = 0; n < 2; n++) c[n] = cn[n];
+    }
+}
+
 // Diagonal block + row blocks of one block column in ONE launch: every row block's workgroup repeats the diagonal
 // factorisation -- as chol_step_kernel does -- and multiplies its block by inv(L_jj)^T; workgroup 0 also stores the diagonal
 // block and its inverse.  chol_diag_kernel + chol_trsm_kernel, same arithmetic.  Workgroups [0, m) take the matrix's row
@@ -1579,6 +1755,8 @@ void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npa
 static std::atomic<int> g_chol_pipe{1};         // ibo_set_option("chol_pipe", 0/1)
 void set_chol_pipe(int v) { g_chol_pipe = v; }
 
+static std::atomic<int> g_step_waves{8};        // ibo_set_option("step_waves", 4/8): fused steps on four or eight waves (same bits)
+void set_step_waves(int v) { g_step_waves = v; }
 static std::atomic<int> g_step_split{256};      // ibo_set_option("step_split"): tiles of a block column from which rows and updates are separate launches
 void set_step_split(int v) { g_step_split = v; }
 
@@ -1616,8 +1794,12 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
             // workgroup costs nothing and two launches disappear; extra tiles come along
             ridden = nextra < MAXT - nchol ? nextra : MAXT - nchol;
             const int nt = nchol + ridden;
-            hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < CU ? nt : CU), dim3(256), 0, s, work, out, Npad, jb, diag64,
-                               info_dev, nchol, 0, Ework, Eout, nt);
+            if (g_step_waves == 8)
+                hipLaunchKernelGGL(chol_step8_kernel, dim3(nt < CU ? nt : CU), dim3(512), 0, s, work, out, Npad, jb, diag64,
+                                   info_dev, nchol, Ework, Eout, nt);
+            else
+                hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < CU ? nt : CU), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                                   info_dev, nchol, 0, Ework, Eout, nt);
         } else if (m == 0 && Ework) {
             // last block column with the ride-along: nothing trails it, E's row blocks only need the multiplication by inv(L_jj)^T
             hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, 0, Ework, Eout);
@@ -1660,8 +1842,12 @@ int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, 
             int nt = 0;
             for (int k = jb + 1; k < pend; k++) nt += nb - k;
             if (nt > 0 && nt <= g_step_split) {
-                hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, work, out, Npad, jb, diag64,
-                                   info_dev, nt, 0, (double *)nullptr, (double *)nullptr, nt);
+                if (g_step_waves == 8)
+                    hipLaunchKernelGGL(chol_step8_kernel, dim3(nt < 256 ? nt : 256), dim3(512), 0, s, work, out, Npad, jb, diag64,
+                                       info_dev, nt, (double *)nullptr, (double *)nullptr, nt);
+                else
+                    hipLaunchKernelGGL(chol_step_kernel<false>, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, work, out, Npad, jb, diag64,
+                                       info_dev, nt, 0, (double *)nullptr, (double *)nullptr, nt);
             } else if (nt > 0) {           // more in-panel tiles than CUs (beyond 5400 rows): row blocks first, then the updates
                 hipLaunchKernelGGL(chol_diag_trsm_kernel, dim3(nb - jb - 1), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nb - jb - 1,
                                    (const double *)nullptr, (double *)nullptr);
