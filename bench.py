@@ -599,22 +599,36 @@ def worker(args):
                 # the second half only for the 32-candidate tiles whose EI bound reaches the best complete value (what the gallery's
                 # first round does); the winner is the full sweep's.
                 import ctypes as _ct
-                am = []
-                for _ in range(4):
-                    ca = DeviceArray.from_host(cand_host, local_rank)        # a new array: no kept state
-                    _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
-                    t0 = time.perf_counter()
-                    ra = sweep(GP, ca, acq='ei', xi=.01, native=True, index_base=start, incremental=True)
-                    am.append((time.perf_counter() - t0) * 1e3)
-                    tl, dn = _ct.c_int64(), _ct.c_int64()
-                    _lib.check(_lib.lib.ibo_sweep_state_info(GP._handle(), _ct.byref(tl), _ct.byref(dn)))
-                    del ca
-                cfgs["argmax_only"] = {"workload": "C2 shape, arg-max of EI only: kept-state sweep in two parts of W's rows (first call on a new array)",
-                                       "ms": float(np.median(am[1:])), "full_sweep_ms": elapsed / args.steps * 1e3,
-                                       "tiles": int(tl.value), "tiles_with_second_part": int(dn.value),
-                                       "second_part_skipped_frac": 1.0 - dn.value / max(1, tl.value),
-                                       "same_index_as_full_sweep": bool(ra["best_idx"] == outs[-1][1]),
-                                       "value_rel_diff_to_full_sweep": float(abs(ra["best_val"] - outs[-1][0]) / abs(outs[-1][0]))}
+
+                def argmax_only(GPm, cand_np, full_ms, full_best, what, **kw):
+                    am = []
+                    for _ in range(4):
+                        ca = DeviceArray.from_host(cand_np, local_rank)        # a new array: no kept state
+                        _lib.check(_lib.lib.ibo_device_synchronize(local_rank))
+                        t0 = time.perf_counter()
+                        ra = sweep(GPm, ca, incremental=True, **kw)
+                        am.append((time.perf_counter() - t0) * 1e3)
+                        nl = _ct.c_int(); sp = (_ct.c_int * 3)(); cnt = (_ct.c_int64 * 4)()
+                        _lib.check(_lib.lib.ibo_sweep_state_levels(GPm._handle(), _ct.byref(nl), sp, cnt))
+                        del ca
+                    ms = float(np.median(am[1:]))
+                    tiles = int(sum(list(cnt)[:nl.value]))
+                    return {"workload": what, "ms": ms, "candidates_per_s": len(cand_np) / ms * 1e3, "full_sweep_ms": full_ms,
+                            "levels": int(nl.value), "level_starts_at_row": [0] + list(sp)[:nl.value - 1],
+                            "tiles": tiles, "tiles_standing_at_each_level": list(cnt)[:nl.value],
+                            "tiles_complete": int(cnt[nl.value - 1]), "last_level_skipped_frac": 1.0 - cnt[nl.value - 1] / max(1, tiles),
+                            "same_index_as_full_sweep": bool(ra["best_idx"] == full_best[1]),
+                            "value_rel_diff_to_full_sweep": float(abs(ra["best_val"] - full_best[0]) / abs(full_best[0]))}
+                cfgs["argmax_only"] = argmax_only(GP, cand_host, elapsed / args.steps * 1e3, outs[-1],
+                                                  "C2 shape, arg-max of EI only: kept-state sweep in levels of W's rows (first call on a new array)",
+                                                  acq='ei', xi=.01, native=True, index_base=start)
+                # the north-star shape (N = 2048, D = 8, Matern-5/2) on one GPU: 2^19 candidates
+                GPn, candn, hostn, startn = c3_setup(C3_SHARD)
+                fulln = sweep(GPn, candn, acq='ei', xi=.3, native=True)
+                cfgs["argmax_only_c3"] = argmax_only(GPn, hostn, float(fulln["kernel_ms"]), (fulln["best_val"], fulln["best_idx"]),
+                                                     "N=2048, D=8, Matern-5/2, arg-max of EI only over 2^19 candidates (first call on a new array)",
+                                                     acq='ei', xi=.3, native=True)
+                del GPn, candn
             if rank == 0:
                 out["configs"] = cfgs
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

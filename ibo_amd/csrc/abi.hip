@@ -247,7 +247,7 @@ struct ibo_gp {
     // kept sweep state (ibo_acq_sweep_incremental): (q, aY.k*, a1.k*) per candidate of ONE device candidate array
     DevBuf<double> state;
     DevBuf<int> tile_done; DevBuf<double> tile_ub; DevBuf<unsigned long long> part_words; DevBuf<int> tile_rows, tile_sel;   // kept state with incomplete tiles (st_pruned)
-    bool st_pruned = false; int st_N0 = 0;          // st_N0: the model's rows when the state was formed
+    bool st_pruned = false; int st_N0 = 0; int st_nlev = 2;   // st_N0: the model's rows when the state was formed; st_nlev: its levels of W's rows
     DevBuf<double> small_ws;        // small2.hip: k* in fragment order + partial sums of a small batch
     uint64_t st_gen = 0; size_t st_off = 0; int64_t st_M = 0; int st_N = 0; double st_sf2 = 0.0; unsigned st_epoch = 0;   // st_gen: generation of the candidate array's allocation (0: no state)
     unsigned fit_epoch = 0;         // bumped by every full fit: a kept state never survives one
@@ -322,6 +322,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "small_split")) { set_small_split(value); return IBO_OK; }
     if (key && !strcmp(key, "gallery_prune")) { g_gallery_prune = value; return IBO_OK; }
     if (key && !strcmp(key, "part_means")) { set_part_means(value); return IBO_OK; }
+    if (key && !strcmp(key, "part_levels")) { set_part_levels(value); return IBO_OK; }
     if (key && !strcmp(key, "gallery_lazy")) { g_gallery_lazy = value; return IBO_OK; }
     if (key && !strcmp(key, "legacy_exact")) { g_legacy_exact = value; return IBO_OK; }
     if (key && !strcmp(key, "small_trace")) {
@@ -1233,7 +1234,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
                 // candidate's own numbers (outputs, PI, the plain mean), the A/B switch, or a mean prior (whose second vector W 1
                 // moves the means of stale tiles by more than any margin allows) has every tile refreshed and completed instead
                 a.tile_done = g->tile_done.p; a.tile_ub = g->tile_ub.p; a.part_best = g->part_words.p; a.part_thresh = g->part_words.p + 1;
-                a.tile_rows = g->tile_rows.p; a.tile_sel = g->tile_sel.p;
+                a.tile_rows = g->tile_rows.p; a.tile_sel = g->tile_sel.p; a.part_nlev = g->st_nlev;
                 a.part_lazy = monotone && g_gallery_prune == 1 && g_gallery_lazy && g->nb == 0 && nu_bounded;
             }
             if (usable) {
@@ -1241,12 +1242,13 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
                 g->sweep_kernel = g->N > g->st_N ? "sweep2_rank1_kernel" : "acq_finish_kernel";
             } else if (g_gallery_prune && monotone && sweep2_part_fits(a.Npad, a.kp.D)) {
                 IBO_TRY(g->tile_done.ensure((size_t)nt32)); IBO_TRY(g->tile_ub.ensure((size_t)nt32)); IBO_TRY(g->part_words.ensure(2));
-                IBO_TRY(g->tile_rows.ensure((size_t)nt32)); IBO_TRY(g->tile_sel.ensure((size_t)nt32));
+                IBO_TRY(g->tile_rows.ensure((size_t)nt32)); IBO_TRY(g->tile_sel.ensure(2 * (size_t)nt32 + 16));     // flags | compact list | counters
                 HIP_TRY(hipMemsetAsync(g->tile_done.p, 0, sizeof(int) * (size_t)nt32, s));
                 HIP_TRY(hipMemsetAsync(g->tile_rows.p, 0, sizeof(int) * (size_t)nt32, s));
-                a.tile_rows = g->tile_rows.p;
+                a.tile_rows = g->tile_rows.p; a.tile_sel = g->tile_sel.p;
                 HIP_TRY(hipMemsetAsync(g->state.p + 3 * (size_t)M, 0, sizeof(double) * 2 * (size_t)M, s));
                 a.tile_done = g->tile_done.p; a.tile_ub = g->tile_ub.p; a.part_best = g->part_words.p; a.part_thresh = g->part_words.p + 1;
+                a.part_nlev = g->st_nlev = sweep2_part_nlev(a.Npad);
                 KERNEL_TRY(launch_sweep2_pruned(a, g_gallery_prune == 1, s, g->ev0, g->ev1));
                 g->st_pruned = true;
                 g->sweep_kernel = "sweep2_kernel<part>";
@@ -1340,10 +1342,36 @@ extern "C" int ibo_sweep_state_info(ibo_gp_t *g, int64_t *tiles, int64_t *comple
         HIP_TRY(hipStreamSynchronize(g->stream));
         HIP_TRY(hipMemcpy(h.data(), g->tile_done.p, sizeof(int) * (size_t)nt, hipMemcpyDeviceToHost));
         done = 0;
-        for (int v : h) done += v != 0;
+        for (int v : h) done += v == g->st_nlev - 1;
     }
     if (tiles) *tiles = nt;
     if (complete) *complete = done;
+    return IBO_OK;
+}
+
+extern "C" int ibo_sweep_state_levels(ibo_gp_t *g, int *nlev, int *splits, int64_t *tiles_at_level)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    IBO_TRY(use_device(g->device));
+    const int64_t nt = g->st_gen ? (g->st_M + IBO_S2_TCAND - 1) / IBO_S2_TCAND : 0;
+    const int nl = (nt && g->st_pruned) ? g->st_nlev : 1;
+    if (nlev) *nlev = nl;
+    if (splits) {
+        int all[3];
+        const int n = sweep2_part_levels(g->Npad, all) - 1;
+        for (int i = 0; i < 3; i++) splits[i] = 0;
+        for (int i = 0; i < nl - 1; i++) splits[i] = all[n - (nl - 1) + i];
+    }
+    if (tiles_at_level) {
+        for (int i = 0; i < 4; i++) tiles_at_level[i] = 0;
+        if (nl == 1) tiles_at_level[0] = nt;
+        else {
+            std::vector<int> h((size_t)nt);
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            HIP_TRY(hipMemcpy(h.data(), g->tile_done.p, sizeof(int) * (size_t)nt, hipMemcpyDeviceToHost));
+            for (int v : h) if (v >= 0 && v < 4) tiles_at_level[v]++;
+        }
+    }
     return IBO_OK;
 }
 

@@ -198,7 +198,8 @@ struct SweepArgs {
     int state5;
     int part_lo, part_hi;                      // sweep2_kernel<.., PART>: the rows of W this launch covers (part_lo > 0: the second part)
     int part_rows;                             // the model's rows when the state was formed: later rows never enter q_a / q_b (zsum has them)
-    int *tile_done;                            // per 32-candidate tile: 1 once q_b is in
+    int *tile_done;                            // per 32-candidate tile: the last LEVEL of W's rows folded into (q_a, q_b): 0 after the first part,
+                                               // part_nlev - 1 once the tile is complete (round 4: up to four levels, see sweep2_part_levels)
     double *tile_ub;                           // per tile: largest value (exact or bound) of its candidates (acq_bound_kernel)
     unsigned long long *part_thresh;           // order-preserving bits of the value a tile's bound must reach to be completed (0: any finite bound)
     int part_all;                              // complete every incomplete tile, whatever its bound
@@ -206,7 +207,8 @@ struct SweepArgs {
     double part_slack;                         // absolute part of the slack a bound is given against the threshold (s2_part_limit)
     // lazy refresh of such a state: per tile the appended rows already folded into zsum (and the means' age), the selection flags of
     // the launch at hand, the model's rows now, W y (the drift margin's source), and whether tiles may be left stale at all
-    int *tile_rows; int *tile_sel; int rank_hi; const double *wy; int part_lazy;
+    int *tile_rows; int *tile_sel; const double *wy; int rank_hi; int part_lazy;
+    int part_level, part_nlev;                 // this launch's level (>= 1: only tiles whose tile_done is part_level - 1 run), and how many levels there are
     double nu_max;                             // bound on |(W k*)_i| for any candidate: sf2_k / sqrt(sf2_fit) (abi.hip: run_sweep); the drift margin's factor
     unsigned long long *part_best;             // acq_bound_kernel: running maximum over the COMPLETE tiles, same encoding
     // small2.hip: when set, the last workgroup of the last kernel stores done_seq there (host-visible memory) after all
@@ -228,7 +230,9 @@ int launch_sweep2_complete(const SweepArgs &a, hipStream_t s);
 int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s);
 bool sweep2_part_fits(int Npad, int D);
 void set_part_means(int v);
-int sweep2_part_split(int Npad);
+int sweep2_part_nlev(int Npad);                   // levels a new kept state gets (<= ibo_set_option("part_levels"))
+void set_part_levels(int v);
+int sweep2_part_levels(int Npad, int *h);        // the row splits h[0] < h[1] < .. (multiples of 128, at most 3): level l covers rows [h[l-1], h[l]); returns the number of levels
 bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);
 void set_small_inline(int v);

@@ -72,14 +72,17 @@ template <int FAM, int KA4, bool BIGN, bool PART = false>   // BIGN: more than s
                                                             // PART: rows [a.part_lo, a.part_hi) of W only, no means (kept-state sweeps)
 __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 {
+    // (PART, a.part_all == 2: the launch's workgroups are the entries of a compact LIST of tiles -- a.tile_sel holds tile numbers, not flags)
+    const unsigned tb = (PART && a.part_all == 2) ? (unsigned)a.tile_sel[blockIdx.x] : blockIdx.x;
     if (PART && a.part_lo > 0) {
-        // second part: only tiles that are not complete and whose bound reaches the threshold (a bound below it cannot win:
-        // the threshold is a value some complete candidate attains, or the cut that picks the first tiles to complete)
-        if (a.tile_done[blockIdx.x]) return;
-        if (a.tile_sel) { if (!a.tile_sel[blockIdx.x]) return; }
+        // a later level: only tiles that stand at the level before it and whose bound reaches the threshold (a bound below it cannot
+        // win: the threshold is a value some complete candidate attains, or the cut that picks the first tiles to complete)
+        if (a.tile_done[tb] != a.part_level - 1) return;
+        if (a.part_all == 2) { /* listed: selected by part_mark_kernel */ }
+        else if (a.tile_sel) { if (!a.tile_sel[tb]) return; }
         else if (!a.part_all) {
             // (no threshold yet: every tile with an admissible candidate; a tile whose candidates are all excluded never needs its variance)
-            if (!(a.tile_ub[blockIdx.x] >= s2_part_limit(*a.part_thresh, a.part_slack))) return;
+            if (!(a.tile_ub[tb] >= s2_part_limit(*a.part_thresh, a.part_slack))) return;
         }
     }
     constexpr int TCAND = IBO_S2_TCAND, CBW = TCAND / 16, RBW = 4, KA = 4 * KA4, S2_AWIN = s2_awin(KA4);
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tile0 = (int64_t)blockIdx.x * TCAND;
+    const int64_t tile0 = (int64_t)tb * TCAND;
     const int D = a.kp.D;
 #ifdef IBO_STAMPS   // diagnostic build (tools/stamp_sweep2.py): a tile's entry / prologue done / panels done / exit, and where it ran
     unsigned long long st2[4];
@@ -353,7 +356,12 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
 #pragma unroll
             for (int w = 0; w < S2_NW; w++) q += lds_q[w][tid];
             const int64_t li = tile0 + tid;
-            if (li < a.M) a.qpart[(a.part_lo > 0 ? 4 * a.M : 0) + li] = q;
+            // q_a: the first level; q_b: the later levels, added in level order (a tile always takes them in order, so its bits do not
+            // depend on WHEN it was taken further)
+            if (li < a.M) {
+                if (a.part_lo == 0) a.qpart[li] = q;
+                else a.qpart[4 * a.M + li] = a.part_level == 1 ? q : a.qpart[4 * a.M + li] + q;
+            }
             if (a.part_means) {
                 const int c = tid;
                 double my = 0.0, m1 = 0.0;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_kernel(SweepArgs a)
                 if (li < a.M) { a.qpart[a.M + li] = my; a.qpart[2 * a.M + li] = m1; }
             }
         }
-        if (a.part_lo > 0 && tid == 0) a.tile_done[blockIdx.x] = 1;
+        if (a.part_lo > 0 && tid == 0) a.tile_done[tb] = a.part_level;
         return;
     }
     for (int p = 0; p + 1 < npanel; p++) run_panel(p, std::false_type{});
@@ -453,13 +461,15 @@ __global__ __launch_bounds__(256) void acq_bound_kernel(SweepArgs a)
     for (int o = 16; o > 0; o >>= 1) val = fmax(val, __shfl_xor(val, o));          // the 32 candidates of a tile: half a wave
     if ((threadIdx.x & 31) == 0 && valid) {
         a.tile_ub[tile] = val;
-        if (a.tile_done[tile] && fresh && val > -INFINITY) atomicMax(a.part_best, s2_enc(val));
+        if (a.tile_done[tile] == a.part_nlev - 1 && fresh && val > -INFINITY) atomicMax(a.part_best, s2_enc(val));
     }
 }
 
-// The cut that picks the FIRST tiles to complete, when no tile is complete yet: the bound of the tile ranked ~3 % from the top
+// The cut that picks the FIRST tiles to complete, when no tile is complete yet: the bound of the tile ranked ~3 % from the top (or ~240th)
 // among 1024 evenly spaced tiles (one workgroup, bitonic sort in LDS).  The tiles at or above it very likely hold the maximum,
 // and whatever value they reach is the threshold for everyone else.
+// (round 4: at most ~256 tiles -- one per CU: the completion of the first tiles is a launch whose length is whole rounds of the chip, and
+// 633 tiles cost three rounds, 2.6 of a 5.2 ms sweep at BASELINE config 3's shape, where 256 cost one)
 __global__ __launch_bounds__(1024) void part_select_kernel(const double *__restrict__ tile_ub, int64_t ntiles, unsigned long long *thresh)
 {
     __shared__ double v[1024];
@@ -477,8 +487,28 @@ __global__ __launch_bounds__(1024) void part_select_kernel(const double *__restr
             }
             __syncthreads();
         }
+    // 3 % of the ranking, but not more than 256 tiles in all: the sample only estimates how many tiles lie above a cut, so the
+    // tiles at or above it are counted and the cut is raised while they are too many (at most four passes over the bounds)
+    __shared__ int cnt;
+    int64_t k = n * 3 / 100;
+    const int64_t k1 = n * 240 / ntiles;
+    if (k1 < k) k = k1;
+    for (int pass = 0; pass < 4; pass++) {
+        const double cut = v[k];
+        if (t == 0) cnt = 0;
+        __syncthreads();
+        int c = 0;
+        for (int64_t i = t; i < ntiles; i += 1024) c += tile_ub[i] >= cut;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((t & 63) == 0 && c) atomicAdd(&cnt, c);
+        __syncthreads();
+        const int total = cnt;
+        __syncthreads();
+        if (total <= 256 || k == 0) break;
+        int64_t kn = k * 230 / total;
+        k = kn < k ? kn : k - 1;
+    }
     if (t == 0) {
-        const int64_t k = n * 3 / 100;
         const double cut = v[k];
         *thresh = cut > -INFINITY ? s2_enc(cut) : 0ull;
     }
@@ -499,7 +529,8 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
     extern __shared__ __attribute__((aligned(16))) double lds_vec[];     // alphaY, alpha1, new row of W: NA128 each
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tile0 = (int64_t)blockIdx.x * TCAND;
+    const unsigned tb = (a.tile_rows && a.part_all == 2) ? (unsigned)a.tile_sel[blockIdx.x] : blockIdx.x;      // (a compact list of tiles, as in sweep2_kernel)
+    const int64_t tile0 = (int64_t)tb * TCAND;
     const int D = a.kp.D, Npad = a.Npad;
     const int NA128 = (Npad + 127) & ~127;
     // one row (a.rank1_row; < 0: the means only), or -- a kept state whose tiles are refreshed lazily (a.tile_rows) -- every appended
@@ -507,8 +538,8 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
     // do not depend on when that is; the last row's pass leaves the means formed from the current alpha vectors
     int row0 = a.rank1_row, row1 = a.rank1_row;
     if (a.tile_rows) {
-        if (a.tile_sel && !a.tile_sel[blockIdx.x]) return;
-        row0 = a.part_rows + a.tile_rows[blockIdx.x]; row1 = a.rank_hi - 1;
+        if (a.part_all != 2 && a.tile_sel && !a.tile_sel[tb]) return;
+        row0 = a.part_rows + a.tile_rows[tb]; row1 = a.rank_hi - 1;
         if (row0 > row1) return;
     }
     lds_tab[tid] = a.exp_tab[tid];
@@ -594,19 +625,34 @@ __global__ __launch_bounds__(S2_NW * 64) void sweep2_rank1_kernel(SweepArgs a)
     }
     __syncthreads();                                 // the row's vector and the partial sums are about to be rewritten
     }
-    if (tid == 0 && a.tile_rows) a.tile_rows[blockIdx.x] = row1 + 1 - a.part_rows;
+    if (tid == 0 && a.tile_rows) a.tile_rows[tb] = row1 + 1 - a.part_rows;
 }
 
 // which tiles the next refresh / completion launches take: those whose bound reaches the threshold and that are not yet exact
 __global__ void part_mark_kernel(const double *__restrict__ tile_ub, const int *__restrict__ tile_done, const int *__restrict__ tile_rows, int rows_all,
-                                 const unsigned long long *__restrict__ thresh, int64_t ntiles, int *__restrict__ tile_sel, int all, double slack_abs)
+                                 const unsigned long long *__restrict__ thresh, int64_t ntiles, int *__restrict__ tile_sel, int all, double slack_abs, int last_level,
+                                 int *__restrict__ list, int *__restrict__ count)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
-    const unsigned long long th = *thresh;
-    const bool exact = tile_done[t] && tile_rows[t] >= rows_all;
-    // all = 2: the complete tiles that lag behind (refreshing them is cheap and their values make the threshold)
-    tile_sel[t] = !exact && (all == 2 ? tile_done[t] != 0 : (all || tile_ub[t] >= s2_part_limit(th, slack_abs)));
+    bool sel = false;
+    if (t < ntiles) {
+        const unsigned long long th = *thresh;
+        const bool complete = tile_done[t] == last_level;
+        const bool exact = complete && tile_rows[t] >= rows_all;
+        // all = 2: the complete tiles that lag behind (refreshing them is cheap and their values make the threshold)
+        sel = !exact && (all == 2 ? complete : (all || tile_ub[t] >= s2_part_limit(th, slack_abs)));
+        tile_sel[t] = sel;
+    }
+    // the selected tiles as a compact list (any order: tiles are independent), its length in *count -- the host reads the length and
+    // launches exactly that many workgroups instead of one early-exit workgroup per tile of the array
+    if (list) {
+        const unsigned long long bal = __ballot(sel);
+        const int lane = threadIdx.x & 63, n = __popcll(bal);
+        int base = 0;
+        if (lane == 0 && n) base = atomicAdd(count, n);
+        base = __shfl(base, 0);
+        if (sel) list[base + __popcll(bal & ((1ull << lane) - 1))] = (int)t;
+    }
 }
 
 // XA: the observations as A-fragments of the exponent GEMM.  Row k of the augmented matrix is
@@ -741,11 +787,11 @@ static int launch_s2_part_fam(const SweepArgs &a, int64_t ntiles, hipStream_t s)
     default: return launch_s2_part_one<FAM, 9>(a, ntiles, s);
     }
 }
-static int launch_s2_part(const SweepArgs &a, int lo, int hi, unsigned long long *thresh, hipStream_t s, int means = 0)
+static int launch_s2_part(const SweepArgs &a, int lo, int hi, unsigned long long *thresh, hipStream_t s, int means = 0, int level = 0, int64_t grid = 0)
 {
-    const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
+    const int64_t ntiles = grid > 0 ? grid : (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;      // (grid: the length of the compact list, a.part_all == 2)
     SweepArgs b = a;
-    b.part_lo = lo; b.part_hi = hi; b.part_thresh = thresh; b.part_means = means;
+    b.part_lo = lo; b.part_hi = hi; b.part_thresh = thresh; b.part_means = means; b.part_level = level;
     if (a.kp.family == FAM_SE) return launch_s2_part_fam<FAM_SE>(b, ntiles, s);
     if (a.kp.family == FAM_M3) return launch_s2_part_fam<FAM_M3>(b, ntiles, s);
     return launch_s2_part_fam<FAM_M5>(b, ntiles, s);
@@ -774,36 +820,98 @@ static std::atomic<int> g_part_means{1};                         // ibo_set_opti
 void set_part_means(int v) { g_part_means = v; }
 // the part kernel has no moving alpha window and the means come from the refresh kernel: both must fit
 bool sweep2_part_fits(int Npad, int D) { return Npad >= 512 && ((Npad + 127) & ~127) <= s2_awin((D + 2 + 3) / 4) && sweep2_rank1_fits(Npad, D); }
-// rows of the first part: half of them, a quarter of the work (W is triangular) -- the multiple of 128 NEAREST to half: rounding
-// up (640 of 1088 padded rows) cost 35 % of a sweep for the first part where 512 costs 22 % (CPU estimate of the total,
-// tools/argmax_bound_probe2.py: 41 % / 31 % / 36 % of a full sweep for h = 5/8, 1/2, 3/8 of the rows)
-int sweep2_part_split(int Npad) { return ((Npad / 2 + 64) / 128) * 128; }
+// The levels of a kept state (round 4; rounds 2-3 had two: rows [0, h) and [h, N) with h = N/2).  q = |W k*|^2 is a sum over W's rows
+// with every term >= 0, so ANY prefix of the rows bounds the variance from above, and W is triangular: rows [0, N/8) are 1/64 of the
+// MFMA work.  Level 0 = rows [0, h0) for every candidate (plus the means, which need every k* row); level l = rows [h_{l-1}, h_l) for the
+// tiles whose bound still reaches the best exact value.  Splits at ~N/8, N/4, N/2 (multiples of 128: the k* stage; distinct; at least
+// 256 rows; the last level ends at the model's rows): tools/argmax_bound_probe3.py -- on BASELINE config 3's shape no tile outside the top 3 % of the
+// level-0 ranking survives even N/8 rows, 4.4 % of a full sweep's MFMA work against 27 % with the single split at N/2.
+int sweep2_part_levels(int Npad, int *h)
+{
+    const int top = (Npad + 127) & ~127;
+    int n = 0;
+    for (int f = 8; f >= 2; f >>= 1) {
+        // (at least 256 rows: the bound from 128 rows is too loose to be worth its 1/64 -- at N = 1024 half the tiles survived it,
+        // 4.6 ms for the first sweep where splits at 256 and 512 take 4.1)
+        const int v = ((Npad / f + 64) / 128) * 128;
+        if (v >= 256 && v < top && (n == 0 || v > h[n - 1])) h[n++] = v;
+    }
+    if (n == 0) h[n++] = ((Npad / 2 + 64) / 128) * 128;
+    return n + 1;
+}
+static std::atomic<int> g_part_maxlev{4};              // ibo_set_option("part_levels", 2..4): at most this many levels (2: the round-3 split at N/2)
+void set_part_levels(int v) { g_part_maxlev = v < 2 ? 2 : (v > 4 ? 4 : v); }
+// the splits of a state with `nlev` levels: the finest ones are dropped first (2 levels: the round-3 split at N/2)
+static void part_splits(int Npad, int nlev, int *h)
+{
+    int all[3];
+    const int n = sweep2_part_levels(Npad, all) - 1;
+    const int keep = nlev - 1 < n ? nlev - 1 : n;
+    for (int i = 0; i < keep; i++) h[i] = all[n - keep + i];
+}
+int sweep2_part_nlev(int Npad)                         // levels a NEW state gets (the switch is read when a state is formed, never afterwards)
+{
+    int all[3];
+    const int n = sweep2_part_levels(Npad, all);
+    return n < g_part_maxlev ? n : g_part_maxlev.load();
+}
+
+// levels [from, nlev) for the tiles the launch's filter lets through (a tile runs level l only if it stands at l - 1, so a tile taken
+// further by one launch is picked up by the next)
+static int launch_s2_levels(const SweepArgs &a, int from, unsigned long long *thresh, hipStream_t s)
+{
+    int h[3];
+    const int nlev = a.part_nlev, hi = (a.part_rows + 15) & ~15;
+    part_splits(a.Npad, nlev, h);
+    for (int l = from < 1 ? 1 : from; l < nlev; l++) {
+        const int rc = launch_s2_part(a, h[l - 1], l + 1 < nlev ? h[l] : hi, thresh, s, 0, l);
+        if (rc) return rc;
+    }
+    return 0;
+}
 
 // First sweep of a kept state (a.qpart = [q_a, aY.k*, a1.k*, zsum, q_b][M], zsum and q_b and a.tile_done zeroed by the caller;
-// a.part_best / a.part_thresh: two device words): rows [0, h) for everyone, the means, the bounds, then the second part for the
-// tiles at the top of the bound ranking, then -- against the best value THOSE reached -- for whoever's bound still reaches it.
-// A tile left incomplete has a bound below a value that a complete candidate attains: it cannot hold the maximum, and the
-// arg-max over (exact where complete, bound elsewhere) is the arg-max of the full sweep.  prune = false completes every tile.
+// a.part_best / a.part_thresh: two device words): level 0 for everyone with the means, the bounds, then every later level for the tiles at
+// the top of the bound ranking, then -- against the best value THOSE reached -- level by level for whoever's bound still reaches it, the
+// bounds re-formed after each level.  A tile left incomplete has a bound below a value that a complete candidate attains: it cannot hold the
+// maximum, and the arg-max over (exact where complete, bound elsewhere) is the arg-max of the full sweep.  prune = false completes every tile.
 int launch_sweep2_pruned(const SweepArgs &a_in, bool prune, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     SweepArgs a = a_in;
     a.tile_sel = nullptr;                            // (the first sweep selects by threshold; a_in.tile_rows is all zeros: everyone is fresh)
-    const int h = sweep2_part_split(a.Npad), hi = (a.part_rows + 15) & ~15;
+    int h[3];
+    const int nlev = a.part_nlev;                    // (set by the caller from sweep2_part_nlev when the state is formed)
+    part_splits(a.Npad, nlev, h);
     const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
     if (e0) (void)hipEventRecord(e0, s);
-    int rc = launch_s2_part(a, 0, h, a.part_thresh, s, g_part_means);        // (the means ride along with the first part)
+    int rc = launch_s2_part(a, 0, h[0], a.part_thresh, s, g_part_means);        // (the means ride along with the first level)
     if (rc) return rc;
     if (!g_part_means && (rc = launch_s2_means(a, s))) return rc;
     if (prune) {
         if ((rc = launch_s2_bound(a, s))) return rc;                               // bounds; nothing complete yet
         hipLaunchKernelGGL(part_select_kernel, dim3(1), dim3(1024), 0, s, (const double *)a.tile_ub, ntiles, a.part_thresh);
-        if ((rc = launch_s2_part(a, h, hi, a.part_thresh, s))) return rc;          // the top of the ranking
-        if ((rc = launch_s2_bound(a, s))) return rc;                               // best value among the complete
-        if ((rc = launch_s2_part(a, h, hi, a.part_best, s))) return rc;            // everyone who can still reach it
+        if ((rc = launch_s2_levels(a, 1, a.part_thresh, s))) return rc;            // the top of the ranking, all the way
+        // everyone who can still reach what they reached: one level at a time, over a compact list of the tiles concerned -- usually
+        // nobody (BASELINE config 3's shape: no tile outside the first ones survives even the first level), and then that is all
+        int *sel = a_in.tile_sel, *list = sel + ntiles, *counters = sel + 2 * ntiles;
+        if ((rc = (int)hipMemsetAsync(counters, 0, 16 * sizeof(int), s))) return rc;
+        SweepArgs al = a;
+        al.part_all = 2; al.tile_sel = list;
+        for (int l = 1; l < nlev; l++) {
+            if ((rc = launch_s2_bound(a, s))) return rc;                           // (best exact value so far; every tile's bound at its own level)
+            int n = 0;
+            hipLaunchKernelGGL(part_mark_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, (const double *)a.tile_ub, (const int *)a.tile_done,
+                               (const int *)a.tile_rows, 0, (const unsigned long long *)a.part_best, ntiles, sel, 0, a.part_slack, nlev - 1, list, counters + l);
+            hipError_t e = hipMemcpyAsync(&n, counters + l, sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return (int)e;
+            if (n == 0) break;
+            if ((rc = launch_s2_part(al, h[l - 1], l + 1 < nlev ? h[l] : ((a.part_rows + 15) & ~15), a.part_best, s, 0, l, n))) return rc;
+        }
     } else {
         SweepArgs b = a;
         b.part_all = 1;
-        if ((rc = launch_s2_part(b, h, hi, a.part_thresh, s))) return rc;
+        if ((rc = launch_s2_levels(b, 1, a.part_thresh, s))) return rc;
     }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a.M + 255) / 256;
@@ -814,20 +922,20 @@ int launch_sweep2_pruned(const SweepArgs &a_in, bool prune, hipStream_t s, hipEv
 }
 
 // after the rank-1 launches of a refresh on such a state (zsum and the means are current): the tiles whose bound now reaches the
-// best complete value get their second part; to be followed by acq_finish_kernel (launch_sweep2_refresh does both)
+// best complete value get their remaining levels; to be followed by acq_finish_kernel (launch_sweep2_refresh does both)
 int launch_sweep2_complete(const SweepArgs &a, hipStream_t s)
 {
     int rc = launch_s2_bound(a, s);
     if (rc) return rc;
-    return launch_s2_part(a, sweep2_part_split(a.Npad), (a.part_rows + 15) & ~15, a.part_best, s);
+    return launch_s2_levels(a, 1, a.part_best, s);
 }
 
-// every incomplete tile of such a state gets its second part (a caller that needs each candidate's full variance)
+// every incomplete tile of such a state gets its remaining levels (a caller that needs each candidate's full variance)
 int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s)
 {
     SweepArgs b = a;
     b.part_all = 1; b.tile_sel = nullptr;
-    return launch_s2_part(b, sweep2_part_split(a.Npad), (a.part_rows + 15) & ~15, a.part_thresh, s);
+    return launch_s2_levels(b, 1, a.part_thresh, s);
 }
 
 // rows [row_first, row_last] were appended to the model since a.qpart (the kept state [3][M]) was last brought up to
@@ -835,35 +943,61 @@ int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s)
 // The same for a state with incomplete tiles (a.tile_done, a.tile_rows, a.tile_sel set): nothing is refreshed that cannot matter.
 // The complete tiles -- few, and the best of earlier rounds -- fold in the rows they are missing; the best value they now reach is
 // the threshold: whoever else's bound (from its stale state: means widened by the drift margin, variance only too large) reaches it
-// folds its rows in and gets its second part; the arg-max then runs over everyone -- a tile left stale has a bound below a value
+// folds its rows in and gets its remaining levels; the arg-max then runs over everyone -- a tile left stale has a bound below a value
 // that an exact candidate attains.
 // lazy = false: every tile is refreshed and completed by the same launches (the reference the lazy run is held to, and the route
 // when a mean prior is set).
 static int launch_sweep2_refresh_lazy(const SweepArgs &a0, bool lazy, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     const int64_t ntiles = (a0.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
-    const int rows_all = a0.rank_hi - a0.part_rows, h = sweep2_part_split(a0.Npad), hi = (a0.part_rows + 15) & ~15;
+    const int rows_all = a0.rank_hi - a0.part_rows;
     const unsigned nmark = (unsigned)((ntiles + 255) / 256);
+    // a0.tile_sel: [flags | list | 16 counters] (abi.hip sizes it so)
+    int *list = a0.tile_sel + ntiles, *counters = a0.tile_sel + 2 * ntiles;
     if (e0) (void)hipEventRecord(e0, s);
-    auto upgrade = [&](unsigned long long *thresh, int all) -> int {       // refresh + complete the tiles at or above *thresh
+    int rc;
+    // mark the tiles at or above *thresh that are not exact (all = 1: every one; 2: the complete ones that lag behind); returns how many
+    // (the host waits for the number -- ~15 us -- and what follows runs on exactly that many workgroups, or not at all)
+    int slot = 0;
+    auto mark = [&](unsigned long long *thresh, int all, int *n) -> int {
+        int *cnt = counters + (slot++ & 15);
         hipLaunchKernelGGL(part_mark_kernel, dim3(nmark), dim3(256), 0, s, (const double *)a0.tile_ub, (const int *)a0.tile_done, (const int *)a0.tile_rows,
-                           rows_all, (const unsigned long long *)thresh, ntiles, a0.tile_sel, all, a0.part_slack);
+                           rows_all, (const unsigned long long *)thresh, ntiles, a0.tile_sel, all, a0.part_slack, a0.part_nlev - 1, list, cnt);
+        hipError_t e = hipMemcpyAsync(n, cnt, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        return (int)e;
+    };
+    auto rank1 = [&](const SweepArgs &a, int64_t grid) -> int {          // fold the appended rows into the listed (or flagged) tiles
+        if (a.kp.family == FAM_SE) return launch_s2_rank1_fam<FAM_SE>(a, grid, s);
+        if (a.kp.family == FAM_M3) return launch_s2_rank1_fam<FAM_M3>(a, grid, s);
+        return launch_s2_rank1_fam<FAM_M5>(a, grid, s);
+    };
+    if ((rc = (int)hipMemsetAsync(counters, 0, 16 * sizeof(int), s))) return rc;
+    SweepArgs al = a0;                                // the same launch arguments over the compact list
+    al.rank1_row = 0; al.part_all = 2; al.tile_sel = list;
+    if (!lazy) {
         SweepArgs a = a0;
         a.rank1_row = 0;
-        int rc;
-        if (a.kp.family == FAM_SE) rc = launch_s2_rank1_fam<FAM_SE>(a, ntiles, s);
-        else if (a.kp.family == FAM_M3) rc = launch_s2_rank1_fam<FAM_M3>(a, ntiles, s);
-        else rc = launch_s2_rank1_fam<FAM_M5>(a, ntiles, s);
-        if (rc) return rc;
-        return launch_s2_part(a, h, hi, thresh, s);
-    };
-    int rc;
-    if (!lazy) {
-        if ((rc = upgrade(a0.part_thresh, 1))) return rc;
+        hipLaunchKernelGGL(part_mark_kernel, dim3(nmark), dim3(256), 0, s, (const double *)a0.tile_ub, (const int *)a0.tile_done, (const int *)a0.tile_rows,
+                           rows_all, (const unsigned long long *)a0.part_thresh, ntiles, a0.tile_sel, 1, a0.part_slack, a0.part_nlev - 1, (int *)nullptr, (int *)nullptr);
+        if ((rc = rank1(a, ntiles))) return rc;
+        if ((rc = launch_s2_levels(a0, 1, a0.part_thresh, s))) return rc;          // (the flags select every tile that is not exact: every level for them)
     } else {
-        if ((rc = upgrade(a0.part_thresh, 2))) return rc;
+        // the complete tiles catch up (cheap, and their values make the threshold); then, level by level, whoever's bound -- re-formed
+        // after each level, from fresh means once a tile has been refreshed -- still reaches the best exact value goes one level further
+        int n = 0;
+        if ((rc = mark(a0.part_thresh, 2, &n))) return rc;
+        if (n > 0 && (rc = rank1(al, n))) return rc;
         if ((rc = launch_s2_bound(a0, s))) return rc;
-        if ((rc = upgrade(a0.part_best, 0))) return rc;
+        int h[3];
+        part_splits(a0.Npad, a0.part_nlev, h);
+        for (int l = 1; l < a0.part_nlev; l++) {
+            if ((rc = mark(a0.part_best, 0, &n))) return rc;
+            if (n == 0) break;                         // nobody's bound reaches the best exact value: the round is decided
+            if ((rc = rank1(al, n))) return rc;
+            if ((rc = launch_s2_part(al, h[l - 1], l + 1 < a0.part_nlev ? h[l] : ((a0.part_rows + 15) & ~15), a0.part_best, s, 0, l, n))) return rc;
+            if (l + 1 < a0.part_nlev && (rc = launch_s2_bound(a0, s))) return rc;
+        }
     }
     if (e1) (void)hipEventRecord(e1, s);
     const int64_t nfin = (a0.M + 255) / 256;

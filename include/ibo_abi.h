@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IBO_ABI_VERSION 5   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info */
+#define IBO_ABI_VERSION 6   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info; 6: + ibo_sweep_state_levels */
 
 /* status codes */
 #define IBO_OK              0
@@ -290,17 +290,20 @@ int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
  * caller's own kernels or hipMemcpy) are the one thing it cannot see.
  *
  * When only the arg-max is asked for (mu_dev, s2_dev and acq_dev all NULL) and the acquisition grows with the variance
- * (IBO_ACQ_EI, IBO_ACQ_UCB), the state is formed in two parts of W's rows: q_a over the first half (a quarter of the work: W
- * is triangular) for every candidate; q_b over the rest only for the 32-candidate tiles whose BOUND -- the acquisition at
- * the variance 1 + noise - q_a, which can only shrink as rows are added -- reaches a value that a complete candidate
- * attains.  The returned (best_val, best_idx) are those of the full sweep: a tile left incomplete cannot hold the maximum.
+ * (IBO_ACQ_EI, IBO_ACQ_UCB with parm >= 0), the state is formed in LEVELS of W's rows, split at about N/8, N/4 and N/2 (multiples
+ * of 128): level 0, rows [0, N/8) -- 1/64 of the work: W is triangular -- for every candidate, together with the means; each later
+ * level only for the 32-candidate tiles whose BOUND -- the acquisition at the variance 1 + noise - q(rows so far), which can only
+ * shrink as rows are added -- reaches a value that a complete candidate attains (the top 3 % of the level-0 ranking are completed
+ * first to supply it).  The returned (best_val, best_idx) are those of the full sweep: a tile left incomplete cannot hold the
+ * maximum.  ibo_set_option("part_levels", 2 | 3 | 4) caps the levels of states formed afterwards (2: one split at N/2, rounds 2-3).
  * Later calls are lazy too: the complete tiles fold in the rows appended since, the best value they reach is the threshold,
- * and only tiles whose bound -- from their stale state, the means widened by sqrt(10) sum |(W y)_i| over the appended rows:
+ * and only tiles whose bound -- from their stale state, the means widened by nu_max sum |(W y)_i| over the appended rows (nu_max =
+ * sf2_k / sqrt(sf2_fit) bounds |W k*|; no lazy mode where the fitted matrix admits no such bound):
  * nothing for observations on the posterior mean (the gallery's), everything for real ones -- reaches it are refreshed and
  * completed.  A call that wants per-candidate outputs (or IBO_ACQ_PI / IBO_ACQ_NONE), or a model with a mean prior, refreshes
  * and completes every tile first.  ibo_set_option("gallery_lazy", 0) refreshes and completes every tile on the first later call.
  * 512 <= padded rows <= 4096; 40 bytes of state per candidate.  ibo_set_option("gallery_prune", 0) restores the one-kernel
- * first sweep, 2 runs the two-part launches with every tile completed (what the pruned run is tested against, bit for bit).
+ * first sweep, 2 runs the same launches with every tile completed (what the pruned run is tested against, bit for bit).
  */
 int ibo_acq_sweep_incremental(ibo_gp_t *gp, int64_t M, const double *cand_dev,
                               int acq, double parm, int erf_mode, double clamp_lo, double ymax,
@@ -312,6 +315,10 @@ int ibo_acq_sweep_incremental(ibo_gp_t *gp, int64_t M, const double *cand_dev,
 /* the kept state of ibo_acq_sweep_incremental: its 32-candidate tiles and how many of them carry their full variance
  * (equal unless the state was formed in two parts); both 0 when the handle keeps no state */
 int ibo_sweep_state_info(ibo_gp_t *gp, int64_t *tiles, int64_t *complete);
+/* the same in detail: the state's number of levels (1: formed by the one-kernel sweep or none), splits[3] = the rows where
+ * levels 1, 2, 3 begin (0 beyond nlev - 1), tiles_at_level[4] = how many tiles stand at each level (a tile at level
+ * nlev - 1 is complete) */
+int ibo_sweep_state_levels(ibo_gp_t *gp, int *nlev, int *splits, int64_t *tiles_at_level);
 
 /* device-side duration (hipEvent, ms) of the dominant kernel of the last
  * ibo_acq_sweep / ibo_posterior_batch on this handle, and its name */

@@ -391,3 +391,48 @@ def test_two_threads_two_handles_one_device(ibo):
     assert len(got_a) == 3 * iters and len(got_b) == iters
     assert all(x == serial_a[0] for x in got_a)
     assert got_b == serial_b
+
+
+def test_levels_of_the_kept_state_agree_with_each_other_and_with_the_oracle(ibo, oracle):
+    """ibo_set_option("part_levels", 2 | 3 | 4): the kept state formed over one, two or three splits of W's rows (N/2; N/4, N/2; N/8, N/4,
+    N/2 -- at least 256 rows each).  Whatever the levels, every round returns the same (value, index) BIT FOR BIT -- a tile's sums do
+    not depend on when it was taken further -- and the oracle's arg-max; ibo_sweep_state_levels reports the splits and where the tiles
+    stand; fewer tiles are complete than exist.  N = 2040 has all three splits, N = 1000 two, N = 600 one."""
+    from ibo_amd import DeviceArray, _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.acquisition import sweep
+
+    def levels(GP):
+        nl = ctypes.c_int(); sp = (ctypes.c_int * 3)(); cnt = (ctypes.c_int64 * 4)()
+        _lib.check(_lib.lib.ibo_sweep_state_levels(GP._handle(), ctypes.byref(nl), sp, cnt))
+        return nl.value, list(sp), list(cnt)
+    try:
+        for N, D, kind, hyp, want in ((2040, 6, "m5", [.5, 1.0], {2: [1024], 3: [512, 1024], 4: [256, 512, 1024]}),
+                                      (1000, 3, "ard", [.3] * 3, {2: [512], 3: [256, 512], 4: [256, 512]}),
+                                      (600, 2, "ard", [.3] * 2, {2: [384], 3: [384], 4: [384]})):
+            X, Y = synth(700 + N, N, D)
+            cand = np.random.RandomState(701 + N).rand(50000 + 3, D)
+            okern = oracle.Kern(kind, hyp)
+            runs = {}
+            for nlev in (2, 3, 4):
+                _lib.check(_lib.lib.ibo_set_option(b"part_levels", nlev))
+                GP = GaussianProcess(_kernels(kind, hyp), X, Y, noise=.05, reserve_rows=8)
+                dc = DeviceArray.from_host(cand)
+                out = []
+                for rnd in range(4):
+                    r = sweep(GP, dc, acq='ei', parm=.2, native=False, incremental=True)
+                    nl, sp, cnt = levels(GP)
+                    assert sp[:nl - 1] == want[nlev] and nl == len(want[nlev]) + 1, (N, nlev, nl, sp)
+                    assert sum(cnt) == (len(cand) + 31) // 32 and cnt[nl - 1] < sum(cnt) // 2, (N, nlev, cnt)
+                    out.append((r["best_val"], r["best_idx"]))
+                    if nlev == 4:
+                        v = _oracle_round(oracle, okern, np.array(GP.X), np.array(GP.Y), .05, cand, oracle.ACQ_EI, .2, oracle.ERF_NR, oracle.CLAMP_PY, None, .5)
+                        k = int(np.argmax(v))
+                        close(r["best_val"], v[k], atol=ACQ_ATOL)
+                        assert r["best_idx"] == k or abs(v[r["best_idx"]] - v[k]) <= 1e-6 * abs(v[k]) + ACQ_ATOL
+                    x = cand[r["best_idx"]]
+                    GP.addData(x, GP.mu(x) + (.2 if rnd == 1 else 0.))
+                runs[nlev] = out
+            assert runs[2] == runs[3] == runs[4], (N, runs)
+    finally:
+        _lib.check(_lib.lib.ibo_set_option(b"part_levels", 4))

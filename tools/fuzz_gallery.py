@@ -4,7 +4,7 @@
 state with every candidate refreshed (0) -- same index, value at 1e-7 (the bar is 1e-6; another association of the same sums moves an EI of 1e-8, deep in
 its tail, by 1e-9 of itself) -- over random models, candidate sets, acquisitions, exclusion
 balls, and rounds that add hallucinated observations, real ones, two at a time, with and without a mean prior.
-    python3 tools/fuzz_gallery.py [cases] [seed]"""
+    python3 tools/fuzz_gallery.py [cases] [seed] [part_levels]"""
 import sys, os, time, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,6 +15,7 @@ from ibo_amd.gaussianprocess.prior import RBFNMeanPrior
 from ibo_amd.acquisition import sweep
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+if len(sys.argv) > 3: _lib.check(_lib.lib.ibo_set_option(b"part_levels", int(sys.argv[3])))
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 opt = lambda v: _lib.check(_lib.lib.ibo_set_option(b"gallery_prune", v))
 def state_info(GP):
@@ -26,15 +27,19 @@ for case in range(cases):
     N = int(rs.choice([520, 700, 1000, 1024, 1500, 2048, 2500, 3000])); D = int(rs.randint(1, 11))
     fam = int(rs.randint(0, 3)); noise = float(rs.choice([1e-3, 1e-2, 1e-1]))
     ls = float(rs.uniform(.2, .6)) * np.sqrt(D / 3.)
-    kern = [K.GaussianKernel_ard(np.full(D, ls)), K.MaternKernel3([ls, 1.0]), K.MaternKernel5([ls, 1.0])][fam]
-    X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .05 * rs.randn(N)
+    # (magnitudes below 1: under native = True libego's k* keeps sf2 = 1 for Matern-3/2 while R carries magnitude^2, so |W k*| reaches
+    # 1 / magnitude -- the drift margin of the lazy rounds must scale with it, round-3 advisor finding)
+    mag = float(rs.choice([1.0, 1.0, .5, .25]))
+    kern = [K.GaussianKernel_ard(np.full(D, ls)), K.MaternKernel3([ls, mag]), K.MaternKernel5([ls, mag])][fam]
+    X = rs.rand(N, D); Y = (np.sin(3 * X.sum(1)) + .05 * rs.randn(N)) * (mag if fam else 1.0)
     M = int(rs.choice([9000, 20000, 50001, 120000])); cand = rs.rand(M, D)
     acq = str(rs.choice(['ei', 'ucb'])); kw = dict(xi=float(rs.choice([.01, .1, .4])), native=bool(rs.randint(2))) if acq == 'ei' else {}
     prior = None
     if rs.rand() < .2:
         k = 4; prior = RBFNMeanPrior(rs.rand(k, D), rs.randn(k) * .3, float(rs.uniform(1, 4)), np.zeros(D), np.ones(D))
     rounds = int(rs.randint(4, 8)); radius = float(rs.choice([.02, .1, .3]))
-    plan = [(rs.rand() < .2, rs.rand() < .15) for _ in range(rounds)]          # (a real observation?, two points at once?)
+    p_real = .6 if mag < 1 else .2
+    plan = [(rs.rand() < p_real, rs.rand() < .15) for _ in range(rounds)]      # (a real observation?, two points at once?)
     runs = {}
     for mode in (1, 2, 0):
         opt(mode)
@@ -62,8 +67,8 @@ for case in range(cases):
         print("FAIL case %d: N=%d D=%d fam=%d noise=%g M=%d %s %s prior=%s\n   pruned %s\n   all    %s\n   plain  %s" %
               (case, N, D, fam, noise, M, acq, kw, prior is not None, runs[1], runs[2], runs[0]))
     else:
-        print("case %2d ok: N=%4d D=%2d fam=%d noise=%g M=%6d %-3s prior=%d rounds=%d  tiles without a second part after the first sweep: %.0f %%" %
-              (case, N, D, fam, noise, M, acq, prior is not None, len(runs[1]), 100 * skipped[-1]), flush=True)
+        print("case %2d ok: N=%4d D=%2d fam=%d mag=%g noise=%g M=%6d %-3s prior=%d rounds=%d  tiles without a second part after the first sweep: %.0f %%" %
+              (case, N, D, fam, mag, noise, M, acq, prior is not None, len(runs[1]), 100 * skipped[-1]), flush=True)
 opt(1)
 print("%d cases, %d failures, %.0f s; median share of tiles left incomplete by the first sweep %.0f %%" % (cases, fails, time.time() - t0, 100 * np.median(skipped)))
 sys.exit(1 if fails else 0)
