@@ -166,7 +166,12 @@ __device__ __forceinline__ void diag64_update_tile(double *S, int o, int it, int
 // part of the off-diagonal 16-blocks is scratch), V its inverse.  T is scratch.  Called by all threads of the workgroup (waves 0..3 work); ends
 // with a barrier.  With 16-blocks L_ij of the factor and V_i = L_ii^-1:
 //   [L11 0; L21 L22]^-1 = [V11 0; -V22 L21 V11, V22]   at the 32- and at the 64-level.
-__device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info)
+// `side`: work for the waves beyond the fourth of an eight-wave workgroup (chol_pipe8_kernel), called once per panel b = 0..3 between
+// the barriers: it must be short enough (~3 k cycles) not to hold the chain's barriers up, and it must stay off wave 4, which shares
+// its SIMD -- hence the fp64 pipe -- with wave 0.
+struct Diag64NoSide { __device__ __forceinline__ void operator()(int) const {} };
+template <typename Side = Diag64NoSide>
+__device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info, Side side = Side())
 {
     const int t = threadIdx.x, wv = t >> 6;
     for (int b = 0; b < 4; b++) {
@@ -175,7 +180,8 @@ __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, doubl
             diag64_panel(S, V, T, o, pivot0, info);
             CSTAMP(2 + 5 * b);
         } else if (wv > 3) {
-            // (an eight-wave workgroup -- chol_step8_kernel: waves 4..7 only keep the barriers' count)
+            // (an eight-wave workgroup: waves 4..7 keep the barriers' count -- chol_step8_kernel -- or do the caller's side work)
+            side(b);
         } else if (b == 1) {
             // the tiles of panel 0's update that panel 1 does not read: (1,1), (2,1), (2,2)
             diag64_update_tile(S, 0, wv == 1 ? 1 : 2, wv == 3 ? 2 : 1);

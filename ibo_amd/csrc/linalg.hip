@@ -438,10 +438,17 @@ __device__ unsigned long long g_upd_stamps[4][32];      // update kernel: 4 samp
 __device__ unsigned long long g_step_stamps[2][16];      // step kernel: workgroup 0 and workgroup 7
 #define SSTAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 7)) \
         g_step_stamps[blockIdx.x ? 1 : 0][i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_pipe_stamps[2][16];      // chol_pipe8_kernel: row workgroups 0 and 1 of block column 8
+#ifdef IBO_NO_PSTAMP
+#define PSTAMP(i)
+#else
+#define PSTAMP(i) do { if (threadIdx.x == 0 && jb == 8 && blockIdx.x < 2) g_pipe_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define CSTAMP(i)
 #define USTAMP(i)
 #define SSTAMP(i)
+#define PSTAMP(i)
 #endif
 __device__ __forceinline__ double lane_bcast(double x, int l)          // value of lane l, wave-uniform
 {
@@ -1752,6 +1759,208 @@ void chol_pipe_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npa
             for (int r = 0; r < 4; r++) Ob[(size_t)TILE_ROW(mm, r) * Npad + TILE_COL_TRI(n)] = acc[mm][n][r];
 }
 
+// ---- the pipelined block column on EIGHT waves, with the row workgroups' own update UNDER the chain (round 4).
+// chol_pipe_kernel's row workgroup brings two tiles up to date before its chain starts -- the diagonal block and its own block of column
+// jb, one 64^3 product each on four waves -- and both sit on the critical path of every block column (21 us per column at N = 2048:
+// gap 2.5 + loads 2.4 + two products 3 + restash 1.5 + chain 8.3 + product 1.5 + stores).  Only the diagonal block's update has to: the own
+// block is needed after the chain.  Here it runs DURING the chain, on waves 5, 6, 7 -- which idle through it, on SIMDs 1-3 (wave 4 shares
+// SIMD 0 and its fp64 pipe with the chain's wave and stays idle) -- in four slices of four k4-steps, one per panel of the chain, between the
+// chain's own barriers (diag64_factor_invert's `side`); its A operand comes straight from memory in fragment form, its B operand (the row
+// block X_jb of step jb - 1) from LDS.  The products before and after the chain run on eight waves.  Every element still receives steps
+// 0, 1, .. in order, each as sixteen ascending k4-steps on the same operands: identical bits (tools/check_pipe.py, test_split_steps_equal_fused_steps).
+// Tile workgroups: one product per tile, eight waves.
+template <int SW>     // side wave SW = 0, 1, 2 (waves 5, 6, 7): tiles 0..5 / 6..10 / 11..15 of the 4 x 4 grid of 16 x 16 tiles, i.e. two row strips each
+struct Pipe8Side {
+    static constexpr int BASE = SW == 0 ? 0 : (SW == 1 ? 6 : 11), CNT = SW == 0 ? 6 : 5;
+    static __device__ __forceinline__ int strip(int s) { return (BASE + s) >> 2; }
+    static __device__ __forceinline__ int cblk(int s) { return (BASE + s) & 3; }
+    static __device__ __forceinline__ void load(const double *Ap, int Npad, int lane, d4_t (&acc)[6])
+    {
+#pragma unroll
+        for (int s = 0; s < CNT; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[s][r] = Ap[(size_t)(16 * strip(s) + (lane >> 4) + 4 * r) * Npad + 16 * cblk(s) + (lane & 15)];
+    }
+    // acc_s -= X_i[strip] X_d[cblk]^T over k4 in [4 b, 4 b + 4): A = -X_i fragments from memory, B = X_d fragments from LDS
+    static __device__ __forceinline__ void slice(int b, const double *Xi, int Npad, const double *Us, int lane, d4_t (&acc)[6])
+    {
+        constexpr int S0 = BASE >> 2, S1 = (BASE + CNT - 1) >> 2;
+        double a0[4], a1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = (4 * b + kk) * 4 + (lane >> 4);
+            a0[kk] = -Xi[(size_t)(16 * S0 + (lane & 15)) * Npad + k];
+            a1[kk] = -Xi[(size_t)(16 * S1 + (lane & 15)) * Npad + k];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = (4 * b + kk) * 4 + (lane >> 4);
+#pragma unroll
+            for (int s = 0; s < CNT; s++) {
+                const double bv = Us[(16 * cblk(s) + (lane & 15)) * SD + k];
+                acc[s] = mfma_f64(strip(s) == S0 ? a0[kk] : a1[kk], bv, acc[s]);
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(double *Us, int lane, const d4_t (&acc)[6])
+    {
+#pragma unroll
+        for (int s = 0; s < CNT; s++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Us[(16 * strip(s) + (lane >> 4) + 4 * r) * SD + 16 * cblk(s) + (lane & 15)] = acc[s][r];
+    }
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void chol_pipe8_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npad, int jb, double *__restrict__ diag64, int *info,
+                       int nrow, double *__restrict__ Ework, double *__restrict__ Eout, int kend, int pre)
+{
+    __shared__ double S[64 * SD];
+    __shared__ double V[64 * SD];
+    __shared__ double T[64 * SD];
+    __shared__ double U[64 * SD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr8 = wv >> 1, wc8 = wv & 1;
+    const int nb = Npad / 64, m = nb - jb - 1, jp = jb - 1;
+    if ((int)blockIdx.x >= nrow) {
+        // ---- a tile of step jp right of column jb (numbering as in chol_pipe_kernel)
+        int nchol = 0;
+        for (int kk = jb + 1; kk < kend; kk++) nchol += nb - kk;
+        const int t = blockIdx.x - nrow;
+        int i, k;
+        const double *Xi;
+        double *C;
+        if (t < nchol) {
+            k = jb + 1;
+            int rem = t;
+            while (rem >= nb - k) { rem -= nb - k; k++; }
+            i = k + rem;
+            Xi = Lout + (size_t)i * 64 * Npad + jp * 64;
+            C = A + (size_t)i * 64 * Npad + k * 64;
+        } else {
+            const int e = t - nchol;
+            i = e / m; k = jb + 1 + e % m;
+            Xi = Eout + (size_t)i * 64 * Npad + jp * 64;
+            C = Ework + (size_t)i * 64 * Npad + k * 64;
+        }
+        const double *Xk = Lout + (size_t)k * 64 * Npad + jp * 64;
+        d2_t va[4], vb[4];
+        pr8_fetch(Xi, Npad, va);
+        pr8_fetch(Xk, Npad, vb);
+        d4_t acc[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[n][r] = C[(size_t)PR8_ROW(r) * Npad + PR8_COL(n)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { va[u] = -va[u]; }
+        pr8_stash(S, va);
+        pr8_stash(V, vb);
+        __syncthreads();
+        pr8_mma_nt(S, V, acc, wr8, wc8, lane);
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(size_t)PR8_ROW(r) * Npad + PR8_COL(n)] = acc[n][r];
+        return;
+    }
+    // ---- a row block of block column jb
+    const size_t doff = (size_t)jb * 64 * Npad + jb * 64;
+    const int nE = Ework ? jb + 1 : 0;
+    const bool has_row = (int)blockIdx.x < m + nE;              // (a last column without ride-along: the diagonal block alone)
+    const bool erow = (int)blockIdx.x >= m;
+    const int ib = erow ? (int)blockIdx.x - m : jb + 1 + (int)blockIdx.x;
+    const size_t roff = (size_t)ib * 64 * Npad + jb * 64;
+    const bool upd_d = pre != 0, upd_a = pre != 0 && has_row && !(erow && ib == jb);     // E's block (jb, jb) is still the identity
+    const double *Xi_glob = (erow ? Eout : Lout) + (size_t)ib * 64 * Npad + jp * 64;      // this row block's X of step jp (upd_a)
+    const double *Ap = (erow ? Ework : A) + roff;
+    PSTAMP(0);
+    // the diagonal block as eight-wave accumulators; this workgroup's own block as the side waves' 16 x 16 tiles
+    d4_t ad[2], aa[6];
+    d2_t vxd[4];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) ad[n][r] = A[doff + (size_t)PR8_ROW(r) * Npad + PR8_COL(n)];
+    if (upd_d) pr8_fetch(Lout + (size_t)jb * 64 * Npad + jp * 64, Npad, vxd);
+    if (has_row) {
+        if (wv == 5) Pipe8Side<0>::load(Ap, Npad, lane, aa);
+        else if (wv == 6) Pipe8Side<1>::load(Ap, Npad, lane, aa);
+        else if (wv == 7) Pipe8Side<2>::load(Ap, Npad, lane, aa);
+    }
+    PSTAMP(1);
+    // the chain's V (zeros) and T (identity rows) are laid out now, beside the operand: the diagonal block's update reads X_jb from U for
+    // BOTH operands (the A side negated in the register: the same bits as a negated copy in LDS), so only S waits for the product
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) V[PR8_ROW(r) * SD + PR8_COL(n)] = 0.0;
+    if (threadIdx.x < 256) T[(threadIdx.x >> 4) * SD + (threadIdx.x & 15)] = ((threadIdx.x >> 4) == (threadIdx.x & 15)) ? 1.0 : 0.0;
+    if (upd_d) {
+        pr8_stash(U, vxd);                                      //  X_jb: both operands here, B operand of the side product
+        __syncthreads();
+        PSTAMP(2);
+        {   // every fragment first (one LDS latency), then the 32 MFMAs
+            double fa[16], fb[2][16];
+#pragma unroll
+            for (int k4 = 0; k4 < 16; k4++) {
+                fa[k4] = -U[(wr8 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+#pragma unroll
+                for (int n = 0; n < 2; n++) fb[n][k4] = U[(wc8 * 32 + n * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 16; k4++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) ad[n] = mfma_f64(fa[k4], fb[n][k4], ad[n]);
+        }
+        PSTAMP(3);
+    }
+    // the diagonal block into the chain's layout
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) S[PR8_ROW(r) * SD + PR8_COL(n)] = ad[n][r];
+    __syncthreads();
+    PSTAMP(4);
+    auto side = [&](int b) {
+        if (!upd_a) return;
+        if (wv == 5) Pipe8Side<0>::slice(b, Xi_glob, Npad, U, lane, aa);
+        else if (wv == 6) Pipe8Side<1>::slice(b, Xi_glob, Npad, U, lane, aa);
+        else if (wv == 7) Pipe8Side<2>::slice(b, Xi_glob, Npad, U, lane, aa);
+    };
+    // (the LAST row-type workgroup has no row block -- the launch gives it none: it reports a failed pivot and stores the diagonal block and
+    // its inverse, 1.3 us that sat on workgroup 0's path, hence on the launch's, while that workgroup still had its product to do)
+    const bool keeper = (int)blockIdx.x == nrow - 1;
+    diag64_factor_invert(S, V, T, jb * 64, keeper ? info : nullptr, side);      // (ends with a barrier)
+    PSTAMP(5);
+    if (keeper) {
+        const int tt = threadIdx.x;
+        double *Lb = Lout + doff, *Db = diag64 + (size_t)jb * 4096;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int r = 8 * u + (tt >> 6), cc = tt & 63;
+            Lb[(size_t)r * Npad + cc] = (cc <= r) ? S[r * SD + cc] : 0.0;
+            Db[r * 64 + cc] = V[r * SD + cc];
+        }
+    }
+    if (!has_row) return;
+    // the own block, up to date, into U (X_jb there has been read for the last time before the chain's last barrier)
+    if (wv == 5) Pipe8Side<0>::store(U, lane, aa);
+    else if (wv == 6) Pipe8Side<1>::store(U, lane, aa);
+    else if (wv == 7) Pipe8Side<2>::store(U, lane, aa);
+    __syncthreads();
+    PSTAMP(6);
+    d4_t acc[2] = {};
+    if (wc8) pr8_mma_nt_tri_body<1, 2>(U, V, acc, wr8, lane);
+    else pr8_mma_nt_tri_body<0, 3>(U, V, acc, wr8, lane);
+    PSTAMP(7);
+    double *Ob = (erow ? Eout : Lout) + roff;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Ob[(size_t)PR8_ROW(r) * Npad + PR8_COL_TRI(n)] = acc[n][r];
+    PSTAMP(8);
+}
+
 static std::atomic<int> g_chol_pipe{1};         // ibo_set_option("chol_pipe", 0/1)
 void set_chol_pipe(int v) { g_chol_pipe = v; }
 
@@ -1766,14 +1975,32 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
     const int nb = Npad / 64;
     const int CU = 256, MAXT = 2 * CU;                  // tiles one fused launch takes: two per workgroup
     if (!info_is_zero) HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
-    // (from ~1300 rows: below, a step has so few tiles that the fused step's shorter critical path wins by 1-2 %)
-    if (g_chol_pipe && (nb >= 20 || g_chol_pipe > 1)) {
+    // (four-wave kernels: from ~1300 rows -- below, a step has so few tiles that the fused step's shorter critical path wins by 1-2 %;
+    // the eight-wave pipelined kernel, whose row workgroups update their own block under the chain, wins from four block columns on:
+    // 0.320 -> 0.304 ms at N = 1024 against the eight-wave fused step, 0.725 -> 0.658 at N = 2048 against the four-wave pipeline)
+    if (g_chol_pipe && (nb >= (g_step_waves == 8 ? 4 : 20) || g_chol_pipe > 1)) {
         for (int jb = 0; jb < nb; jb++) {
             const int m = nb - jb - 1, nE = Ework ? jb + 1 : 0;
-            const int nrow = m + nE > 0 ? m + nE : 1;
+            const int nrow = g_step_waves == 8 ? m + nE + 1 : (m + nE > 0 ? m + nE : 1);      // (eight waves: one more, the diagonal block's keeper)
             const int ntile = jb > 0 ? m * (m + 1) / 2 + (Ework ? jb * m : 0) : 0;        // step jb - 1 right of column jb
-            hipLaunchKernelGGL(chol_pipe_kernel, dim3(nrow + ntile), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
-                               Ework, Eout, nb, jb > 0 ? 1 : 0);
+            if (g_step_waves == 8) {
+                hipLaunchKernelGGL(chol_pipe8_kernel, dim3(nrow + ntile), dim3(512), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
+                                   Ework, Eout, nb, jb > 0 ? 1 : 0);
+#ifdef IBO_STAMPS
+            if (jb == nb - 1 && getenv("IBO_PIPE_STAMPS")) {
+                unsigned long long h[2][16];
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pipe_stamps), sizeof(h));
+                for (int w = 0; w < 2; w++) {
+                    fprintf(stderr, "[pipe8 stamps, column 8, workgroup %d] cycles from entry:", w);
+                    for (int i = 1; i <= 8; i++) fprintf(stderr, " %llu", h[w][i] - h[w][0]);
+                    fprintf(stderr, "\n");
+                }
+            }
+#endif
+            } else
+                hipLaunchKernelGGL(chol_pipe_kernel, dim3(nrow + ntile), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
+                                   Ework, Eout, nb, jb > 0 ? 1 : 0);
         }
         return (int)hipGetLastError();
     }
@@ -1836,8 +2063,8 @@ int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, 
     if (!info_is_zero) HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
     for (int p0 = 0; p0 < nb; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
-        // (the in-panel columns pipelined like the fused route's -- chol_pipe_kernel with kend = pend -- measured 2 % slower:
-        // <= 189 tiles per column, where the fused step's shorter critical path wins, as below 1300 rows)
+        // (the in-panel columns pipelined like the fused route's -- chol_pipe_kernel with kend = pend -- measured 2 % slower on four waves,
+        // 1 % faster on eight (2.48 -> 2.45 ms at N = 4096): not worth a second order to keep bit-identical)
         for (int jb = p0; jb < pend; jb++) {
             int nt = 0;
             for (int k = jb + 1; k < pend; k++) nt += nb - k;

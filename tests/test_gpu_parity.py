@@ -1300,17 +1300,21 @@ def test_split_steps_equal_fused_steps(ibo):
     from ibo_amd import _lib
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
-    for N in (1500, 2048, 1985):
+    for N in (1500, 2048, 1985, 1024, 700, 257):
         X, Y = synth(N + 2, N, 4)
         res = []
-        for pipe, split in ((1, 256), (0, 256), (0, 1 << 30), (0, 64)):      # software-pipelined columns (the default from ~1300 rows); split / fused steps
+        # software-pipelined columns on eight waves (the default: the row workgroups' own update runs under the chain) and on four;
+        # split / fused steps on eight and four waves
+        for pipe, split, waves in ((1, 256, 8), (1, 256, 4), (0, 256, 8), (0, 256, 4), (0, 1 << 30, 8), (0, 1 << 30, 4), (0, 64, 4)):
             _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
+            _lib.check(_lib.lib.ibo_set_option(b"step_waves", waves))
             try:
                 GP = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05)
                 W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
                 res.append((GP.L.copy(), W))
             finally:
                 _lib.check(_lib.lib.ibo_set_option(b"step_split", 256)); _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
+                _lib.check(_lib.lib.ibo_set_option(b"step_waves", 8))
         for L, W in res[1:]:
             assert np.array_equal(L, res[0][0]) and np.array_equal(W, res[0][1])
         _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 0))
