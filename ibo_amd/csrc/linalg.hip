@@ -1875,12 +1875,19 @@ void chol_pipe8_kernel(double *__restrict__ A, double *__restrict__ Lout, int Np
     const double *Ap = (erow ? Ework : A) + roff;
     PSTAMP(0);
     // the diagonal block as eight-wave accumulators; this workgroup's own block as the side waves' 16 x 16 tiles
+    // (the chain reads only the 16-blocks of the diagonal block on and below its diagonal -- diag64_panel, diag64_update_tile --, so
+    // only those ten get the update; dealt so that the two waves of a SIMD hold three, three, two and two of them: 48 MFMAs on the
+    // busiest fp64 pipe instead of 64 for the full 64^3 product, whose floor on one CU is 4.1 k cycles)
     d4_t ad[2], aa[6];
     d2_t vxd[4];
+    const int dt_rb0 = wv == 0 ? 0 : (wv == 1 ? 1 : (wv < 4 ? 2 : 3)), dt_cb0 = wv == 0 ? 0 : (wv == 1 ? 1 : (wv == 2 ? 1 : (wv == 3 ? 2 : (wv == 4 ? 3 : (wv == 5 ? 2 : (wv == 6 ? 0 : 1))))));
+    const int dt_rb1 = wv == 0 ? 1 : 2, dt_cb1 = 0;               // second tile: waves 0 and 1 only: (1, 0) and (2, 0)
+    const bool dt_two = wv < 2;
 #pragma unroll
-    for (int n = 0; n < 2; n++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) ad[n][r] = A[doff + (size_t)PR8_ROW(r) * Npad + PR8_COL(n)];
+    for (int r = 0; r < 4; r++) {
+        ad[0][r] = A[doff + (size_t)(16 * dt_rb0 + (lane >> 4) + 4 * r) * Npad + 16 * dt_cb0 + (lane & 15)];
+        ad[1][r] = dt_two ? A[doff + (size_t)(16 * dt_rb1 + (lane >> 4) + 4 * r) * Npad + 16 * dt_cb1 + (lane & 15)] : 0.0;
+    }
     if (upd_d) pr8_fetch(Lout + (size_t)jb * 64 * Npad + jp * 64, Npad, vxd);
     if (has_row) {
         if (wv == 5) Pipe8Side<0>::load(Ap, Npad, lane, aa);
@@ -1899,26 +1906,34 @@ void chol_pipe8_kernel(double *__restrict__ A, double *__restrict__ Lout, int Np
         pr8_stash(U, vxd);                                      //  X_jb: both operands here, B operand of the side product
         __syncthreads();
         PSTAMP(2);
-        {   // every fragment first (one LDS latency), then the 32 MFMAs
-            double fa[16], fb[2][16];
+        {   // every fragment first (one LDS latency), then the MFMAs
+            double fa0[16], fb0[16], fa1[16];
 #pragma unroll
             for (int k4 = 0; k4 < 16; k4++) {
-                fa[k4] = -U[(wr8 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
-#pragma unroll
-                for (int n = 0; n < 2; n++) fb[n][k4] = U[(wc8 * 32 + n * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+                fa0[k4] = -U[(dt_rb0 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+                fb0[k4] = U[(dt_cb0 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
+                fa1[k4] = -U[(dt_rb1 * 16 + (lane & 15)) * SD + k4 * 4 + (lane >> 4)];
             }
+            if (dt_two) {                                       // (both of a wave's second tiles are in column block 0, as wave 0's first)
 #pragma unroll
-            for (int k4 = 0; k4 < 16; k4++)
+                for (int k4 = 0; k4 < 16; k4++) {
+                    const double fb1 = U[(lane & 15) * SD + k4 * 4 + (lane >> 4)];
+                    ad[0] = mfma_f64(fa0[k4], fb0[k4], ad[0]);
+                    ad[1] = mfma_f64(fa1[k4], fb1, ad[1]);
+                }
+            } else {
 #pragma unroll
-                for (int n = 0; n < 2; n++) ad[n] = mfma_f64(fa[k4], fb[n][k4], ad[n]);
+                for (int k4 = 0; k4 < 16; k4++) ad[0] = mfma_f64(fa0[k4], fb0[k4], ad[0]);
+            }
         }
         PSTAMP(3);
     }
     // the diagonal block into the chain's layout
 #pragma unroll
-    for (int n = 0; n < 2; n++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) S[PR8_ROW(r) * SD + PR8_COL(n)] = ad[n][r];
+    for (int r = 0; r < 4; r++) {
+        S[(16 * dt_rb0 + (lane >> 4) + 4 * r) * SD + 16 * dt_cb0 + (lane & 15)] = ad[0][r];
+        if (dt_two) S[(16 * dt_rb1 + (lane >> 4) + 4 * r) * SD + 16 * dt_cb1 + (lane & 15)] = ad[1][r];
+    }
     __syncthreads();
     PSTAMP(4);
     auto side = [&](int b) {
