@@ -282,6 +282,11 @@ def worker(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # IBO_BENCH_ONE_DEVICE=1: every rank on device 0, exchanges over ibo_amd.multigpu.SocketComm (RCCL refuses two ranks on one device).  A
+    # CORRECTNESS run of the multi-rank path on a one-GPU box (tests/test_gpu_two_ranks.py) -- its numbers mean nothing: the ranks share the GPU.
+    one_device = bool(os.environ.get("IBO_BENCH_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     os.environ["IBO_DEVICE"] = str(local_rank)
     if world > 1:
         # one node: RCCL's bootstrap sockets go over loopback (the container hostname may not
@@ -311,8 +316,12 @@ def worker(args):
         watchdog = threading.Timer(300.0, _stuck)   # a rendezvous that never completes must not hang the node
         watchdog.daemon = True
         watchdog.start()
-        uid, id_path = exchange_unique_id(world, rank)
-        comm = RcclArgmax(world, rank, uid, device=local_rank)
+        if one_device:
+            from ibo_amd.multigpu import SocketComm
+            comm = SocketComm(world, rank, os.environ["IBO_COMM_ID_FILE"] + ".sock")
+        else:
+            uid, id_path = exchange_unique_id(world, rank)
+            comm = RcclArgmax(world, rank, uid, device=local_rank)
         comm.barrier()
         watchdog.cancel()
         if comm.nranks() != world:
@@ -340,6 +349,7 @@ def worker(args):
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rccl_nranks": comm.nranks() if comm is not None else None,
+            "transport": None if comm is None else ("socket, every rank on device 0 (a correctness run, not a measurement)" if one_device else "rccl"),
             "launcher": "self (bench.py children)" if os.environ.get("IBO_BENCH_CHILD") else
                         ("torch.distributed.run" if "RANK" in os.environ else "single process")}
 

@@ -50,13 +50,13 @@ def pytest_unconfigure(config):
 
 @pytest.fixture(scope="session")
 def launch_ranks():
-    """launch_ranks(argv, world, env=None, timeout=600) -> dict(rc, out, err): `world` fresh python processes running argv,
+    """launch_ranks(argv, world, env=None, timeout=600, rank_env=True) -> dict(rc, out, err): `world` fresh python processes running argv,
     started by a helper that never touched the GPU"""
     import json
 
-    def launch(argv, world, env=None, timeout=600):
+    def launch(argv, world, env=None, timeout=600, rank_env=True):
         assert _LAUNCHER is not None and _LAUNCHER.poll() is None, "the rank launcher is not running"
-        job = {"argv": list(argv), "world": int(world), "env": env or {}, "timeout": timeout}
+        job = {"argv": list(argv), "world": int(world), "env": env or {}, "timeout": timeout, "rank_env": bool(rank_env)}
         _LAUNCHER.stdin.write((json.dumps(job) + "\n").encode())
         _LAUNCHER.stdin.flush()
         return json.loads(_LAUNCHER.stdout.readline().decode())

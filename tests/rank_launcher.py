@@ -6,10 +6,10 @@ process that has run GPU tests is such a process -- a fork of it inherits the dr
 THIS helper in pytest_configure, before any test runs; it imports nothing but the standard library, makes no HIP call,
 and stays idle on its stdin.  A test that needs fresh rank processes (tests/test_gpu_two_ranks.py) sends one JSON line
 
-    {"argv": [...], "world": W, "env": {...}, "timeout": seconds}
+    {"argv": [...], "world": W, "env": {...}, "timeout": seconds, "rank_env": true}
 
 and gets one back: {"rc": [...], "out": [...], "err": [...]} (per rank).  Every child is started with RANK / LOCAL_RANK /
-WORLD_SIZE set; if one rank exits non-zero or the time is up, the others are terminated by their exact pids (never by
+WORLD_SIZE set (unless rank_env is false: a program that starts its own ranks, bench.py --gpus N); if one rank exits non-zero or the time is up, the others are terminated by their exact pids (never by
 pattern) and their exit codes reported as they are.  EOF on stdin ends the helper.
 """
 import json
@@ -27,7 +27,8 @@ def run(job):
     for r in range(world):
         env = dict(os.environ)
         env.update({k: str(v) for k, v in job.get("env", {}).items()})
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world))
+        if job.get("rank_env", True):
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world))
         fo, fe = tempfile.TemporaryFile(), tempfile.TemporaryFile()
         files.append((fo, fe))
         procs.append(subprocess.Popen([sys.executable] + list(job["argv"]), env=env, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL))

@@ -84,3 +84,25 @@ def test_a_failing_rank_fails_the_launch(launch_ranks):
     res = launch_ranks(["-c", code], 2, timeout=60)
     assert res["rc"][1] == 3 and res["rc"][0] not in (0, None), res["rc"]
     assert res["seconds"] < 30
+
+
+def test_bench_line_with_two_ranks_on_one_device(launch_ranks):
+    """bench.py --gpus 2 as the driver runs it (its own launcher, fresh rank processes, barriers, max-over-ranks timing, the
+    candidate-sharded sweep with one arg-max exchange per step, the sharded C3 gallery and C5 grid of the `configs` block) on a box with ONE
+    GPU: IBO_BENCH_ONE_DEVICE=1 puts both ranks on device 0 and the exchange on the socket transport.  The numbers mean nothing (the ranks
+    share the GPU); the line's structure, the agreement of the ranks and the sharded configs' results are what is checked."""
+    import json
+    env = {"IBO_BENCH_ONE_DEVICE": "1"}
+    res = launch_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], 1, env=env,
+                       timeout=900, rank_env=False)
+    assert res["rc"] == [0], res["err"][0][-3000:]
+    lines = [l for l in res["out"][0].splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_nranks"] == 2 and j["transport"].startswith("socket") and j["launcher"] == "self (bench.py children)"
+    assert j["scaling"] == "weak" and j["value"] > 0 and j["steps"] == 2
+    c = j["configs"]
+    assert c["c3_gallery8"]["min_pairwise_distance"] > 0.5 and c["c5_nlml_grid"]["n_not_pd"] == 0 and c["c3_shard_sweep"]["value"] > 0
+    # the same global arg-max as ONE process sweeping the two ranks' candidates: bench.py --gpus 1 over 2^21 candidates is not a config, so
+    # the check is on the index range and the value's sign here; bit-equality of sharded and single-process results is the test above
+    assert 0 <= j["best"]["index"] < 2 * (1 << 20)
