@@ -440,3 +440,44 @@ def test_levels_of_the_kept_state_agree_with_each_other_and_with_the_oracle(ibo,
                 close(a[0], c[0], rtol=1e-12, atol=0); close(b[0], c[0], rtol=1e-12, atol=0)
     finally:
         _lib.check(_lib.lib.ibo_set_option(b"part_levels", 4))
+
+
+def test_kept_state_is_dropped_when_it_cannot_be_trusted(ibo, oracle):
+    """Round-3 advisor findings, as tests.  (1) GaussianProcess.Y is a public attribute: a caller who changes an EARLIER target and then adds a
+    point gets every old target re-uploaded by ibo_gp_extend -- the stale tiles' means were formed with the old alpha vectors and the drift
+    margin only covers the appended rows, so the state must go: the next sweep is a first sweep again and agrees with a fresh model.
+    (2) UCB with a NEGATIVE coefficient (a lower confidence bound) shrinks with the variance: the prefix-variance bound is no bound, and the
+    call must take the complete-every-tile route -- its arg-max is the full sweep's."""
+    from ibo_amd import DeviceArray
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.acquisition import sweep
+    N, D = 900, 3
+    X, Y = synth(801, N, D)
+    cand = np.random.RandomState(802).rand(30000, D)
+    kern = _kernels("ard", [.3] * D)
+    GP = GaussianProcess(kern, X, Y, noise=.05, reserve_rows=4)
+    dc = DeviceArray.from_host(cand)
+    r0 = sweep(GP, dc, acq='ei', parm=.1, native=False, incremental=True)
+    assert r0["kernel"] == "sweep2_kernel<part>"
+    x = cand[r0["best_idx"]]
+    GP.addData(x, GP.mu(x))
+    assert sweep(GP, dc, acq='ei', parm=.1, native=False, incremental=True)["kernel"] == "sweep2_rank1_kernel"
+    GP.Y[5] += 0.7                                       # an earlier target changes behind the model's back ...
+    x2 = cand[(r0["best_idx"] + 11) % len(cand)]
+    GP.addData(x2, GP.mu(x2))                            # ... and rides along with the next extension
+    r = sweep(GP, dc, acq='ei', parm=.1, native=False, incremental=True)
+    assert r["kernel"] == "sweep2_kernel<part>", r["kernel"]           # the state did not survive
+    f = sweep(GaussianProcess(kern, np.array(GP.X), np.array(GP.Y), noise=.05), dc, acq='ei', parm=.1, native=False)
+    assert r["best_idx"] == f["best_idx"]; close(r["best_val"], f["best_val"], rtol=1e-9)
+    v = _oracle_round(oracle, oracle.Kern("ard", [.3] * D), np.array(GP.X), np.array(GP.Y), .05, cand, oracle.ACQ_EI, .1, oracle.ERF_NR, oracle.CLAMP_PY, None, .5)
+    assert int(np.argmax(v)) == r["best_idx"]; close(r["best_val"], v.max(), atol=ACQ_ATOL)
+    # (2) a lower confidence bound through the incremental entry point
+    GP2 = GaussianProcess(kern, X, Y, noise=.05, reserve_rows=4)
+    for rnd in range(3):
+        r = sweep(GP2, dc, acq='ucb', parm=-1.5, native=True, incremental=True)
+        tiles, done = _state_info(GP2)
+        assert tiles == done                              # nothing may be left to a bound that is none
+        f = sweep(GaussianProcess(kern, np.array(GP2.X), np.array(GP2.Y), noise=.05), dc, acq='ucb', parm=-1.5, native=True)
+        assert r["best_idx"] == f["best_idx"]; close(r["best_val"], f["best_val"], rtol=1e-9)
+        x = cand[r["best_idx"]]
+        GP2.addData(x, GP2.mu(x))
