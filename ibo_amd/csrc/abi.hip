@@ -534,6 +534,7 @@ static int dot_form_ok(const KParams &kp, const double *X, int N, int D)
 }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static int ensure_pinned(ibo_gp *g, size_t need);
 
 // stage observations (optionally in reverse order) and size every buffer
 static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y, bool reverse)
@@ -558,7 +559,11 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
     }
     IBO_TRY(g->tmp.ensure(3 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));     // launch_alpha's scratch + one vector (ibo_gp_extend)
     IBO_TRY(g->info.ensure(1));
-    std::vector<double> xp((size_t)Np * DP, 0.0), yp(Np, 0.0);
+    // staged through the handle's pinned buffer: the copies are truly asynchronous and nothing has to be waited for before the fit's
+    // kernels are queued (a pageable source is staged by the runtime and had to be kept alive by a stream synchronise: ~25 us of a 0.37 ms fit)
+    IBO_TRY(ensure_pinned(g, (size_t)Np * DP + Np));
+    double *xp = g->pin, *yp = g->pin + (size_t)Np * DP;
+    memset(g->pin, 0, sizeof(double) * ((size_t)Np * DP + Np));
     g->Yhost.assign(N, 0.0);
     double my = Y[0];
     for (int i = 0; i < N; i++) {
@@ -569,10 +574,9 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
         if (Y[i] > my) my = Y[i];      // acqmaxGP's maxY scan, cpp/optimizeGP.cpp:316-321
     }
     g->maxY = my;
-    HIP_TRY(hipMemcpyAsync(g->Xp.p, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(hipMemcpyAsync(g->Y.p, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(hipStreamSynchronize(g->stream));      // xp/yp go out of scope
-    return IBO_OK;
+    HIP_TRY(hipMemcpyAsync(g->Xp.p, xp, sizeof(double) * (size_t)Np * DP, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipMemcpyAsync(g->Y.p, yp, sizeof(double) * Np, hipMemcpyHostToDevice, g->stream));
+    return IBO_OK;                                  // (every caller ends with a stream synchronise before the pinned buffer is used again)
 }
 
 static int check_info(ibo_gp *g, int *info)
