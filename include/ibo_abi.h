@@ -406,7 +406,13 @@ typedef double (*objective_t)(int, double *);
 
 /* cpp/optimizeGP.cpp:262-283.  Returns malloc'd [fmin, xmin[0..ndim)] with
  * fmin = minimum of the NEGATED acquisition; caller frees with free(). NULL on
- * unknown acqfunc (as the reference) or on any failure (message on stderr). */
+ * unknown acqfunc (as the reference) or on any failure (message on stderr).
+ * The objective is evaluated in the reference's own operation order (cpp/optimizeGP.cpp:57-236: k*, prior mean and the
+ * acquisition with the host's libm; aMb's two sequential sums per contraction on the device, products and sums rounded
+ * separately), so fmin and xmin equal libego's BIT FOR BIT, whatever the conditioning of invR (csrc/legacy.hip).
+ * Differences kept on purpose: kerneltype 3 takes its magnitude from hyperparams[1] (the reference reads hyperparams[ndim],
+ * out of bounds for ndim > 1) and prints nothing.  ibo_set_option("legacy_exact", 0): the fast route (invR factored on the
+ * device, MFMA sweep kernels; within 1e-6 of libego on well-conditioned data only).  Re-entrant: own handle per call. */
 const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR, double *X, double *Y,
                        int nx, int acqfunc, int kerneltype, double *hyperparams,
                        int npbases, double *pbasismeans, double *pbasisbeta, double pbasistheta,
