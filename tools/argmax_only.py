@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """the exact arg-max WITHOUT per-candidate values (kept-state first sweep on a new array) at a config's shape: wall time, levels, tiles per level.
-python3 tools/argmax_only.py [c2|c3|c4] [part_levels] [repeats]"""
+python3 tools/argmax_only.py [c2|c3|c4|n4096|n3000] [part_levels] [repeats]"""
 import sys, os, time, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,9 @@ if len(sys.argv) > 2: _lib.check(_lib.lib.ibo_set_option(b"part_levels", int(sys
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 N, D, kern, M, kw = {"c2": (1024, 4, GaussianKernel_ard([.3] * 4), 1 << 20, dict(acq='ei', xi=.01, native=True)),
                      "c3": (2048, 8, MaternKernel5([.5, 1.0]), 1 << 19, dict(acq='ei', xi=.3, native=True)),
-                     "c4": (1024, 6, GaussianKernel_ard([.4] * 6), 1 << 20, dict(acq='ei', xi=.4, native=False))}[cfg]
+                     "c4": (1024, 6, GaussianKernel_ard([.4] * 6), 1 << 20, dict(acq='ei', xi=.4, native=False)),
+                     "n4096": (4096, 16, GaussianKernel_ard([.6] * 16), 1 << 17, dict(acq='ei', xi=.01, native=True)),
+                     "n3000": (3000, 5, MaternKernel5([.4, 1.0]), 1 << 18, dict(acq='ucb', native=True))}[cfg]
 rs = np.random.RandomState(3); X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + 0.01 * rs.randn(N)
 cand = np.random.RandomState(103).rand(M, D)
 GP = GaussianProcess(kern, X, Y, noise=.1)
