@@ -1,7 +1,9 @@
 // launch_floor.hip -- what one dependent host <-> GPU round trip costs on this box, three ways:
 //   (a) launch of an empty kernel whose only thread stores a sequence number into pinned host memory, host spins on it;
 //   (b) the same with 4 KiB of kernel arguments (small2.hip's inline candidates);
-//   (c) a RESIDENT kernel polling a pinned mailbox: host writes a sequence number, the kernel answers (no launch on the path).
+//   (c) a RESIDENT kernel polling a pinned mailbox: host writes a sequence number, the kernel answers (no launch on the path);
+//   (g3) the three dependent launches of (a3) as ONE instantiated hipGraph whose kernel nodes get new arguments before every launch
+//        (hipGraphExecKernelNodeSetParams x 3 + hipGraphLaunch): what a DIRECT batch's three kernels would cost as a graph.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/launch_floor.hip -o tools/launch_floor
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -70,6 +72,45 @@ int main()
         v.push_back(now_us() - t0);
     }
     report("(d) empty launch + hipStreamSynchronize", v);
+    // (g3) three kernel nodes in a chain, parameters refreshed per launch
+    {
+        hipGraph_t graph; hipGraphExec_t exec;
+        hipGraphCreate(&graph, 0);
+        hipGraphNode_t nodes[3];
+        unsigned long long sq = seq;
+        volatile unsigned long long *f0 = flag + 16, *f2 = flag;
+        void *args[3][2] = {{(void *)&f0, (void *)&sq}, {(void *)&f0, (void *)&sq}, {(void *)&f2, (void *)&sq}};
+        hipKernelNodeParams kp[3];
+        for (int k = 0; k < 3; k++) {
+            kp[k] = hipKernelNodeParams{};
+            kp[k].func = (void *)flag_kernel; kp[k].gridDim = dim3(1); kp[k].blockDim = dim3(64); kp[k].sharedMemBytes = 0;
+            kp[k].kernelParams = args[k]; kp[k].extra = nullptr;
+            hipGraphAddKernelNode(&nodes[k], graph, k ? &nodes[k - 1] : nullptr, k ? 1 : 0, &kp[k]);
+        }
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            for (int pass = 0; pass < 2; pass++) {
+                v.clear();
+                for (int i = 0; i < R; i++) {
+                    const double t0 = now_us(); sq = ++seq;
+                    for (int k = 0; k < 3; k++) hipGraphExecKernelNodeSetParams(exec, nodes[k], &kp[k]);
+                    hipGraphLaunch(exec, s);
+                    while (*(volatile unsigned long long *)flag != seq) {}
+                    v.push_back(now_us() - t0);
+                }
+            }
+            report("(g3) the three launches as one hipGraph", v);
+            v.clear();
+            for (int i = 0; i < R; i++) {                       // without the parameter updates (a fixed graph): the launch alone
+                const double t0 = now_us();
+                hipGraphLaunch(exec, s);
+                hipStreamSynchronize(s);
+                v.push_back(now_us() - t0);
+            }
+            report("(g3s) the same graph, no updates, + sync", v);
+            hipGraphExecDestroy(exec);
+        } else printf("(g3) hipGraphInstantiate failed\n");
+        hipGraphDestroy(graph);
+    }
     // (c) resident kernel
     volatile unsigned long long *req = flag + 8, *ack = flag;
     *req = 0; *ack = 0;
