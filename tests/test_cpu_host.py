@@ -31,6 +31,52 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.ibo_abi_version() == 6
 
 
+def test_the_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """the drop-in boundary is a C ABI (no C++ or torch types in the signatures): include/ibo_abi.h compiles as C99, and a C program
+    compiled with gcc links against libibo_hip.so and calls the entry points that need no GPU (version, option switches, the host DIRECT
+    with a C callback -- cpp/direct.h:76's signature -- and logCDFs)"""
+    import subprocess
+    from ibo_amd import _lib
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", os.path.join(inc, "ibo_abi.h")])
+    src = tmp_path / "abi_c.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stdlib.h>
+#include "ibo_abi.h"
+static double bowl(int n, double *x) { double s = 0.0; for (int i = 0; i < n; i++) s += (x[i] - 0.3) * (x[i] - 0.3); return s; }
+int main(void)
+{
+    double lb[2] = {0.0, 0.0}, ub[2] = {1.0, 1.0}, fmin = 0.0, xmin[2] = {0.0, 0.0};
+    int64_t ns = 0;
+    int pairs[4] = {0, 1, 1, 2};
+    double y[3] = {0.5, 0.1, -0.2};
+    if (ibo_abi_version() != IBO_ABI_VERSION) return 2;
+    if (ibo_set_option("legacy_exact", 1) != IBO_OK || ibo_set_option("no such option", 1) == IBO_OK) return 3;
+    if (ibo_direct_host(bowl, 2, lb, ub, 20, 10, 10000, 1, &fmin, xmin, &ns) != IBO_OK) return 4;
+    const double *r = direct(bowl, 2, lb, ub, 20, 10, 10000);
+    if (!r || r[0] != fmin || r[1] != xmin[0] || r[2] != xmin[1]) return 5;
+    printf("%.17g %.17g %.17g %lld %.17g\n", fmin, xmin[0], xmin[1], (long long)ns, logCDFs(4, pairs, y));
+    free((void *)r);
+    return 0;
+}
+""")
+    exe = tmp_path / "abi_c"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-l:libibo_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr[-500:])
+    fmin, x0, x1, ns, lc = out.stdout.split()
+    assert abs(float(x0) - .3) < .02 and abs(float(x1) - .3) < .02 and float(fmin) < 1e-3 and int(ns) > 50
+    # the same numbers through ctypes
+    import ctypes
+    lb = _lib.f64([0., 0.]); ub = _lib.f64([1., 1.]); xm = np.empty(2); fm = ctypes.c_double(); n2 = ctypes.c_int64()
+    cb = _lib.OBJECTIVE(lambda n, x: sum((x[i] - 0.3) ** 2 for i in range(n)))
+    _lib.check(_lib.lib.ibo_direct_host(cb, 2, _lib.dp(lb), _lib.dp(ub), 20, 10, 10000, 1, ctypes.byref(fm), _lib.dp(xm), ctypes.byref(n2)))
+    assert n2.value == int(ns) and np.allclose([xm[0], xm[1]], [float(x0), float(x1)], rtol=0, atol=1e-15)
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     from ibo_amd import _lib
     if _lib.device_count() > 0:
