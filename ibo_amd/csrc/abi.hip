@@ -53,7 +53,7 @@ void ibo_internal_set_error(const char *msg)
 extern std::atomic<int> g_sweep_variant;     // sweep.hip
 static std::atomic<int> g_host_pipeline{1};  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static std::atomic<int> g_chol_fused{1};     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
-static std::atomic<int> g_fused2_min_nb{33};  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
+static std::atomic<int> g_fused2_min_nb{86};  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
 static std::atomic<int> g_chol_fused2{1};    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
 static std::atomic<int> g_zero_copy{1};      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
 static std::atomic<int> g_small_trace{0};    // ibo_set_option("small_trace", 1: start / 2: print to stderr): host-side split of the zero-copy small batches
@@ -534,6 +534,11 @@ static int dot_form_ok(const KParams &kp, const double *X, int N, int D)
 }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// Which order factors an Np-row matrix: the single-level right-looking order with pipelined block columns and W = L^-1 riding along
+// (launch_cholesky_fused) below g_fused2_min_nb block columns, the two-level order (panels of four, K = 256 updates, recursive-doubling
+// inversion) from there on.  Round 4 moved the switch from 33 to 86 block columns: with the eight-wave pipelined column the single-level order
+// wins up to ~5400 rows (N = 2304: 1.19 -> 0.72 ms, 3072: 1.65 -> 1.18, 4096: 2.49 -> 2.25, 5120: 4.06 -> 3.83; 5632: 4.70 against 4.85).
+static inline bool single_level_order(int Np) { return Np / 64 < (g_fused2_min_nb > 33 ? g_fused2_min_nb.load() : 33); }
 static int ensure_pinned(ibo_gp *g, size_t need);
 
 // stage observations (optionally in reverse order) and size every buffer
@@ -602,7 +607,7 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     HIP_TRY(hipEventRecord(g->fit0, s));
     // R, and in the same pass the identity-padded copy the factorisation works on
     const bool fused2 = Np / 64 >= g_fused2_min_nb && g_chol_fused && g_chol_fused2;      // the two-level order, out of place as well
-    const bool fused = !fused2 && Np / 64 <= 32 && g_chol_fused;
+    const bool fused = !fused2 && single_level_order(Np) && g_chol_fused;
     double *work = (fused || fused2) ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
     // (with the working copy the same pass writes the identity the ride-along starts from and clears the info word)
     const bool ride = fused && g_chol_ride != 0;
@@ -832,7 +837,7 @@ static int pref_factor(ibo_gp *g, int *info)
     auto &pw = g->pw;
     const int N = g->N, Np = g->Npad;
     hipStream_t s = g->stream;
-    if (Np / 64 <= 32 && g_chol_fused && g_chol_ride) {
+    if (single_level_order(Np) && g_chol_fused && g_chol_ride) {
         KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, pw.E.p, Np, 1.0, s));                  // identity
         KERNEL_TRY(launch_cholesky_fused(pw.A.p, pw.Lh.p, Np, pw.d64.p, pw.info.p, s, pw.E.p, pw.Et.p));
         KERNEL_TRY(launch_transpose_lower(pw.Et.p, pw.E.p, Np, s));
@@ -1748,12 +1753,12 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     HIP_TRY(hipMemcpy(dY.p, yp.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
     // up to 2048 rows: the fit's route -- fused steps with W = L^-1 riding along (dT: the matrix being reduced, dKi: (L^-1)^T
     // until the transpose) -- instead of the three-kernel columns and the recursive-doubling inversion
-    const bool fused = Np / 64 <= 32 && g_chol_fused && g_chol_ride;
+    const bool fused = single_level_order(Np) && g_chol_fused && g_chol_ride;
     if (fused) {
         KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np, 0,
                                      dW.p, dinfo.p));
         KERNEL_TRY(launch_cholesky_fused(dT.p, dL.p, Np, d64.p, dinfo.p, s, dW.p, dKi.p, true));
-    } else if (Np / 64 > 32 && g_chol_fused && g_chol_fused2) {
+    } else if (!single_level_order(Np) && g_chol_fused && g_chol_fused2) {
         // beyond: the two-level order with fused in-panel columns, out of place
         KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np));
         KERNEL_TRY(launch_cholesky_fused2(dT.p, dL.p, Np, d64.p, dinfo.p, 4, s));

@@ -1276,7 +1276,10 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
     for N in (2113, 2200, 2250, 3000):                        # 34, 35, 36, 47 blocks
         X, Y = synth(N + 1, N, 5)
         res = []
+        # (fused2_min_nb = 33: the two-level order from 2049 rows on, as until round 4; since then it starts at 86 block columns and these
+        # sizes take the pipelined single-level order by default -- compared below, to rounding: another order of the same sums)
         for fused2, split in ((1, 256), (0, 256), (1, 40)):      # split 40: in-panel columns as row blocks + updates (as beyond 5400 rows)
+            _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 33))
             _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", fused2)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
             try:
                 GP = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)
@@ -1284,12 +1287,22 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
                 res.append((GP.L.copy(), W))
             finally:
                 _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", 1)); _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
+                _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 86))
         for L, W in res[1:]:
             assert np.array_equal(res[0][0], L) and np.array_equal(res[0][1], W)
         assert np.abs(res[0][0] - np.linalg.cholesky(GP.R)).max() < 1e-11 and np.abs(np.triu(res[0][0], 1)).max() == 0.0
+        GP = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)          # the default order at these sizes
+        W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+        assert np.abs(GP.L - res[0][0]).max() < 1e-12 and np.abs(W - res[0][1]).max() < 1e-9 * max(1.0, np.abs(W).max())
+        assert np.abs(W.dot(GP.L) - np.eye(N)).max() < 1e-10 and np.all(np.triu(W, 1) == 0.0)
     Xd = np.vstack([X[:2199], X[77:78]])                      # a duplicate point and no noise
-    with pytest.raises(NotPositiveDefinite):
-        GaussianProcess(GaussianKernel_ard([.45] * 5), Xd, Y[:2200], noise=0.0)
+    for min_nb in (33, 86):                                   # in both orders
+        _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", min_nb))
+        try:
+            with pytest.raises(NotPositiveDefinite):
+                GaussianProcess(GaussianKernel_ard([.45] * 5), Xd, Y[:2200], noise=0.0)
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 86))
 
 
 def test_split_steps_equal_fused_steps(ibo):
