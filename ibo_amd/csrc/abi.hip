@@ -233,6 +233,7 @@ struct ibo_gp {
     bool reversed = false;          // legacy invR path stores the observations in reverse order
     bool plain_fit = false;         // L = chol(R) of the model's own kernel matrix: ibo_gp_extend may append rows
     bool L_upper_dirty = false;     // zero_upper is deferred to ibo_gp_get_L
+    bool R_valid = false;           // R = K(X, X) + diag is formed when someone asks for it (ibo_gp_get_R, ibo_pref_finish): ensure_R
     int dot_form = 1;               // SE k* via a_k + b_c + x~.c~; off when |x~|^2 is so large that the
                                     // cancellation would cost more than 1e-10 (pathological length scales)
     KParams kp;
@@ -548,12 +549,13 @@ static int stage_data(ibo_gp *g, int N, int D, const double *X, const double *Y,
     if (!X || !Y) return fail(IBO_ERR_ARG, "X/Y is NULL");
     g->N = N; g->D = D; g->Npad = round_up(N + (reverse ? 0 : g->reserve), 64); g->DP = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64)));
     g->reversed = reverse;
+    g->R_valid = false;             // new points: R is formed again when someone asks (ensure_R)
     const int Np = g->Npad, DP = g->DP;
     size_t nn = (size_t)Np * Np;
     IBO_TRY(g->Xp.ensure((size_t)Np * DP)); IBO_TRY(g->Xs.ensure((size_t)Np * DP)); IBO_TRY(g->ak.ensure(Np));
     IBO_TRY(g->XA.ensure((size_t)((Np + 127) / 128 * 8) * ((D + 5) / 4) * 64));
     IBO_TRY(g->Y.ensure(Np));
-    IBO_TRY(g->R.ensure(nn)); IBO_TRY(g->L.ensure(nn)); IBO_TRY(g->W.ensure(nn));     // R: N x N with row stride Npad (room to extend)
+    IBO_TRY(g->L.ensure(nn)); IBO_TRY(g->W.ensure(nn));
     IBO_TRY(g->T.ensure(nn)); IBO_TRY(g->Wp.ensure(nn)); IBO_TRY(g->diag64.ensure((size_t)(Np / 64) * 4096));
     // sweep2's stages cover rows up to the next multiple of 128: the tail of both alpha vectors stays zero
     IBO_TRY(g->alphaY.ensure((size_t)Np + 128)); IBO_TRY(g->alpha1.ensure((size_t)Np + 128));
@@ -597,6 +599,19 @@ static int check_info(ibo_gp *g, int *info)
     return IBO_OK;
 }
 
+// R = K(X, X) with the reference's hard-wired diagonal 1 + noise (ego/gaussianprocess/__init__.py:138), over the rows the
+// model holds now, by the kernel and in the order of operations the fit's own covariance pass uses: what a fit, or a fit
+// and its extensions, would have written had they kept R up to date.
+static int ensure_R(ibo_gp *g)
+{
+    if (g->R_valid) return IBO_OK;
+    IBO_TRY(g->R.ensure((size_t)g->Npad * g->Npad));             // N x N with row stride Npad (room to extend)
+    KERNEL_TRY(launch_cov_matrix(g->kp_fit, g->N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, g->noise, g->R.p, g->Npad,
+                                 g->stream, nullptr, 0, 0, nullptr, nullptr));
+    g->R_valid = true;
+    return IBO_OK;
+}
+
 // Everything of a fit after the data are staged: R, L = chol(R) -- or chol(A) for a matrix already in g->A (N x N) --,
 // W = L^-1 and its packed copy, both alpha vectors.
 static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool have_A, int *info)
@@ -612,9 +627,15 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     // (with the working copy the same pass writes the identity the ride-along starts from and clears the info word)
     const bool ride = fused && g_chol_ride != 0;
     const bool one_pass = ride && !A_host;
-    KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, g->R.p, Np, s,
-                                 A_host ? nullptr : work, Np, 0, one_pass ? g->W.p : nullptr, (one_pass || fused2) ? g->info.p : nullptr));
-    if (A_host) KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
+    // (GP.R itself is not written here: 33 MB of stores at N = 2048 that only ibo_gp_get_R and ibo_pref_finish read -- ensure_R;
+    // stage_data marked it stale)
+    if (!A_host)
+        KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, nullptr, Np, s,
+                                     work, Np, 0, one_pass ? g->W.p : nullptr, (one_pass || fused2) ? g->info.p : nullptr));
+    else {
+        if (fused2) HIP_TRY(hipMemsetAsync(g->info.p, 0, sizeof(int), s));
+        KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
+    }
     bool packed = false;
     if (fused) {
         // small enough for the plain right-looking order: one fused launch per block column, out of place, with
@@ -698,7 +719,7 @@ extern "C" int ibo_gp_extend(ibo_gp_t *g, int n, const double *Xnew, const doubl
     for (int i = 0; i < n; i++) {
         const int N = N0 + i;                       // rows present before this point
         // k = K(X, x_new) (also the new row / column of R), z = W k and u = W^T z, then the new rows of L and W
-        KERNEL_TRY(launch_extend_kvec(g->kp_fit, g->Xp.p, DP, N, Np, g->noise, g->R.p, g->tmp.p + 2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np, s));
+        KERNEL_TRY(launch_extend_kvec(g->kp_fit, g->Xp.p, DP, N, Np, g->noise, g->R_valid ? g->R.p : nullptr, g->tmp.p + 2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np, s));
         double *kvec = g->tmp.p + 2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np;
         KERNEL_TRY(launch_alpha(g->W.p, N, Np, kvec, g->tmp.p, g->T.p, g->T.p + Np, s));      // t2[0..Np) = z, T[0..Np) = W^T z
         KERNEL_TRY(launch_extend_rows(N, Np, g->noise, g->tmp.p, g->T.p, g->L.p, g->W.p, g->Wp.p, g->info.p, s));
@@ -941,7 +962,7 @@ extern "C" int ibo_pref_finish(ibo_gp_t *g, int nnz, const int64_t *lin_host, co
     IBO_TRY(pref_factor(g, info));
     KERNEL_TRY(launch_wtw(pw.E.p, pw.Et.p, pw.A.p, Np, s));                              // C^-1
     IBO_TRY(g->A.ensure((size_t)N * N));
-    // R: the plain fit left it on the handle (and every fit writes it again)
+    IBO_TRY(ensure_R(g));
     KERNEL_TRY(launch_pref_sum(g->R.p, pw.A.p, N, Np, g->A.p, s));
     return fit_factor(g, g->kp_fit, N, g->noise, true, info);
 }
@@ -984,6 +1005,9 @@ extern "C" int ibo_gp_get_R(ibo_gp_t *g, double *R_host)
 {
     if (!g || !R_host) return fail(IBO_ERR_ARG, "NULL argument");
     if (!g->fitted || g->reversed) return fail(IBO_ERR_STATE, "R not available");
+    IBO_TRY(use_device(g->device));
+    IBO_TRY(ensure_R(g));
+    HIP_TRY(hipStreamSynchronize(g->stream));
     return copy_square(g, g->R.p, g->Npad, R_host);
 }
 extern "C" int ibo_gp_get_L(ibo_gp_t *g, double *L_host)

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp1, int n1, co
     const bool mirror = square && !lower_only && K && j0 < i0;
     const bool skip = square && j0 > i0;             // (lower_only: a factorisation only reads the lower triangle)
     if (j0 > i0) K2 = nullptr;                       // ... so the working copy gets no blocks above the diagonal (67 MB less at N = 4096)
-    if (Eye) {                                       // an np2 x np2 identity in the same pass (the fit's ride-along rows)
+    if (Eye && j0 >= i0) {                           // an np2 x np2 identity in the same pass (the fit's ride-along rows: tile (i, k) of
+                                                     // E is read by steps i <= j < k only -- its blocks left of the diagonal never)
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -2618,9 +2619,8 @@ __global__ __launch_bounds__(256) void extend_kvec_kernel(KParams kp, const doub
             z += kp.w[d] * (u * u);
         }
         v = cov_from_z_rt(kp.family, z, kp.sf2);
-        R[(size_t)N * Npad + i] = v;
-        R[(size_t)i * Npad + N] = v;
-    } else if (i == N) R[(size_t)N * Npad + N] = 1.0 + noise;
+        if (R) { R[(size_t)N * Npad + i] = v; R[(size_t)i * Npad + N] = v; }
+    } else if (i == N && R) R[(size_t)N * Npad + N] = 1.0 + noise;
     kvec[i] = v;
 }
 

@@ -31,7 +31,7 @@ def newest(pattern):
 SPEC = {
     "c3": (("sweep2_kernel<2, 3",), -(1 << 22), "EI evaluation (bench.py --config c3: launches of 2^22 candidates, N=2048, D=8, Matern-5/2)"),
     "c5": (("chol_update3_kernel",), 4 * 64, "theta-point (tools/c5_only.py: 4 grids of 64)"),
-    "fit4096": (("chol_update_kernel", "chol_update2_kernel"), 8, "fit (tools/time_fit.py: the constructor's fit + 7)"),
+    "fit4096": (("chol_pipe", "chol_step"), 8, "fit (tools/time_fit.py: the constructor's fit + 7)"),
     "fit2048": (("chol_pipe", "chol_step"), 8, "fit"),           # chol_pipe8_kernel since round 4 (chol_pipe_kernel / chol_step*_kernel before)
     "fit1024": (("chol_pipe", "chol_step"), 8, "fit"),
 }
