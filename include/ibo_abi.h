@@ -145,7 +145,7 @@ int ibo_gp_fit(ibo_gp_t *gp, int ktype, int N, int D,
  * Same, but factor a caller-supplied symmetric matrix A (N x N, host) in place
  * of R: PrefGaussianProcess uses A = R + C^-1
  * (ego/gaussianprocess/__init__.py:487-498, ego/acquisition/__init__.py:385-386).
- * R itself is still built (ibo_gp_get_R) because callers read GP.R.
+ * R itself stays available (ibo_gp_get_R) because callers read GP.R.
  */
 int ibo_gp_fit_with_matrix(ibo_gp_t *gp, int ktype, int N, int D,
                            const double *X_host, const double *Y_host,
@@ -202,7 +202,8 @@ int ibo_gp_set_kstar_sf2(ibo_gp_t *gp, double sf2);
 int ibo_gp_set_prior(ibo_gp_t *gp, int nb, const double *means_host, const double *beta_host,
                      double theta, const double *lowerb_host, const double *width_host);
 
-/* copy the public attributes back (N x N row-major each) */
+/* copy the public attributes back (N x N row-major each).  R = K(X, X) with the reference's diagonal 1 + noise is formed on the
+ * first request after a fit (a fit itself only needs its factor; ibo_gp_extend keeps a formed R up to date) */
 int ibo_gp_get_R(ibo_gp_t *gp, double *R_host);
 int ibo_gp_get_L(ibo_gp_t *gp, double *L_host);
 /* W = L^-1 (N x N, lower triangular), and R^-1 = W^T W if wanted by a caller */
