@@ -53,7 +53,7 @@ void ibo_internal_set_error(const char *msg)
 extern std::atomic<int> g_sweep_variant;     // sweep.hip
 static std::atomic<int> g_host_pipeline{1};  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static std::atomic<int> g_chol_fused{1};     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
-static std::atomic<int> g_fused2_min_nb{86};  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
+static std::atomic<int> g_fused2_min_nb{104};  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
 static std::atomic<int> g_chol_fused2{1};    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
 static std::atomic<int> g_zero_copy{1};      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
 static std::atomic<int> g_small_trace{0};    // ibo_set_option("small_trace", 1: start / 2: print to stderr): host-side split of the zero-copy small batches
@@ -310,6 +310,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "trinv_wide")) { set_trinv_wide(value); return IBO_OK; }
     if (key && !strcmp(key, "step_split")) { set_step_split(value); return IBO_OK; }
     if (key && !strcmp(key, "step_waves")) { set_step_waves(value); return IBO_OK; }
+    if (key && !strcmp(key, "pipe_pairs")) { set_pipe_pairs(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_pipe")) { set_chol_pipe(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_diag")) { set_chol_panel_diag(value); return IBO_OK; }

@@ -1812,9 +1812,17 @@ struct Pipe8Side {
     }
 };
 
+// TMODE (which tiles ride in the launch; the row workgroups are the same in both).  0: step jp on every tile right of column jb -- one pass
+// over the trailing matrix per block column.  Beyond ~2000 rows that pass is what a column costs (44 us at N = 4096 against the chain's 18:
+// 128 KiB moved per 64^3 product), so there a tile gets TWO steps per pass, the accumulators staying in registers between them
+// (the four operand blocks fill the four LDS arrays) -- 1: the launch carries `nsingle` tiles of column jb + 1 with step jp alone (odd jb:
+// the column the next launch factors) and then the tiles of columns [c_lo, c_hi) with steps q - 1 and q; the host deals the columns of a
+// pair of steps over the two launches that may carry it (launch_cholesky_fused).  A tile receives the same k4-steps in the same order on the
+// same operands as with a store and a reload in between: identical bits.
+template <int TMODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void chol_pipe8_kernel(double *__restrict__ A, double *__restrict__ Lout, int Npad, int jb, double *__restrict__ diag64, int *info,
-                       int nrow, double *__restrict__ Ework, double *__restrict__ Eout, int kend, int pre)
+                       int nrow, double *__restrict__ Ework, double *__restrict__ Eout, int kend, int pre, int nsingle, int q, int c_lo, int c_hi)
 {
     __shared__ double S[64 * SD];
     __shared__ double V[64 * SD];
@@ -1822,7 +1830,67 @@ void chol_pipe8_kernel(double *__restrict__ A, double *__restrict__ Lout, int Np
     __shared__ double U[64 * SD];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr8 = wv >> 1, wc8 = wv & 1;
     const int nb = Npad / 64, m = nb - jb - 1, jp = jb - 1;
-    if ((int)blockIdx.x >= nrow) {
+    if (TMODE != 0 && (int)blockIdx.x >= nrow) {
+        int t = blockIdx.x - nrow;
+        int i, k, sc;                                           // tile (i, k); sc: the block column of the (second) step's row blocks
+        bool etile, two;
+        if (t < nsingle) {                                      // column jb + 1: its m tiles of the matrix, then E's rows 0 .. jp
+            k = jb + 1; sc = jp;
+            etile = t >= m;
+            i = etile ? t - m : k + t;
+            two = false;
+        } else {
+            t -= nsingle;
+            sc = q;
+            int nchol = 0;
+            for (int kk = c_lo; kk < c_hi; kk++) nchol += nb - kk;
+            etile = t >= nchol;
+            if (!etile) {
+                k = c_lo;
+                int rem = t;
+                while (rem >= nb - k) { rem -= nb - k; k++; }
+                i = k + rem;
+            } else {
+                const int e = t - nchol, w = c_hi - c_lo;
+                i = e / w; k = c_lo + e % w;
+            }
+            two = !(etile && i == q);                           // (E's row q takes part from step q on)
+        }
+        const double *Xi = (etile ? Eout : Lout) + (size_t)i * 64 * Npad + sc * 64;
+        const double *Xk = Lout + (size_t)k * 64 * Npad + sc * 64;
+        double *C = (etile ? Ework : A) + (size_t)i * 64 * Npad + k * 64;
+        d2_t va[4], vb[4], va2[4], vb2[4];
+        if (two) {
+            pr8_fetch(Xi - 64, Npad, va2);                      // step q - 1: the block column to the left
+            pr8_fetch(Xk - 64, Npad, vb2);
+        }
+        pr8_fetch(Xi, Npad, va);
+        pr8_fetch(Xk, Npad, vb);
+        d4_t acc[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[n][r] = C[(size_t)PR8_ROW(r) * Npad + PR8_COL(n)];
+        if (two) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { va2[u] = -va2[u]; }
+            pr8_stash(S, va2);
+            pr8_stash(V, vb2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { va[u] = -va[u]; }
+        pr8_stash(T, va);
+        pr8_stash(U, vb);
+        __syncthreads();
+        if (two) pr8_mma_nt(S, V, acc, wr8, wc8, lane);
+        pr8_mma_nt(T, U, acc, wr8, wc8, lane);
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(size_t)PR8_ROW(r) * Npad + PR8_COL(n)] = acc[n][r];
+        return;
+    }
+    if (TMODE == 0 && (int)blockIdx.x >= nrow) {
         // ---- a tile of step jp right of column jb (numbering as in chol_pipe_kernel)
         int nchol = 0;
         for (int kk = jb + 1; kk < kend; kk++) nchol += nb - kk;
@@ -1982,6 +2050,8 @@ void set_chol_pipe(int v) { g_chol_pipe = v; }
 
 static std::atomic<int> g_step_waves{8};        // ibo_set_option("step_waves", 4/8): fused steps on four or eight waves (same bits)
 void set_step_waves(int v) { g_step_waves = v; }
+static std::atomic<int> g_pipe_pairs{12};       // ibo_set_option("pipe_pairs"): block columns from which the pipelined order applies two steps per pass (0: never)
+void set_pipe_pairs(int v) { g_pipe_pairs = v; }
 static std::atomic<int> g_step_split{256};      // ibo_set_option("step_split"): tiles of a block column from which rows and updates are separate launches
 void set_step_split(int v) { g_step_split = v; }
 
@@ -1995,13 +2065,39 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
     // the eight-wave pipelined kernel, whose row workgroups update their own block under the chain, wins from four block columns on:
     // 0.320 -> 0.304 ms at N = 1024 against the eight-wave fused step, 0.725 -> 0.658 at N = 2048 against the four-wave pipeline)
     if (g_chol_pipe && (nb >= (g_step_waves == 8 ? 4 : 20) || g_chol_pipe > 1)) {
+        const bool pairs = g_pipe_pairs > 0 && nb >= g_pipe_pairs;
+        int split = nb;                                 // (pairs: first column whose pair of steps waits for the odd launch)
         for (int jb = 0; jb < nb; jb++) {
             const int m = nb - jb - 1, nE = Ework ? jb + 1 : 0;
             const int nrow = g_step_waves == 8 ? m + nE + 1 : (m + nE > 0 ? m + nE : 1);      // (eight waves: one more, the diagonal block's keeper)
             const int ntile = jb > 0 ? m * (m + 1) / 2 + (Ework ? jb * m : 0) : 0;        // step jb - 1 right of column jb
-            if (g_step_waves == 8) {
-                hipLaunchKernelGGL(chol_pipe8_kernel, dim3(nrow + ntile), dim3(512), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
-                                   Ework, Eout, nb, jb > 0 ? 1 : 0);
+            if (g_step_waves == 8 && pairs) {
+                // two steps per pass.  The pair of steps (2 p, 2 p + 1) is due on every column right of 2 p + 2 and may ride in launch
+                // 2 p + 2 or 2 p + 3: the columns up to `split` (at least the two that the next launches factor) take it in the even launch,
+                // the rest in the odd one -- which also carries step jb - 1 for column jb + 1 alone -- so that both launches have about
+                // the same number of tiles to hide under their chain.
+                const int nE1 = Ework ? 1 : 0;
+                int nsingle = 0, q = 0, c_lo = 0, c_hi = 0;
+                if (jb & 1) {
+                    nsingle = m > 0 ? m + nE1 * jb : 0;
+                    if (jb >= 3) { q = jb - 2; c_lo = split < nb ? split : nb; c_hi = nb; }
+                } else if (jb >= 2) {
+                    q = jb - 1;
+                    // tiles of column k: (nb - k) of the matrix + (q + 1) of E; half of them, but columns jb + 1 and jb + 2 in any case
+                    long total = 0, run = 0;
+                    for (int k = jb + 1; k < nb; k++) total += (nb - k) + nE1 * (q + 1);
+                    const long later = nb - jb - 2 > 0 ? (nb - jb - 2) + nE1 * (jb + 1) : 0;        // the odd launch's own tiles (column jb + 2)
+                    split = jb + 1;
+                    while (split < nb && (split < jb + 3 || 2 * run < total + later)) { run += (nb - split) + nE1 * (q + 1); split++; }
+                    c_lo = jb + 1; c_hi = split;
+                }
+                long npair = 0;
+                for (int k = c_lo; k < c_hi; k++) npair += (nb - k) + nE1 * (q + 1);
+                hipLaunchKernelGGL(chol_pipe8_kernel<1>, dim3(nrow + nsingle + (int)npair), dim3(512), 0, s, work, out, Npad, jb, diag64, info_dev,
+                                   nrow, Ework, Eout, nb, jb > 0 ? 1 : 0, nsingle, q, c_lo, c_hi);
+            } else if (g_step_waves == 8) {
+                hipLaunchKernelGGL(chol_pipe8_kernel<0>, dim3(nrow + ntile), dim3(512), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
+                                   Ework, Eout, nb, jb > 0 ? 1 : 0, 0, 0, 0, 0);
 #ifdef IBO_STAMPS
             if (jb == nb - 1 && getenv("IBO_PIPE_STAMPS")) {
                 unsigned long long h[2][16];

@@ -1276,7 +1276,7 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
     for N in (2113, 2200, 2250, 3000):                        # 34, 35, 36, 47 blocks
         X, Y = synth(N + 1, N, 5)
         res = []
-        # (fused2_min_nb = 33: the two-level order from 2049 rows on, as until round 4; since then it starts at 86 block columns and these
+        # (fused2_min_nb = 33: the two-level order from 2049 rows on, as until round 4; since then it starts at 104 block columns and these
         # sizes take the pipelined single-level order by default -- compared below, to rounding: another order of the same sums)
         for fused2, split in ((1, 256), (0, 256), (1, 40)):      # split 40: in-panel columns as row blocks + updates (as beyond 5400 rows)
             _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 33))
@@ -1287,7 +1287,7 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
                 res.append((GP.L.copy(), W))
             finally:
                 _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", 1)); _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
-                _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 86))
+                _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 104))
         for L, W in res[1:]:
             assert np.array_equal(res[0][0], L) and np.array_equal(res[0][1], W)
         assert np.abs(res[0][0] - np.linalg.cholesky(GP.R)).max() < 1e-11 and np.abs(np.triu(res[0][0], 1)).max() == 0.0
@@ -1295,14 +1295,21 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
         W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
         assert np.abs(GP.L - res[0][0]).max() < 1e-12 and np.abs(W - res[0][1]).max() < 1e-9 * max(1.0, np.abs(W).max())
         assert np.abs(W.dot(GP.L) - np.eye(N)).max() < 1e-10 and np.all(np.triu(W, 1) == 0.0)
+        _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", 0))                         # ... with one step per pass over the trailing tiles: the same bits
+        try:
+            GP1 = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)
+            W1 = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP1._handle(), _lib.dp(W1)))
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", 12))
+        assert np.array_equal(GP1.L, GP.L) and np.array_equal(W1, W)
     Xd = np.vstack([X[:2199], X[77:78]])                      # a duplicate point and no noise
-    for min_nb in (33, 86):                                   # in both orders
+    for min_nb in (33, 104):                                   # in both orders
         _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", min_nb))
         try:
             with pytest.raises(NotPositiveDefinite):
                 GaussianProcess(GaussianKernel_ard([.45] * 5), Xd, Y[:2200], noise=0.0)
         finally:
-            _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 86))
+            _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 104))
 
 
 def test_split_steps_equal_fused_steps(ibo):
@@ -1318,16 +1325,19 @@ def test_split_steps_equal_fused_steps(ibo):
         res = []
         # software-pipelined columns on eight waves (the default: the row workgroups' own update runs under the chain) and on four;
         # split / fused steps on eight and four waves
-        for pipe, split, waves in ((1, 256, 8), (1, 256, 4), (0, 256, 8), (0, 256, 4), (0, 1 << 30, 8), (0, 1 << 30, 4), (0, 64, 4)):
+        # (pairs: the pipelined order applying two steps per pass over the trailing tiles -- the default from 12 block columns on --, one
+        # step per pass, and two steps per pass forced from the first column)
+        for pipe, split, waves, pairs in ((1, 256, 8, 12), (1, 256, 8, 0), (1, 256, 8, 1), (1, 256, 4, 12), (0, 256, 8, 12), (0, 256, 4, 12), (0, 1 << 30, 8, 12),
+                                          (0, 1 << 30, 4, 12), (0, 64, 4, 12)):
             _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
-            _lib.check(_lib.lib.ibo_set_option(b"step_waves", waves))
+            _lib.check(_lib.lib.ibo_set_option(b"step_waves", waves)); _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", pairs))
             try:
                 GP = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05)
                 W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
                 res.append((GP.L.copy(), W))
             finally:
                 _lib.check(_lib.lib.ibo_set_option(b"step_split", 256)); _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
-                _lib.check(_lib.lib.ibo_set_option(b"step_waves", 8))
+                _lib.check(_lib.lib.ibo_set_option(b"step_waves", 8)); _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", 12))
         for L, W in res[1:]:
             assert np.array_equal(L, res[0][0]) and np.array_equal(W, res[0][1])
         _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 0))
