@@ -15,6 +15,8 @@ python3 tools/time_incremental.py > profiles/${TAG}_time_incremental.txt 2> $O/i
 { for c in c2 c3 c4; do for l in 4 3 2; do python3 tools/argmax_only.py $c $l; done; done; } > profiles/${TAG}_argmax_only.txt 2> $O/argmax.err
 { python3 tools/legacy_probe.py 1e-4 1 2>&1 | grep -a "per-point\|maxiter 10\|legacy_exact" | cut -c1-260; python3 tools/legacy_probe.py 1e-4 0 2>&1 | grep -a "per-point\|maxiter 10\|legacy_exact" | cut -c1-260; } > profiles/${TAG}_legacy_probe.txt
 python3 tools/check_step8.py > profiles/${TAG}_fit_wave_ab.txt 2> $O/step8.err
+python3 tools/check_pairs.py > profiles/${TAG}_fit_pairs_ab.txt 2> $O/pairs.err
+bash tools/pipe_columns.sh 4096 > profiles/${TAG}_pipe8_n4096_columns_pairs.txt 2>&1
 [ -f tools/libibo_hip_stamps.so ] && { IBO_HIP_LIB=tools/libibo_hip_stamps.so IBO_PIPE_STAMPS=1 python3 tools/time_fit.py 1024 2048 2>&1 | tail -8; } > profiles/${TAG}_pipe8_stamps.txt
 { [ -x tools/launch_floor ] && tools/launch_floor; python3 tools/time_small_split.py 2>&1; } > profiles/${TAG}_direct_batch_floor.txt 2> $O/floor.err
 timeout 600 python3 tools/fuzz_nlml.py 60 7 > $O/fuzz_nlml.txt 2>&1; tail -4 $O/fuzz_nlml.txt > profiles/${TAG}_fuzz_nlml_summary.txt

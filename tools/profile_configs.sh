@@ -15,11 +15,11 @@ P3="WRITE_SIZE"
 P4="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM"
 run() {   # name, then the program and its arguments (the program itself after --: no shell in between)
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/trace -- "$@" > $OUT/$name.trace.log 2>&1
+  timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/trace -- "$@" > $OUT/$name.trace.log 2>&1
   i=0
   for pass in "$P1" "$P2" "$P3" "$P4"; do
     i=$((i+1))
-    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$name/pmc$i -- "$@" > $OUT/$name.pmc$i.log 2>&1
+    timeout -k 5 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/$name/pmc$i -- "$@" > $OUT/$name.pmc$i.log 2>&1
   done
 }
 run c3 python3 bench.py --config c3 --steps 2 --warmup 1 --no-cpu-baseline
@@ -28,6 +28,6 @@ run fit4096 python3 tools/time_fit.py 4096
 run fit2048 python3 tools/time_fit.py 2048
 run fit1024 python3 tools/time_fit.py 1024
 # kernel stats only
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gallery/trace -- python3 tools/run_configs.py c3 > $OUT/gallery.trace.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4/trace -- python3 tools/run_configs.py c4 > $OUT/c4.trace.log 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gallery/trace -- python3 tools/run_configs.py c3 > $OUT/gallery.trace.log 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4/trace -- python3 tools/run_configs.py c4 > $OUT/c4.trace.log 2>&1
 python3 tools/summarize_configs.py $OUT $TAG
