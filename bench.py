@@ -505,7 +505,7 @@ def worker(args):
                     fits["N%d_D%d" % (n, d)] = {"device_ms": ms, "host_to_ready_ms": float(np.median(host_ms)),
                                                 "roofline": attach_pmc(roofline_mfma(f_fit(n, d), ms * 1e-3, flops_per_fit=f_fit(n, d),
                                                                                      algorithmic_bytes_per_fit=8 * n * d + 24 * n * n,
-                                                                                     kernels="cov_matrix + chol_pipe8 (up to 2048 rows) / chol_step8 + chol_update + trinv_* (beyond) + transpose_pack / pack_w + gemv"),
+                                                                                     kernels="cov_matrix + chol_pipe8 (pipelined block columns, two steps per pass over the trailing tiles, W riding along: up to 6592 rows; two-level order + trinv_* beyond) + transpose_pack + gemv"),
                                                                        "fit%d" % n)}
                     del g
                     # one more observation through addData: an in-place extension of L, W and the packed copies
