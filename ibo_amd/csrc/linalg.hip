@@ -2098,6 +2098,9 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
             } else if (g_step_waves == 8) {
                 hipLaunchKernelGGL(chol_pipe8_kernel<0>, dim3(nrow + ntile), dim3(512), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
                                    Ework, Eout, nb, jb > 0 ? 1 : 0, 0, 0, 0, 0);
+            } else
+                hipLaunchKernelGGL(chol_pipe_kernel, dim3(nrow + ntile), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
+                                   Ework, Eout, nb, jb > 0 ? 1 : 0);
 #ifdef IBO_STAMPS
             if (jb == nb - 1 && getenv("IBO_PIPE_STAMPS")) {
                 unsigned long long h[2][16];
@@ -2110,9 +2113,6 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
                 }
             }
 #endif
-            } else
-                hipLaunchKernelGGL(chol_pipe_kernel, dim3(nrow + ntile), dim3(256), 0, s, work, out, Npad, jb, diag64, info_dev, nrow,
-                                   Ework, Eout, nb, jb > 0 ? 1 : 0);
         }
         return (int)hipGetLastError();
     }
