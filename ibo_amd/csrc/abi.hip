@@ -53,6 +53,7 @@ void ibo_internal_set_error(const char *msg)
 extern std::atomic<int> g_sweep_variant;     // sweep.hip
 static std::atomic<int> g_host_pipeline{1};  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
 static std::atomic<int> g_chol_fused{1};     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
+static std::atomic<int> g_cov_fit{1};         // ibo_set_option("cov_fit", 0/1): the fit's own covariance pass (cov_fit_kernel) or the general kernel; same bits
 static std::atomic<int> g_fused2_min_nb{104};  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
 static std::atomic<int> g_chol_fused2{1};    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
 static std::atomic<int> g_zero_copy{1};      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
@@ -311,6 +312,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "step_split")) { set_step_split(value); return IBO_OK; }
     if (key && !strcmp(key, "step_waves")) { set_step_waves(value); return IBO_OK; }
     if (key && !strcmp(key, "pipe_pairs")) { set_pipe_pairs(value); return IBO_OK; }
+    if (key && !strcmp(key, "cov_fit")) { g_cov_fit = value; return IBO_OK; }
     if (key && !strcmp(key, "chol_pipe")) { set_chol_pipe(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_diag")) { set_chol_panel_diag(value); return IBO_OK; }
@@ -631,8 +633,14 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     // (GP.R itself is not written here: 33 MB of stores at N = 2048 that only ibo_gp_get_R and ibo_pref_finish read -- ensure_R;
     // stage_data marked it stale)
     if (!A_host)
-        KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, nullptr, Np, s,
-                                     work, Np, 0, one_pass ? g->W.p : nullptr, (one_pass || fused2) ? g->info.p : nullptr));
+    {
+        if (g_cov_fit)
+            KERNEL_TRY(launch_cov_fit(kp, N, g->Xp.p, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, work, Np, one_pass ? g->W.p : nullptr,
+                                      (one_pass || fused2) ? g->info.p : nullptr, s));
+        else
+            KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, nullptr, Np, s,
+                                         work, Np, 0, one_pass ? g->W.p : nullptr, (one_pass || fused2) ? g->info.p : nullptr));
+    }
     else {
         if (fused2) HIP_TRY(hipMemsetAsync(g->info.p, 0, sizeof(int), s));
         KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));

@@ -247,6 +247,8 @@ int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
                       int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2 = nullptr, int np2 = 0, int lower_only = 0,
                       double *Eye = nullptr, int *zero_word = nullptr, int fast = 0);     // Eye: np2 x np2 identity written in the same pass (with K2); fast: see cov_matrix_kernel
+int launch_cov_fit(const KParams &kp, int n, const double *X, int ldp, int diag_rule, double noise, double *K2, int np2, double *Eye,
+                   int *zero_word, hipStream_t s);          // the fit's own pass: working copy (lower blocks), ride-along identity, info word
 int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const double *A1, int ldp, int diag_rule, double noise,
                               double *K, int ldk, size_t kstride, hipStream_t s, int fast);
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the

@@ -131,6 +131,85 @@ __global__ __launch_bounds__(256) void cov_matrix_kernel(KParams kp1, int n1, co
     }
 }
 
+// The FIT's covariance pass by itself (round 4): only what a factorisation reads -- the 64 x 64 blocks of K(X, X) + diag on and below the
+// diagonal, padded with the identity to np2 x np2, into the working copy; the identity the W ride-along starts from (its blocks on and right of
+// the diagonal) and the cleared info word in the same pass.  GP.R is formed on request (abi.hip ensure_R, cov_matrix_kernel).  Entry by entry
+// the arithmetic of cov_matrix_kernel<false>: the same bits.  TS x TS entries per workgroup of 256 threads: with 64 x 64 tiles a 1024-point fit
+// is 136 workgroups of four waves doing 16 entries per thread -- one wave per SIMD on half the chip, 14.7 us for 4 MB; 32 x 32 tiles put four
+// times as many workgroups on it.
+template <int LD, int TS>
+__global__ __launch_bounds__(256) void cov_fit_kernel(KParams kp, int n, const double *__restrict__ X, int ldp, int diag_rule, double noise,
+                                                      double *__restrict__ K2, int np2, double *__restrict__ Eye, int *__restrict__ zero_word)
+{
+    constexpr int R = TS / 16;
+    __shared__ double As[TS * LD], Bs[TS * LD];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int j0 = blockIdx.x * TS, i0 = blockIdx.y * TS, D = kp.D;
+    if (zero_word && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) *zero_word = 0;
+    const bool lower = j0 / 64 <= i0 / 64, upper = j0 / 64 >= i0 / 64;        // by 64 x 64 BLOCK: a diagonal block is written whole
+    if (Eye && upper) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < R; c++) {
+                const int i = i0 + ty * R + r, j = j0 + tx + 16 * c;
+                if (i < np2 && j < np2) Eye[(size_t)i * np2 + j] = (i == j) ? 1.0 : 0.0;
+            }
+    }
+    if (!lower) return;
+    for (int e = t; e < TS * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        As[r * LD + d] = (i0 + r < n) ? X[(size_t)(i0 + r) * ldp + d] : 0.0;
+        Bs[r * LD + d] = (j0 + r < n) ? X[(size_t)(j0 + r) * ldp + d] : 0.0;
+    }
+    __syncthreads();
+    double z[R][R] = {};
+    for (int d = 0; d < D; d++) {
+        const double w = kp.w[d];
+        double a[R], b[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) a[r] = As[(ty * R + r) * LD + d];
+#pragma unroll
+        for (int c = 0; c < R; c++) b[c] = Bs[(tx + 16 * c) * LD + d];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < R; c++) {
+                const double u = a[r] - b[c];
+                z[r][c] += w * (u * u);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = i0 + ty * R + r;
+#pragma unroll
+        for (int c = 0; c < R; c++) {
+            const int j = j0 + tx + 16 * c;
+            if (i < n && j < n) {
+                double v = cov_from_z_rt(kp.family, z[r][c], kp.sf2);
+                if (i == j) v = (diag_rule == 0) ? (1.0 + noise) : (v + noise);
+                K2[(size_t)i * np2 + j] = v;
+            } else if (i < np2 && j < np2) {
+                K2[(size_t)i * np2 + j] = (i == j) ? 1.0 : 0.0;
+            }
+        }
+    }
+}
+int launch_cov_fit(const KParams &kp, int n, const double *X, int ldp, int diag_rule, double noise, double *K2, int np2, double *Eye,
+                   int *zero_word, hipStream_t s)
+{
+    if (np2 <= 2560) {
+        dim3 grid(np2 / 32, np2 / 32);
+        if (kp.D <= 32) hipLaunchKernelGGL((cov_fit_kernel<33, 32>), grid, dim3(256), 0, s, kp, n, X, ldp, diag_rule, noise, K2, np2, Eye, zero_word);
+        else hipLaunchKernelGGL((cov_fit_kernel<65, 32>), grid, dim3(256), 0, s, kp, n, X, ldp, diag_rule, noise, K2, np2, Eye, zero_word);
+    } else {
+        dim3 grid(np2 / 64, np2 / 64);
+        if (kp.D <= 32) hipLaunchKernelGGL((cov_fit_kernel<33, 64>), grid, dim3(256), 0, s, kp, n, X, ldp, diag_rule, noise, K2, np2, Eye, zero_word);
+        else hipLaunchKernelGGL((cov_fit_kernel<65, 64>), grid, dim3(256), 0, s, kp, n, X, ldp, diag_rule, noise, K2, np2, Eye, zero_word);
+    }
+    return (int)hipGetLastError();
+}
+
 // K2 (optional, square case): a second, np2 x np2 copy of K padded with the identity -- the matrix the
 // factorisation works on, written by the same kernel instead of a separate pad-and-copy pass: its blocks on and below
 // the diagonal only.  K may be NULL when only the working copy is wanted.
@@ -2242,19 +2321,19 @@ __global__ void transpose_pack_kernel(const double *__restrict__ Et, int N, int 
     const int nk8 = Npad / 8;
     const bool lower = blockIdx.x <= blockIdx.y;
     if (lower) {
-        for (int e = threadIdx.x; e < 4096; e += 256) {
+        for (int e = threadIdx.x; e < 4096; e += blockDim.x) {
             const int r = e >> 6, c = e & 63;
             tile[r][c] = Et[(size_t)(bx + r) * Npad + by + c];   // Et block (x, y)
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < 4096; e += 256) {
+    for (int e = threadIdx.x; e < 4096; e += blockDim.x) {
         const int r = e >> 6, c = e & 63;
         const int row = by + r, col = bx + c;
         W[(size_t)row * Npad + col] = (lower && row < N && col <= row) ? tile[c][r] : 0.0;
     }
     // packed copy: the block's 4 row groups x 8 column steps, 128 consecutive doubles each
-    for (int e = threadIdx.x; e < 4096; e += 256) {
+    for (int e = threadIdx.x; e < 4096; e += blockDim.x) {
         const int h = e & 1, lane = (e >> 1) & 63, chunk = e >> 7;       // chunk = g_local * 8 + j_local
         const int r = 16 * (chunk >> 3) + (lane & 15), c = 8 * (chunk & 7) + 4 * h + (lane >> 4);
         const int row = by + r, col = bx + c;
@@ -2264,7 +2343,9 @@ __global__ void transpose_pack_kernel(const double *__restrict__ Et, int N, int 
 }
 int launch_transpose_pack(const double *Et, int N, int Npad, double *W, double *Wp, hipStream_t s)
 {
-    hipLaunchKernelGGL(transpose_pack_kernel, dim3(Npad / 64, Npad / 64), dim3(256), 0, s, Et, N, Npad, W, Wp);
+    // (up to ~1500 rows the grid is at most two workgroups per CU and a workgroup's three passes over its 4096 elements are what the kernel lasts:
+    // 1024 threads take four elements each instead of sixteen)
+    hipLaunchKernelGGL(transpose_pack_kernel, dim3(Npad / 64, Npad / 64), dim3(Npad <= 1536 ? 1024 : 256), 0, s, Et, N, Npad, W, Wp);
     return (int)hipGetLastError();
 }
 

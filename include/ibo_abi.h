@@ -92,7 +92,7 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * than T tiles as two launches, row blocks then updates; 256),
  * "trinv_wide" (eight-wave tiles in the small levels of the triangular inversion), "update2_min_tiles", "fused2_min_nb" (block columns from which a fit takes the two-level order: 104; the order fixes
  * the rounding of L and W, so results at 2049 .. 6592 rows differ from ABI 5's in the last bits), "pipe_pairs" (block columns from which the
- * pipelined order applies two steps per pass over the trailing tiles: 12; same bits either way).
+ * pipelined order applies two steps per pass over the trailing tiles: 12; same bits either way), "cov_fit" (the fit's own covariance pass; same bits).
  * ibo_nlml_grid (same values whatever the setting, except "cov_fast", which changes the covariance entries by a rounding error):
  * "chol_left" (left-looking outer order from one packed copy of the factor), "nlml_groups" (sub-batches on their own streams),
  * "chol_panel_rows" 0..3 (which kernel takes the rows below a panel), "cov_fast".  Small batches: "small_local" 0/1/2 (the

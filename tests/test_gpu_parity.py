@@ -1312,6 +1312,30 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
             _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 104))
 
 
+def test_fit_covariance_pass_equals_the_general_kernel(ibo):
+    """the fit's own covariance pass (cov_fit_kernel: working copy, ride-along identity and info word, 32 x 32 tiles up to 2560 rows) leaves the
+    factor the general kernel's pass leaves, bit for bit; GP.R, formed on request since round 4, is the matrix that was factored"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard, MaternKernel3
+    for N, D in ((97, 2), (700, 5), (1024, 4), (2600, 9)):
+        X, Y = synth(N + 5, N, D)
+        for kern in (GaussianKernel_ard([.35] * D), MaternKernel3([.6] * D)):
+            res = []
+            for cf in (0, 1):
+                _lib.check(_lib.lib.ibo_set_option(b"cov_fit", cf))
+                try:
+                    GP = GaussianProcess(kern, X, Y, noise=1e-3)
+                    W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+                    res.append((GP.L.copy(), W, np.array(GP.R)))
+                finally:
+                    _lib.check(_lib.lib.ibo_set_option(b"cov_fit", 1))
+            for a, b in zip(res[0], res[1]):
+                assert np.array_equal(a, b)
+            L, R = res[1][0], res[1][2]
+            assert np.abs(L @ L.T - R).max() < 1e-12 * N and np.array_equal(R, R.T) and np.all(np.diag(R) == 1.0 + 1e-3)
+
+
 def test_split_steps_equal_fused_steps(ibo):
     """fits of up to 2048 rows: software-pipelined block columns (a launch holds column j's row blocks and the rest of step
     j - 1's tiles), block columns as two launches (row blocks with the chain, then one product per tile), fused steps with two
