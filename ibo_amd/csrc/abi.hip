@@ -1788,8 +1788,10 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     // until the transpose) -- instead of the three-kernel columns and the recursive-doubling inversion
     const bool fused = single_level_order(Np) && g_chol_fused && g_chol_ride;
     if (fused) {
-        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np, 0,
-                                     dW.p, dinfo.p));
+        if (g_cov_fit) KERNEL_TRY(launch_cov_fit(kp, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dT.p, Np, dW.p, dinfo.p, s));
+        else
+            KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np, 0,
+                                         dW.p, dinfo.p));
         KERNEL_TRY(launch_cholesky_fused(dT.p, dL.p, Np, d64.p, dinfo.p, s, dW.p, dKi.p, true));
     } else if (!single_level_order(Np) && g_chol_fused && g_chol_fused2) {
         // beyond: the two-level order with fused in-panel columns, out of place

@@ -1334,6 +1334,17 @@ def test_fit_covariance_pass_equals_the_general_kernel(ibo):
                 assert np.array_equal(a, b)
             L, R = res[1][0], res[1][2]
             assert np.abs(L @ L.T - R).max() < 1e-12 * N and np.array_equal(R, R.T) and np.all(np.diag(R) == 1.0 + 1e-3)
+    # ibo_nlml_grad takes the same pass: same value and gradient either way
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+    X, Y = synth(1203, 1200, 3)
+    out = []
+    for cf in (0, 1):
+        _lib.check(_lib.lib.ibo_set_option(b"cov_fit", cf))
+        try:
+            out.append(marginalLikelihood(GaussianKernel_ard([.3, .4, .5]), X, Y, 3, True, noise=1e-2))
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"cov_fit", 1))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
 
 
 def test_split_steps_equal_fused_steps(ibo):
