@@ -1803,15 +1803,18 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
         KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
     }
     // no look at the info word until everything is queued: a failed factorisation only turns the rest into NaNs
-    if (fused) KERNEL_TRY(launch_transpose_pack(dKi.p, N, Np, dW.p, dT.p, s));         // W, pad rows zero (dT: the packed copy, unused)
+    if (fused) KERNEL_TRY(launch_transpose_pack(dKi.p, N, Np, dW.p, nullptr, s));      // W, pad rows zero (no packed copy: nothing sweeps here)
     else {
         KERNEL_TRY(launch_zero_upper(dL.p, Np, s));
         KERNEL_TRY(launch_trinv(dL.p, Np, d64.p, dW.p, dT.p, s));
         KERNEL_TRY(launch_pack_w(dW.p, N, Np, 0, dW.p, dT.p, s));                      // zero the pad rows
     }
     KERNEL_TRY(launch_alpha(dW.p, N, Np, dY.p, tmp.p, dal.p, da1.p, s));
-    KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s, 1));
-    KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, dKi.p, Np, dal.p, dpart.p, dout.p, s));
+    // K^-1 = W^T W: with the ride-along, W^T is what the factorisation left in dKi -- no transpose; the result goes to dT, free by now
+    const double *Kinv = fused ? dT.p : dKi.p;
+    if (fused) KERNEL_TRY(launch_wtw(dW.p, dKi.p, dT.p, Np, s, 1, 1));
+    else KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s, 1));
+    KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, Kinv, Np, dal.p, dpart.p, dout.p, s));
     KERNEL_TRY(launch_nlml_scalars(dL.p, Np, N, dY.p, dal.p, dout.p + ngrad, s));        // (y . alpha, sum log L_ii) behind the gradient
     std::vector<double> res(ngrad + 2);
     int h = 0;

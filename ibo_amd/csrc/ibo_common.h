@@ -305,7 +305,7 @@ int launch_alpha(const double *W, int N, int Npad, const double *y, double *tmp2
 // Xs = Xp * sqrt(w), ak = -|Xs_k|^2/2; maxnorm2 (device double) receives max_k |Xs_k|^2
 int launch_scale_x(const KParams &kp, const double *Xp, int Npad, int DP, double *Xs, double *ak, hipStream_t s);
 // C = W^T W (Wt: scratch for the transpose), all Npad x Npad
-int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, int lower_only = 0);     // lower_only: blocks on and below the diagonal
+int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, int lower_only = 0, int wt_ready = 0);     // lower_only: blocks on and below the diagonal
 int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double *X, int ldx, const double *Kinv, int ldk,
                      const double *alpha, double *partial, double *out, hipStream_t s);
 // one-point block extension (ibo_gp_extend): kvec[i] = k(x_i, x_N) for i < N (zero beyond) and row / column N of R

@@ -2332,7 +2332,8 @@ __global__ void transpose_pack_kernel(const double *__restrict__ Et, int N, int 
         const int row = by + r, col = bx + c;
         W[(size_t)row * Npad + col] = (lower && row < N && col <= row) ? tile[c][r] : 0.0;
     }
-    // packed copy: the block's 4 row groups x 8 column steps, 128 consecutive doubles each
+    // packed copy (if wanted): the block's 4 row groups x 8 column steps, 128 consecutive doubles each
+    if (Wp)
     for (int e = threadIdx.x; e < 4096; e += blockDim.x) {
         const int h = e & 1, lane = (e >> 1) & 63, chunk = e >> 7;       // chunk = g_local * 8 + j_local
         const int r = 16 * (chunk >> 3) + (lane & 15), c = 8 * (chunk & 7) + 4 * h + (lane >> 4);
@@ -2547,10 +2548,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < 4; q++) Ct[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
 }
 
-int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, int lower_only)
+// wt_ready: Wt already holds W^T on and right of the diagonal blocks (the ride-along's (L^-1)^T as the factorisation leaves it: the blocks
+// left of the diagonal, which it never writes, are never read here) -- no transpose pass
+int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, int lower_only, int wt_ready)
 {
     dim3 g(Npad / 64, Npad / 64);
-    hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, s, W, Wt, Npad);
+    if (!wt_ready) hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, s, W, Wt, Npad);
     hipLaunchKernelGGL(wtw_kernel, g, dim3(256), 0, s, Wt, W, C, Npad, lower_only);
     return (int)hipGetLastError();
 }
