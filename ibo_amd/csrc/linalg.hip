@@ -2527,8 +2527,9 @@ __global__ void transpose_kernel(const double *__restrict__ A, double *__restric
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W,
-                                                  double *__restrict__ C, int Npad, int lower_only)
+template <int NW>                                               // four or eight waves per 64 x 64 tile: the same MFMAs in the same order per element
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, NW == 4 ? 2 : 4)))
+void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W, double *__restrict__ C, int Npad, int lower_only)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * TNN_LD];
@@ -2537,16 +2538,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lower_only && tj > ti) return;                          // the caller reads C[max(i,j)][min(i,j)] (C is symmetric, bit for bit)
     const double *A = Wt + (size_t)ti * 64 * Npad;              // rows i of W^T, all k
     const double *B = W + (size_t)tj * 64;                      // columns j of W
-    d4_t acc[2][2] = {};
-    tile64_gemm_nn<4>(A, Npad, B, Npad, max(ti, tj), Npad / 64, acc, As, Bs);      // W is lower triangular: k >= max(i, j)
+    d4_t acc[8 / NW][2] = {};
+    tile64_gemm_nn<NW>(A, Npad, B, Npad, max(ti, tj), Npad / 64, acc, As, Bs);     // W is lower triangular: k >= max(i, j)
     double *Ct = C + (size_t)ti * 64 * Npad + (size_t)tj * 64;
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < 8 / NW; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) Ct[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
+            for (int q = 0; q < 4; q++) Ct[(size_t)TNN_ROW(m, q) * Npad + TNN_COL(n)] = acc[m][n][q];
 }
+static std::atomic<int> g_wtw_waves{8};         // ibo_set_option("wtw_waves", 4/8)
+void set_wtw_waves(int v) { g_wtw_waves = v; }
 
 // wt_ready: Wt already holds W^T on and right of the diagonal blocks (the ride-along's (L^-1)^T as the factorisation leaves it: the blocks
 // left of the diagonal, which it never writes, are never read here) -- no transpose pass
@@ -2554,7 +2557,8 @@ int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, 
 {
     dim3 g(Npad / 64, Npad / 64);
     if (!wt_ready) hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, s, W, Wt, Npad);
-    hipLaunchKernelGGL(wtw_kernel, g, dim3(256), 0, s, Wt, W, C, Npad, lower_only);
+    if (g_wtw_waves == 8) hipLaunchKernelGGL(wtw_kernel<8>, g, dim3(512), 0, s, Wt, W, C, Npad, lower_only);
+    else hipLaunchKernelGGL(wtw_kernel<4>, g, dim3(256), 0, s, Wt, W, C, Npad, lower_only);
     return (int)hipGetLastError();
 }
 
