@@ -2633,6 +2633,93 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs,
     if (t < gs.nh) partial[(size_t)t * gridDim.x * gridDim.y + blk] = ((red[t][0] + red[t][1]) + red[t][2]) + red[t][3];
 }
 
+// The SE-ARD case by itself (round 4): derivatives 0 .. D - 1 are the D length scales in order (dK_h = K_ab w_h u_h^2), optionally followed by
+// the signal magnitude (2 K_ab).  The general kernel reads both points' coordinates from LDS once per pair and dimension and again per
+// derivative, and walks a switch per pair and derivative -- ~1000 LDS reads per thread, 530 us at N = 4096, D = 16 for 0.8 GFLOP.  Here a
+// thread's 4 x 4 pairs share their eight points' coordinates per dimension (8 LDS reads for 16 pairs), in two passes over the dimensions:
+// z_ab, then -- with t_ab = (K^-1 - alpha alpha^T)_ab K_ab known -- acc_d += sum_pairs t_ab w_d u_d^2.  The sum over (a, b) is symmetric:
+// tiles above the diagonal contribute nothing, tiles below it count twice (an exact scaling).
+template <int GM, int LD>
+__global__ __launch_bounds__(256) void nlml_grad_ard_kernel(KParams kp, int nh, int N, const double *__restrict__ X, int ldx,
+                                                            const double *__restrict__ Kinv, int ldk, const double *__restrict__ alpha,
+                                                            double *__restrict__ partial)
+{
+    __shared__ double As[64 * LD], Bs[64 * LD], ala[64], alb[64];
+    __shared__ double red[GM][4];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, D = kp.D;
+    const int b0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    if (blockIdx.x > blockIdx.y) {                              // (b-block > a-block: its mirror image carries the weight)
+        if (t < nh) partial[(size_t)t * gridDim.x * gridDim.y + blk] = 0.0;
+        return;
+    }
+    for (int e = t; e < 64 * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        As[r * LD + d] = (a0 + r < N) ? X[(size_t)(a0 + r) * ldx + d] : 0.0;
+        Bs[r * LD + d] = (b0 + r < N) ? X[(size_t)(b0 + r) * ldx + d] : 0.0;
+    }
+    if (t < 64) ala[t] = (a0 + t < N) ? alpha[a0 + t] : 0.0;
+    else if (t < 128) alb[t - 64] = (b0 + t - 64 < N) ? alpha[b0 + t - 64] : 0.0;
+    // (K^-1 - alpha alpha^T): requested now, used after the first pass
+    double wm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int a = a0 + ty * 4 + r, b = b0 + tx + 16 * c;
+            wm[r][c] = (a < N && b < N) ? Kinv[(size_t)(a > b ? a : b) * ldk + (a > b ? b : a)] : 0.0;
+        }
+    __syncthreads();
+    double z[4][4] = {};
+    for (int d = 0; d < D; d++) {
+        const double w = kp.w[d];
+        double av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) av[r] = As[(ty * 4 + r) * LD + d];
+#pragma unroll
+        for (int c = 0; c < 4; c++) bv[c] = Bs[(tx + 16 * c) * LD + d];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { const double u = av[r] - bv[c]; z[r][c] += w * (u * u); }
+    }
+    double tsum = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int a = a0 + ty * 4 + r, b = b0 + tx + 16 * c;
+            const double kab = cov_from_z_rt(kp.family, z[r][c], kp.sf2);
+            const double tt = (a < N && b < N) ? (wm[r][c] - ala[ty * 4 + r] * alb[tx + 16 * c]) * kab : 0.0;
+            z[r][c] = tt;                                       // t_ab
+            tsum += tt;
+        }
+    const int lane = t & 63, wave = t >> 6;
+    const double scale = blockIdx.x < blockIdx.y ? 2.0 : 1.0;
+    for (int d = 0; d < D; d++) {
+        const double w = kp.w[d];
+        double av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) av[r] = As[(ty * 4 + r) * LD + d];
+#pragma unroll
+        for (int c = 0; c < 4; c++) bv[c] = Bs[(tx + 16 * c) * LD + d];
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { const double u = av[r] - bv[c]; s = fma(z[r][c], w * (u * u), s); }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[d][wave] = s;
+    }
+    if (nh > D) {                                               // the signal magnitude: dK = 2 K
+        double s = 2.0 * tsum;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[D][wave] = s;
+    }
+    __syncthreads();
+    if (t < nh) partial[(size_t)t * gridDim.x * gridDim.y + blk] = scale * (((red[t][0] + red[t][1]) + red[t][2]) + red[t][3]);
+}
+
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const double *__restrict__ partial, int nblk, double *__restrict__ out)
 {
     __shared__ double red[256];
@@ -2645,6 +2732,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double *__restri
     if (t == 0) out[h] = 0.5 * red[0];
 }
 
+static std::atomic<int> g_grad_ard{1};         // ibo_set_option("grad_ard", 0/1): the SE-ARD gradient kernel (0: the general one)
+void set_grad_ard(int v) { g_grad_ard = v; }
 int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double *X, int ldx, const double *Kinv, int ldk,
                      const double *alpha, double *partial, double *out, hipStream_t s)
 {
@@ -2652,6 +2741,14 @@ int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double 
     // at most 17 derivatives per pass (17 accumulators per thread: 64 VGPRs, no spills): beyond 16 dimensions the components go
     // in two passes that each rebuild K_ab -- the 33-accumulator instantiation needed 256 VGPRs, 232 spilled SGPRs, occupancy 1
     const int nblk = (int)(grid.x * grid.y);
+    // SE-ARD: the D length scales in order, then (optionally) the signal magnitude
+    bool ard = g_grad_ard && kp.family == FAM_SE && kp.D <= 32 && (gs.nh == kp.D || gs.nh == kp.D + 1);
+    for (int h = 0; ard && h < gs.nh; h++) ard = h < kp.D ? (gs.mode[h] == 0 && gs.dim[h] == h) : gs.mode[h] == 2;
+    if (ard) {
+        hipLaunchKernelGGL((nlml_grad_ard_kernel<33, 33>), grid, dim3(256), 0, s, kp, gs.nh, N, X, ldx, Kinv, ldk, alpha, partial);
+        hipLaunchKernelGGL(grad_reduce_kernel, dim3(gs.nh), dim3(256), 0, s, partial, nblk, out);
+        return (int)hipGetLastError();
+    }
     for (int h0 = 0; h0 < gs.nh; h0 += 17) {
         GradSpec part;
         part.nh = gs.nh - h0 < 17 ? gs.nh - h0 : 17;

@@ -1347,6 +1347,30 @@ def test_fit_covariance_pass_equals_the_general_kernel(ibo):
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
 
 
+def test_se_ard_gradient_kernel_equals_the_general_one(ibo):
+    """dnlml for SE-ARD kernels runs in its own kernel (two passes over the dimensions with the pairs' coordinates shared, lower tiles counted
+    twice): the general kernel's gradient to rounding, the same value, and the oracle's gradient"""
+    import oracle.oracle as orc
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+    for N, theta in ((130, [.3, .6]), (700, [.3, .4, .5, .6, .7]), (1100, list(np.linspace(.8, 1.6, 20)))):
+        D = len(theta)
+        X, Y = synth(N + D, N, D)
+        out = []
+        for fast in (0, 1):
+            _lib.check(_lib.lib.ibo_set_option(b"grad_ard", fast))
+            try:
+                out.append(marginalLikelihood(GaussianKernel_ard(theta), X, Y, D, True, noise=1e-2))
+            finally:
+                _lib.check(_lib.lib.ibo_set_option(b"grad_ard", 1))
+        g0, g1 = np.asarray(out[0][1]), np.asarray(out[1][1])
+        assert out[0][0] == out[1][0] and np.abs(g0 - g1).max() <= 1e-11 * np.abs(g0).max()
+        if N <= 700:
+            ov, od = orc.marginal_likelihood(orc.Kern("ard", theta), X, Y, D, True, 1e-2)
+            assert abs(out[1][0] - ov) <= 1e-9 * abs(ov) and np.abs(g1 - np.asarray(od)).max() <= 1e-8 * np.abs(od).max()
+
+
 def test_split_steps_equal_fused_steps(ibo):
     """fits of up to 2048 rows: software-pipelined block columns (a launch holds column j's row blocks and the rest of step
     j - 1's tiles), block columns as two launches (row blocks with the chain, then one product per tile), fused steps with two
