@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last fit: from the last cov_matrix_kernel on
 lastc = max(i for i, r in enumerate(rows) if 'chol_' in r['Kernel_Name'])
-last = max(i for i, r in enumerate(rows[:lastc]) if 'cov_matrix' in r['Kernel_Name'])      # the last fit's covariance pass (a later one is GP.R, formed on request)
+last = max(i for i, r in enumerate(rows[:lastc]) if 'cov_fit' in r['Kernel_Name'] or 'cov_matrix' in r['Kernel_Name'])      # the last fit's covariance pass (a later one is GP.R, formed on request)
 seq = [r for i, r in enumerate(rows[last:]) if i == 0 or 'cov_matrix' not in r['Kernel_Name']]
 t0 = int(seq[0]['Start_Timestamp'])
 tot = collections.OrderedDict()

@@ -9,7 +9,7 @@ import csv, glob
 f = glob.glob('gpurun_out/pipe_cols/t/*/*_kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 lastp = max(i for i, r in enumerate(rows) if 'chol_pipe8' in r['Kernel_Name'])
-last = max(i for i, r in enumerate(rows[:lastp]) if 'cov_matrix' in r['Kernel_Name'])      # the last fit's covariance pass (a later one is GP.R on request)
+last = max(i for i, r in enumerate(rows[:lastp]) if 'cov_fit' in r['Kernel_Name'] or 'cov_matrix' in r['Kernel_Name'])      # the last fit's covariance pass (a later one is GP.R on request)
 seq = [r for r in rows[last:] if 'chol_pipe8' in r['Kernel_Name']]
 t0 = int(rows[last]['Start_Timestamp'])
 print("column: grid (workgroups), duration us, gap to the previous launch us")
