@@ -1,7 +1,7 @@
 // Diagnostic: per-segment cycle stamps of chol_diag_kernel (built with -DIBO_STAMPS) on one 64x64 block.
 //   hipcc --offload-arch=gfx950 -O3 -DIBO_STAMPS -I ibo_amd/csrc tools/chol_diag_bench.hip -o tools/chol_diag_bench
 #include "../ibo_amd/csrc/linalg.hip"
-#include "../ibo_amd/csrc/update2.hip"
+#include "../ibo_amd/csrc/update3.hip"
 #include <cstdio>
 #include <vector>
 int main()
