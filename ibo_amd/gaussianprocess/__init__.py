@@ -356,6 +356,26 @@ class PrefGaussianProcess(GaussianProcess):
         if prefs is not None:
             self.addPreferences(prefs)
 
+    # GP.C (ego/gaussianprocess/__init__.py:476-486) is a public attribute, but nothing on the device path reads the dense N x N matrix: the
+    # device forms C, C^-1 and R + C^-1 from the pairs' entries (ibo_pref_finish).  It is built on the host when someone asks for it
+    # (np.eye(n) * 5 and four np.add.at passes were a quarter of an addPreferences call at 512 pairs).
+    @property
+    def C(self):
+        if self._C is None and self._C_spec is not None:
+            n, pv, pu, w, reg = self._C_spec
+            C = np.eye(n) * 5
+            np.add.at(C, (pv, pu), -w); np.add.at(C, (pu, pv), -w)
+            np.add.at(C, (pv, pv), w); np.add.at(C, (pu, pu), w)
+            for _ in range(reg):                  # the reference's regulariser, one identity at a time (:491-496)
+                C += np.eye(n)
+            self._C = C
+        return self._C
+
+    @C.setter
+    def C(self, value):
+        self._C = value
+        self._C_spec = None
+
     @staticmethod
     def _S_terms(y, Ry, v, u, w, hess=True):
         """MAP functional S(y) = -sum (d+1) log(Phi((y_v-y_u)/sqrt 2) + 1e-10) + y^T R^-1 y / 2
@@ -510,10 +530,8 @@ class PrefGaussianProcess(GaussianProcess):
         cdf = np.maximum(CDF(d), 1e-10)
         pdf = np.maximum(PDF(d), 1e-10)
         w = 1.0 / (2 * self.noise) * (pdf ** 2 / cdf ** 2 + d * pdf / cdf)
-        C = np.eye(n) * 5
-        np.add.at(C, (pv, pu), -w); np.add.at(C, (pu, pv), -w)
-        np.add.at(C, (pv, pv), w); np.add.at(C, (pu, pu), w)
-        self.C = C
+        self.C = None
+        self._C_spec = (n, pv, pu, w, 0)             # GP.C, formed when read (the property above)
         # L = chol(R + C^-1) (:488-497): C, its inverse and the sum are formed on the device from the pairs' entries
         # (ibo_pref_finish); a C too ill-conditioned to factor gets the reference's regulariser, one identity at a time
         import ctypes
@@ -526,7 +544,8 @@ class PrefGaussianProcess(GaussianProcess):
                                           5.0 + i, ctypes.byref(info))
             if rc == _lib.ERR_NOT_PD:
                 print('[addPreferences] GP.C matrix is ill-conditioned, adding regularizer delta = %d' % (i + 1))
-                self.C += np.eye(n)
+                self.C = None
+                self._C_spec = (n, pv, pu, w, i + 1)
                 continue
             _lib.check(rc)
             break
