@@ -2633,20 +2633,21 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs,
     if (t < gs.nh) partial[(size_t)t * gridDim.x * gridDim.y + blk] = ((red[t][0] + red[t][1]) + red[t][2]) + red[t][3];
 }
 
-// The SE-ARD case by itself (round 4): derivatives 0 .. D - 1 are the D length scales in order (dK_h = K_ab w_h u_h^2), optionally followed by
-// the signal magnitude (2 K_ab).  The general kernel reads both points' coordinates from LDS once per pair and dimension and again per
-// derivative, and walks a switch per pair and derivative -- ~1000 LDS reads per thread, 530 us at N = 4096, D = 16 for 0.8 GFLOP.  Here a
-// thread's 4 x 4 pairs share their eight points' coordinates per dimension (8 LDS reads for 16 pairs), in two passes over the dimensions:
-// z_ab, then -- with t_ab = (K^-1 - alpha alpha^T)_ab K_ab known -- acc_d += sum_pairs t_ab w_d u_d^2.  The sum over (a, b) is symmetric:
-// tiles above the diagonal contribute nothing, tiles below it count twice (an exact scaling).
+// The gradient kernel of round 4.  The first one (above) reads both points' coordinates from LDS once per pair and dimension and again per
+// derivative, and walks a switch per pair and derivative -- ~1000 LDS reads per thread, 530 us at N = 4096, D = 16 for 0.8 GFLOP, two passes
+// beyond 16 dimensions.  Here a thread's 4 x 4 pairs share their eight points' coordinates per dimension (8 LDS reads for 16 pairs): one pass
+// over the dimensions gives z_ab (and the unscaled |x_a - x_b|^2 the Matern-3/2 derivative uses), then t_ab = (K^-1 - alpha alpha^T)_ab K_ab,
+// then one short loop per derivative: a length scale of an ARD kernel is one more pass over ITS dimension (acc_h = sum_pairs t_ab w_h u_h^2),
+// the others need only z, d2 and K.  The sum over (a, b) is symmetric: tiles above the diagonal contribute nothing, tiles below it count
+// twice (an exact scaling).  Per-workgroup partial sums in a fixed order, as before.
 template <int GM, int LD>
-__global__ __launch_bounds__(256) void nlml_grad_ard_kernel(KParams kp, int nh, int N, const double *__restrict__ X, int ldx,
-                                                            const double *__restrict__ Kinv, int ldk, const double *__restrict__ alpha,
-                                                            double *__restrict__ partial)
+__global__ __launch_bounds__(256) void nlml_grad_fast_kernel(KParams kp, GradSpec gs, int N, const double *__restrict__ X, int ldx,
+                                                             const double *__restrict__ Kinv, int ldk, const double *__restrict__ alpha,
+                                                             double *__restrict__ partial)
 {
     __shared__ double As[64 * LD], Bs[64 * LD], ala[64], alb[64];
     __shared__ double red[GM][4];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, D = kp.D;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, D = kp.D, nh = gs.nh;
     const int b0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     if (blockIdx.x > blockIdx.y) {                              // (b-block > a-block: its mirror image carries the weight)
@@ -2670,7 +2671,7 @@ __global__ __launch_bounds__(256) void nlml_grad_ard_kernel(KParams kp, int nh, 
             wm[r][c] = (a < N && b < N) ? Kinv[(size_t)(a > b ? a : b) * ldk + (a > b ? b : a)] : 0.0;
         }
     __syncthreads();
-    double z[4][4] = {};
+    double z[4][4] = {}, d2[4][4] = {};
     for (int d = 0; d < D; d++) {
         const double w = kp.w[d];
         double av[4], bv[4];
@@ -2681,40 +2682,61 @@ __global__ __launch_bounds__(256) void nlml_grad_ard_kernel(KParams kp, int nh, 
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) { const double u = av[r] - bv[c]; z[r][c] += w * (u * u); }
+            for (int c = 0; c < 4; c++) { const double u = av[r] - bv[c]; z[r][c] += w * (u * u); d2[r][c] += u * u; }
     }
-    double tsum = 0.0;
+    double tt[4][4], kk[4][4];                                  // t_ab = (K^-1 - alpha alpha^T)_ab K_ab and (K^-1 - alpha alpha^T)_ab (0 off the matrix)
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int a = a0 + ty * 4 + r, b = b0 + tx + 16 * c;
             const double kab = cov_from_z_rt(kp.family, z[r][c], kp.sf2);
-            const double tt = (a < N && b < N) ? (wm[r][c] - ala[ty * 4 + r] * alb[tx + 16 * c]) * kab : 0.0;
-            z[r][c] = tt;                                       // t_ab
-            tsum += tt;
+            const bool in = a < N && b < N;
+            kk[r][c] = in ? wm[r][c] - ala[ty * 4 + r] * alb[tx + 16 * c] : 0.0;
+            tt[r][c] = kk[r][c] * kab;
         }
     const int lane = t & 63, wave = t >> 6;
     const double scale = blockIdx.x < blockIdx.y ? 2.0 : 1.0;
-    for (int d = 0; d < D; d++) {
-        const double w = kp.w[d];
-        double av[4], bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) av[r] = As[(ty * 4 + r) * LD + d];
-#pragma unroll
-        for (int c = 0; c < 4; c++) bv[c] = Bs[(tx + 16 * c) * LD + d];
+    for (int h = 0; h < nh; h++) {
+        const int mode = gs.mode[h];
         double s = 0.0;
+        if (mode == 0) {                                        // SE-ARD length scale of dimension dim[h]: dK = K w u^2
+            const int d = gs.dim[h];
+            const double w = kp.w[d];
+            double av[4], bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+            for (int r = 0; r < 4; r++) av[r] = As[(ty * 4 + r) * LD + d];
 #pragma unroll
-            for (int c = 0; c < 4; c++) { const double u = av[r] - bv[c]; s = fma(z[r][c], w * (u * u), s); }
+            for (int c = 0; c < 4; c++) bv[c] = Bs[(tx + 16 * c) * LD + d];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) { const double u = av[r] - bv[c]; s = fma(tt[r][c], w * (u * u), s); }
+        } else if (mode == 1) {                                 // SE-iso length scale: dK = K z
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) s = fma(tt[r][c], z[r][c], s);
+        } else if (mode == 2) {                                 // signal magnitude: dK = 2 K
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) s += tt[r][c];
+            s *= 2.0;
+        } else {                                                // Matern length scales, as the reference's derivative() has them (quirks included)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int a = a0 + ty * 4 + r, b = b0 + tx + 16 * c;
+                    double dk;
+                    if (mode == 3) { const double r3 = sqrt(d2[r][c]); dk = kp.sf2 * r3 * r3 * exp(-r3); }
+                    else { const double zz = 5.0 * z[r][c], q = sqrt(zz); dk = kp.sf2 * (zz + q * q * q) * exp(-q) / 3.0; }
+                    s = fma(kk[r][c], (a == b) ? 0.0 : dk, s);
+                }
+        }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) red[d][wave] = s;
-    }
-    if (nh > D) {                                               // the signal magnitude: dK = 2 K
-        double s = 2.0 * tsum;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) red[D][wave] = s;
+        if (lane == 0) red[h][wave] = s;
     }
     __syncthreads();
     if (t < nh) partial[(size_t)t * gridDim.x * gridDim.y + blk] = scale * (((red[t][0] + red[t][1]) + red[t][2]) + red[t][3]);
@@ -2741,11 +2763,9 @@ int launch_nlml_grad(const KParams &kp, const GradSpec &gs, int N, const double 
     // at most 17 derivatives per pass (17 accumulators per thread: 64 VGPRs, no spills): beyond 16 dimensions the components go
     // in two passes that each rebuild K_ab -- the 33-accumulator instantiation needed 256 VGPRs, 232 spilled SGPRs, occupancy 1
     const int nblk = (int)(grid.x * grid.y);
-    // SE-ARD: the D length scales in order, then (optionally) the signal magnitude
-    bool ard = g_grad_ard && kp.family == FAM_SE && kp.D <= 32 && (gs.nh == kp.D || gs.nh == kp.D + 1);
-    for (int h = 0; ard && h < gs.nh; h++) ard = h < kp.D ? (gs.mode[h] == 0 && gs.dim[h] == h) : gs.mode[h] == 2;
-    if (ard) {
-        hipLaunchKernelGGL((nlml_grad_ard_kernel<33, 33>), grid, dim3(256), 0, s, kp, gs.nh, N, X, ldx, Kinv, ldk, alpha, partial);
+    if (g_grad_ard && gs.nh <= 33) {                    // the round-4 kernel ("grad_ard" = 0: the first one, below)
+        if (kp.D <= 32) hipLaunchKernelGGL((nlml_grad_fast_kernel<33, 33>), grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
+        else hipLaunchKernelGGL((nlml_grad_fast_kernel<33, 65>), grid, dim3(256), 0, s, kp, gs, N, X, ldx, Kinv, ldk, alpha, partial);
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(gs.nh), dim3(256), 0, s, partial, nblk, out);
         return (int)hipGetLastError();
     }

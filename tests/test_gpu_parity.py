@@ -1348,8 +1348,8 @@ def test_fit_covariance_pass_equals_the_general_kernel(ibo):
 
 
 def test_se_ard_gradient_kernel_equals_the_general_one(ibo):
-    """dnlml for SE-ARD kernels runs in its own kernel (two passes over the dimensions with the pairs' coordinates shared, lower tiles counted
-    twice): the general kernel's gradient to rounding, the same value, and the oracle's gradient"""
+    """dnlml runs in the round-4 kernel (the pairs' coordinates shared over a thread's 4 x 4 pairs, one short loop per derivative, lower tiles
+    counted twice): the first kernel's gradient to rounding, the same value, and the oracle's gradient -- SE-ARD here, the other families below"""
     import oracle.oracle as orc
     from ibo_amd import _lib
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
@@ -1369,6 +1369,19 @@ def test_se_ard_gradient_kernel_equals_the_general_one(ibo):
         if N <= 700:
             ov, od = orc.marginal_likelihood(orc.Kern("ard", theta), X, Y, D, True, 1e-2)
             assert abs(out[1][0] - ov) <= 1e-9 * abs(ov) and np.abs(g1 - np.asarray(od)).max() <= 1e-8 * np.abs(od).max()
+    # SE-iso with signal variance, Matern-3/2, Matern-5/2 (one length scale each; test_g2_g8_marginal_likelihood holds them to the reference's values)
+    from ibo_amd.gaussianprocess import kernel as K
+    X, Y = synth(905, 900, 4)
+    for k, nh in ((K.SVGaussianKernel_iso([.7, 1.3]), 2), (K.MaternKernel3([.8, 1.1]), 2), (K.MaternKernel5([.9, 1.2]), 2), (K.GaussianKernel_iso([.6]), 1)):
+        out = []
+        for fast in (0, 1):
+            _lib.check(_lib.lib.ibo_set_option(b"grad_ard", fast))
+            try:
+                out.append(marginalLikelihood(k, X, Y, nh, True, noise=1e-2))
+            finally:
+                _lib.check(_lib.lib.ibo_set_option(b"grad_ard", 1))
+        g0, g1 = np.atleast_1d(out[0][1]), np.atleast_1d(out[1][1])
+        assert out[0][0] == out[1][0] and np.abs(g0 - g1).max() <= 1e-11 * np.abs(g0).max()
 
 
 def test_split_steps_equal_fused_steps(ibo):
