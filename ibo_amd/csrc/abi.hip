@@ -314,6 +314,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (key && !strcmp(key, "pipe_pairs")) { set_pipe_pairs(value); return IBO_OK; }
     if (key && !strcmp(key, "cov_fit")) { g_cov_fit = value; return IBO_OK; }
     if (key && !strcmp(key, "wtw_waves")) { set_wtw_waves(value); return IBO_OK; }
+    if (key && !strcmp(key, "wtw_xcd")) { set_wtw_xcd(value); return IBO_OK; }
     if (key && !strcmp(key, "grad_ard")) { set_grad_ard(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_pipe")) { set_chol_pipe(value); return IBO_OK; }
     if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }

@@ -279,6 +279,7 @@ void set_step_split(int v);
 void set_step_waves(int v);
 void set_pipe_pairs(int v);
 void set_wtw_waves(int v);
+void set_wtw_xcd(int v);
 void set_grad_ard(int v);
 void set_chol_pipe(int v);
 void set_chol_panel_rows(int v);

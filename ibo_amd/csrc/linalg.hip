@@ -2529,12 +2529,26 @@ __global__ void transpose_kernel(const double *__restrict__ A, double *__restric
 
 template <int NW>                                               // four or eight waves per 64 x 64 tile: the same MFMAs in the same order per element
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, NW == 4 ? 2 : 4)))
-void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W, double *__restrict__ C, int Npad, int lower_only)
+void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W, double *__restrict__ C, int Npad, int lower_only, int nsb)
 {
     __shared__ double As[64 * T64_LD];
     __shared__ double Bs[64 * TNN_LD];
     TILE_IDS;
-    int ti = blockIdx.y, tj = blockIdx.x;
+    int ti, tj;
+    if (nsb > 0) {
+        // XCD-aware tile order (as chol_update_kernel): workgroup b runs on XCD b % 8 and that XCD's 64 consecutive workgroups take one 8 x 8
+        // super-block of tiles -- 8 strips of W^T and 8 of W serve 64 tiles out of that XCD's L2 instead of every tile pulling its own 64 KiB per
+        // stage through the fabric (at N = 4096: 2.9 GB in 0.8 ms, which is what the fabric gives).  Super-blocks by rows, the longest K ranges first.
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int sb = (q >> 6) * 8 + xcd, lt = q & 63;
+        if (sb >= nsb) return;
+        const int nsr = (Npad / 64 + 7) / 8;
+        int SI, SJ;
+        if (lower_only) { SI = 0; int rem = sb; while (rem > SI) { rem -= SI + 1; SI++; } SJ = rem; }       // (SI, SJ <= SI) row by row
+        else { SI = sb / nsr; SJ = sb % nsr; }
+        ti = 8 * SI + (lt >> 3); tj = 8 * SJ + (lt & 7);
+        if (ti >= Npad / 64 || tj >= Npad / 64) return;
+    } else { ti = blockIdx.y; tj = blockIdx.x; }
     if (lower_only && tj > ti) return;                          // the caller reads C[max(i,j)][min(i,j)] (C is symmetric, bit for bit)
     const double *A = Wt + (size_t)ti * 64 * Npad;              // rows i of W^T, all k
     const double *B = W + (size_t)tj * 64;                      // columns j of W
@@ -2550,6 +2564,8 @@ void wtw_kernel(const double *__restrict__ Wt, const double *__restrict__ W, dou
 }
 static std::atomic<int> g_wtw_waves{8};         // ibo_set_option("wtw_waves", 4/8)
 void set_wtw_waves(int v) { g_wtw_waves = v; }
+static std::atomic<int> g_wtw_xcd{32};          // ibo_set_option("wtw_xcd"): block rows from which W^T W's tiles are dealt to the XCDs in 8 x 8 super-blocks (0: never)
+void set_wtw_xcd(int v) { g_wtw_xcd = v; }
 
 // wt_ready: Wt already holds W^T on and right of the diagonal blocks (the ride-along's (L^-1)^T as the factorisation leaves it: the blocks
 // left of the diagonal, which it never writes, are never read here) -- no transpose pass
@@ -2557,8 +2573,14 @@ int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, 
 {
     dim3 g(Npad / 64, Npad / 64);
     if (!wt_ready) hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, s, W, Wt, Npad);
-    if (g_wtw_waves == 8) hipLaunchKernelGGL(wtw_kernel<8>, g, dim3(512), 0, s, Wt, W, C, Npad, lower_only);
-    else hipLaunchKernelGGL(wtw_kernel<4>, g, dim3(256), 0, s, Wt, W, C, Npad, lower_only);
+    int nsb = 0;
+    if (g_wtw_xcd && Npad / 64 >= g_wtw_xcd) {                  // enough tiles that the operands do not stay in L2 by themselves
+        const int nsr = (Npad / 64 + 7) / 8;
+        nsb = lower_only ? nsr * (nsr + 1) / 2 : nsr * nsr;
+        g = dim3((unsigned)((nsb + 7) / 8) * 512);
+    }
+    if (g_wtw_waves == 8) hipLaunchKernelGGL(wtw_kernel<8>, g, dim3(512), 0, s, Wt, W, C, Npad, lower_only, nsb);
+    else hipLaunchKernelGGL(wtw_kernel<4>, g, dim3(256), 0, s, Wt, W, C, Npad, lower_only, nsb);
     return (int)hipGetLastError();
 }
 

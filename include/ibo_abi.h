@@ -93,7 +93,8 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * "trinv_wide" (eight-wave tiles in the small levels of the triangular inversion), "update2_min_tiles", "fused2_min_nb" (block columns from which a fit takes the two-level order: 104; the order fixes
  * the rounding of L and W, so results at 2049 .. 6592 rows differ from ABI 5's in the last bits), "pipe_pairs" (block columns from which the
  * pipelined order applies two steps per pass over the trailing tiles: 12; same bits either way), "cov_fit" (the fit's own covariance pass; same bits).
- * ibo_nlml_grad: "wtw_waves" 4/8 (waves per tile of K^-1 = W^T W; same bits), "grad_ard" 0/1 (the round-4 gradient kernel; 0: the first one --
+ * ibo_nlml_grad: "wtw_waves" 4/8 (waves per tile of K^-1 = W^T W; same bits), "wtw_xcd" (block rows from which its tiles are dealt to the XCDs in
+ * 8 x 8 super-blocks: 32; same bits), "grad_ard" 0/1 (the round-4 gradient kernel; 0: the first one --
  * the same value, the gradient to rounding).
  * ibo_nlml_grid (same values whatever the setting, except "cov_fast", which changes the covariance entries by a rounding error):
  * "chol_left" (left-looking outer order from one packed copy of the factor), "nlml_groups" (sub-batches on their own streams),
