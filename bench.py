@@ -532,8 +532,9 @@ def worker(args):
                 else:
                     gal = sharded_gallery(GP3, [[0., 1.]] * C3_D, 8, cand3, start3, comm)
                 gms_all.append(max_over_ranks((time.perf_counter() - t0) * 1e3))
-            # "ms": the first call, as rounds 1 and 2 reported it (the only call then); "warm_ms": a second call on the same model
-            gms, gms_warm = gms_all[0], gms_all[1]
+            # "ms": the warm (second) call on the same model, "first_call_ms": the first one -- BENCH_r03's keys and meaning (BENCH_r04 had
+            # them swapped under "ms" / "warm_ms": compare that round through "first_call_ms")
+            gms_first, gms = gms_all[0], gms_all[1]
             if rank == 0:
                 k3 = float(np.mean([o[2] for o in o3])) * 1e-3
                 gal = np.array(gal)
@@ -547,7 +548,8 @@ def worker(args):
                                            "c3", float(C3_SHARD))}
                 cfgs["c3_gallery8"] = {"workload": "fastUCBGallery(N=8) on the same GP and shard(s): 7 rounds of DIRECT + "
                                                    "sharded sweep + exchange + hallucinated addData",
-                                       "ms": gms, "warm_ms": gms_warm, "min_pairwise_distance": float(min(
+                                       "ms": gms, "first_call_ms": gms_first, "ms_key_means": "second call on the same model (as in round 3; round 4 stored the first call here)",
+                                       "min_pairwise_distance": float(min(
                                            np.linalg.norm(gal[i] - gal[j]) for i in range(8) for j in range(i)))}
             del GP3, cand3
             # C5: 64 theta-points per GPU
@@ -586,8 +588,47 @@ def worker(args):
                     g4.append((time.perf_counter() - t0) * 1e3)
                 cfgs["c4_prefgp"] = {"workload": "PrefGaussianProcess, 512 pairs -> 1024 points, D=6; gallery of 8 over 2^20 candidates",
                                      "addPreferences_ms": pms, "addPreferences_first_call_ms": pref_ms[0],
-                                     "gallery8_ms": g4[0], "gallery8_warm_ms": g4[1]}
+                                     "gallery8_ms": g4[1], "gallery8_first_call_ms": g4[0]}
                 del PG, cand4
+                # The drop-in symbol acqmaxGP (include/ibo_abi.h section A) as the reference's cdirectGP calls it
+                # (ego/acquisition/__init__.py:385-436: inv(R) formed by the caller, default budget 50 iterations / 10 000 samples), at
+                # C2's and C3's model sizes, both routes: "exact" = libego's operation order (csrc/legacy.hip, the default: the
+                # reference's numbers bit for bit), "fast" = inv(R) factored on the device + the MFMA sweep kernels (within 1e-6 of
+                # libego on well-conditioned data only).  Whole-call wall time, host buffers in (the 8 N^2-byte inv(R) upload included).
+                import ctypes as _ct0
+                libc = _ct0.CDLL(None); libc.free.argtypes = [_ct0.c_void_p]
+
+                def legacy_ms(Xl, Yl, kern, ktype, hyper, what):
+                    g = GaussianProcess(kern, Xl, Yl, noise=.1, device=local_rank)
+                    invR = _lib.f64(np.linalg.inv(np.array(g.R)))
+                    d = Xl.shape[1]
+                    lb, ub, Xc, Yc, hy, one = _lib.f64([0.] * d), _lib.f64([1.] * d), _lib.f64(Xl), _lib.f64(Yl), _lib.f64(hyper), _lib.f64([0.])
+                    res = {"workload": what}
+                    for route, key in ((1, "exact"), (0, "fast")):
+                        _lib.check(_lib.lib.ibo_set_option(b"legacy_exact", route))
+                        ms = []
+                        try:
+                            for _ in range(4):
+                                t0 = time.perf_counter()
+                                r = _lib.lib.acqmaxGP(d, _lib.dp(lb), _lib.dp(ub), _lib.dp(invR), _lib.dp(Xc), _lib.dp(Yc), len(Yc), 0, ktype, _lib.dp(hy),
+                                                      0, _lib.dp(one), _lib.dp(one), 0., _lib.dp(one), _lib.dp(one), .01, .1, 50, 30, 10000)
+                                ms.append((time.perf_counter() - t0) * 1e3)
+                                if not bool(r):
+                                    raise RuntimeError("acqmaxGP returned NULL")
+                                res[key + "_EI"] = -r[0]
+                                libc.free(r)
+                        finally:
+                            _lib.check(_lib.lib.ibo_set_option(b"legacy_exact", 1))
+                        res[key + "_ms"] = float(np.median(ms[1:]))
+                    res["rel_diff_fast_vs_exact"] = float(abs(res["fast_EI"] - res["exact_EI"]) / max(abs(res["exact_EI"]), 1e-300))
+                    res["default_route"] = "exact"
+                    return res
+                Xl, Yl = synth(2, N_OBS, DIM)
+                cfgs["legacy_acqmaxGP_c2"] = legacy_ms(Xl, Yl, GaussianKernel_ard([.3] * DIM), 0, [.3] * DIM,
+                                                       "acqmaxGP, EI xi=.01, N=1024, D=4, SE-ARD, noise .1, maxiter 50 / maxsample 10000, inv(R) from the host")
+                Xl, Yl = synth(3, C3_N, C3_D)
+                cfgs["legacy_acqmaxGP_c3"] = legacy_ms(Xl, Yl, MaternKernel5([.5, 1.0]), 3, [.5, 1.0],
+                                                       "acqmaxGP, EI xi=.01, N=2048, D=8, Matern-5/2, noise .1, maxiter 50 / maxsample 10000, inv(R) from the host")
                 # the sweep kernel against the input dimension (N = 1024, 2^18 candidates: a quarter of the headline batch, so the
                 # tail of the tile rounds weighs more): D = 17..32 take a 32-coordinate row layout and 6..9 k4-steps of the exponent GEMM
                 from ibo_amd.acquisition import sweep as _sweep

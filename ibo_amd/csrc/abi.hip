@@ -1830,63 +1830,50 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
 }
 
 // ------------------------------------------------------------------------ libego's arithmetic in libego's order (legacy.hip)
-struct LegacyModel {
-    int ndim, nx, acqfunc, kerneltype, npbases;
-    const double *X, *Y, *hyper, *pmeans, *pbeta, *plowerb, *pwidth;
-    double sf2, ptheta, parm, noise;
-};
-
 // DIRECT (same host search as every other entry point, libego's dimension-0 quirk on) over an objective whose every number is
-// libego's: k*, the prior mean and the acquisition on the host's libm, the two N^2 contractions per point on the device in
-// libego's summation order.  Without a prior the first contraction's inner vector inv(R) Y is the same for every point:
-// formed once.  Buffers: the handle's (MT in g->W, vectors in g->cand / g->outs / g->tmp, pinned staging).
-static int legacy_direct(ibo_gp *g, const LegacyModel &m, const double *invR_host, const double *lb, const double *ub,
+// libego's: k*, the prior mean and the acquisition on the host's libm (LegacyHost, a crew of host threads over the batch's
+// points), the two N^2 contractions per point on the device in libego's summation order.  Without a prior the first
+// contraction's inner vector inv(R) Y is the same for every point: formed once.  Buffers: the handle's (MT in g->W, vectors in
+// g->cand / g->outs / g->tmp, pinned staging).
+static int legacy_direct(ibo_gp *g, const LegacySpec &m, const double *invR_host, const double *lb, const double *ub,
                          int maxiter, int maxtime, int maxsample, double *fmin, double *xmin)
 {
     IBO_TRY(use_device(g->device));
-    const int N = m.nx, D = m.ndim;
-    if (N < 1 || D < 1 || !invR_host || !m.X || !m.Y || !m.hyper) return fail(IBO_ERR_ARG, "bad argument");
+    const int N = m.rows, D = m.dim;
+    if (N < 1 || D < 1 || !invR_host || !m.obs || !m.targets || !m.hyper) return fail(IBO_ERR_ARG, "bad argument");
     hipStream_t s = g->stream;
     const size_t nn = (size_t)N * N;
     IBO_TRY(g->A.ensure(nn)); IBO_TRY(g->W.ensure(nn)); IBO_TRY(g->Y.ensure(2 * (size_t)N));
     HIP_TRY(hipMemcpyAsync(g->A.p, invR_host, sizeof(double) * nn, hipMemcpyHostToDevice, s));
     KERNEL_TRY(launch_legacy_transpose(g->A.p, g->W.p, N, s));
-    double maxY = m.Y[0];
-    for (int i = 0; i < N; i++) if (m.Y[i] > maxY) maxY = m.Y[i];                       // cpp/optimizeGP.cpp:316-321
+    const bool prior = m.nbasis > 0;
     double *MbY = g->Y.p + N;                                                            // inv(R) Y in libego's order (no prior)
-    if (m.npbases <= 0) {
-        HIP_TRY(hipMemcpyAsync(g->Y.p, m.Y, sizeof(double) * N, hipMemcpyHostToDevice, s));
+    if (!prior) {
+        HIP_TRY(hipMemcpyAsync(g->Y.p, m.targets, sizeof(double) * N, hipMemcpyHostToDevice, s));
         IBO_TRY(g->outs.ensure(1));
         // (the matvec half of aMb; its dot half runs per point against that point's r)
         KERNEL_TRY(launch_legacy_aMb(g->W.p, g->Y.p, g->Y.p, MbY, g->outs.p, N, 1, s));
     }
+    LegacyHost host(m);
     std::vector<double> pmu;
     ibo::batch_eval_t ev = [&](const double *pts, int n, double *vals) -> int {
         // per point: r (and Y - m under a prior) from the host; vectors B = [r | ymu], A = [r | r]
-        const int nvec = m.npbases > 0 ? 2 * n : n;
+        const int nvec = prior ? 2 * n : n;
         const size_t vb = (size_t)nvec * N;
         IBO_TRY(ensure_pinned(g, vb + 2 * (size_t)n));
         IBO_TRY(g->cand.ensure(vb)); IBO_TRY(g->tmp.ensure(vb + (size_t)n * N)); IBO_TRY(g->outs.ensure(2 * (size_t)n + 1));
         double *hB = g->pin, *hout = g->pin + vb;
-        pmu.assign(n, 0.0);
-        for (int p = 0; p < n; p++) {
-            const double *x = pts + (size_t)p * D;
-            legacy_kstar(m.kerneltype, D, N, m.X, m.hyper, m.sf2, x, hB + (size_t)p * N);
-            if (m.npbases > 0) {
-                pmu[p] = legacy_prior_mean(D, x, m.npbases, m.pmeans, m.pbeta, m.ptheta, m.plowerb, m.pwidth);
-                double *ymu = hB + (size_t)(n + p) * N;
-                for (int i = 0; i < N; i++) ymu[i] = m.Y[i] - pmu[p];
-            }
-        }
+        pmu.resize(n);
+        host.prepare(pts, n, hB, pmu.data());
         HIP_TRY(hipMemcpyAsync(g->cand.p, hB, sizeof(double) * vb, hipMemcpyHostToDevice, s));
         double *dB = g->cand.p, *dMb = g->tmp.p, *dout = g->outs.p + 1;
         // x2 = aMb(r, invR, r) for every point; x1 = aMb(r, invR, ymu) under a prior, else the dot of r with the cached inv(R) Y
         KERNEL_TRY(launch_legacy_aMb(g->W.p, dB, dB, dMb, dout + n, N, n, s));
-        if (m.npbases > 0) KERNEL_TRY(launch_legacy_aMb(g->W.p, dB + (size_t)n * N, dB, dMb + (size_t)n * N, dout, N, n, s));
+        if (prior) KERNEL_TRY(launch_legacy_aMb(g->W.p, dB + (size_t)n * N, dB, dMb + (size_t)n * N, dout, N, n, s));
         else KERNEL_TRY(launch_legacy_dots(MbY, dB, dout, N, n, s));
         HIP_TRY(hipMemcpyAsync(hout, dout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        for (int p = 0; p < n; p++) vals[p] = legacy_neg_acq(m.acqfunc, pmu[p], hout[p], hout[n + p], m.noise, maxY, m.parm);
+        for (int p = 0; p < n; p++) vals[p] = host.negated(pmu[p], hout[p], hout[n + p]);
         return 0;
     };
     ibo::DirectOptions o;
@@ -1909,6 +1896,11 @@ extern "C" const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR
         printf("[C++] unknown acquisition function\n");     // cpp/optimizeGP.cpp:342-345
         return NULL;
     }
+    if (kerneltype < 0 || kerneltype > 3) {
+        // the reference's switch has no such case and would evaluate uninitialised k* values (cpp/optimizeGP.cpp:67-113): refused
+        fprintf(stderr, "[libibo_hip] acqmaxGP: unknown kernel type %d\n", kerneltype);
+        return NULL;
+    }
     ibo_gp *g = nullptr;
     int dev = 0;
     const char *e = getenv("IBO_DEVICE");
@@ -1923,11 +1915,11 @@ extern "C" const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR
     double *res = nullptr;
     int rc;
     if (g_legacy_exact) {
-        LegacyModel m;
-        m.ndim = ndim; m.nx = nx; m.acqfunc = acqfunc; m.kerneltype = kerneltype; m.X = X; m.Y = Y; m.hyper = hyperparams;
-        m.sf2 = kerneltype == IBO_K_MATERN5 ? exp(2.0 * log(hyperparams[1])) : 1.0;      // (cpp/optimizeGP.cpp:303-314)
-        m.npbases = npbases; m.pmeans = pbasismeans; m.pbeta = pbasisbeta; m.ptheta = pbasistheta; m.plowerb = pbasislowerb; m.pwidth = pbasiswidth;
-        m.parm = parm; m.noise = noise;
+        LegacySpec m;
+        m.family = kerneltype; m.dim = ndim; m.rows = nx; m.obs = X; m.targets = Y; m.hyper = hyperparams;
+        m.amp = kerneltype == IBO_K_MATERN5 ? exp(2.0 * log(hyperparams[1])) : 1.0;      // (cpp/optimizeGP.cpp:303-314)
+        m.nbasis = npbases; m.centres = pbasismeans; m.weights = pbasisbeta; m.sharpness = pbasistheta; m.origin = pbasislowerb; m.extent = pbasiswidth;
+        m.acq = acqfunc; m.parm = parm; m.noise = noise;
         std::vector<double> xo(ndim);
         double fmin = 0.0;
         rc = legacy_direct(g, m, invR, lb, ub, maxiter, maxtime, maxsample, &fmin, xo.data());

@@ -23,8 +23,15 @@
 #include "ibo_common.h"
 #include "legacy.h"
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <sched.h>
+#include <thread>
 #include <vector>
 
 #pragma clang fp contract(off)     // host and device code of this file: no fused multiply-add, anywhere
@@ -104,65 +111,201 @@ int launch_legacy_dots(const double *Mb, const double *A, double *out, int N, in
     return (int)hipGetLastError();
 }
 
-// ---- host side: the statements of cpp/optimizeGP.cpp in their order, with the host's libm --------------------------------
-// r[i] = k(x, X_i) (cpp/optimizeGP.cpp:67-113).  Kernel type 3 reads its magnitude from hyperparams[1] (the reference reads
-// hyperparams[ndim], out of bounds unless ndim = 1, and prints every value: DESIGN 7 -- both deviations are kept out).
-static inline double sq(double v) { return v * v; }     // pow(v, 2): libstdc++'s pow(double, int) is __builtin_powi = v * v
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+// What is shared with cpp/optimizeGP.cpp:67-236 is the ROUNDING SEQUENCE of every number, nothing else: each double below goes
+// through the same IEEE operations in the same order as the reference's (the bit-for-bit tests against the compiled reference are
+// the guard), under -ffp-contract=off, with the host's libm for exp / sqrt / erf.  Quantities that do not depend on the sample
+// point (1 / h_d^2, sqrt 3, sqrt 5, 3 h^2) are formed once per call -- a rounded operation gives the same double whenever it runs.
+namespace {
 
-void legacy_kstar(int kerneltype, int NA, int NX, const double *X, const double *hyperparams, double sf2, const double *x, double *r)
+// one kernel family = how a coordinate difference enters the running sum, and what the sum becomes
+template <int FAMILY> struct Radial;
+template <> struct Radial<0> {                       // squared exponential, one length scale per dimension: sum w_d (d_d^2), w_d = 1 / h_d^2
+    static double step(double sum, double diff, double w) { const double d2 = diff * diff; const double t = w * d2; return sum + t; }
+    static double shape(double sum, double amp, const LegacyHost::Consts &) { return amp * exp(-.5 * sum); }
+};
+template <> struct Radial<1> {                       // squared exponential, one length scale: sum (d_d / h)^2
+    static double step(double sum, double diff, double h) { const double q = diff / h; return sum + q * q; }
+    static double shape(double sum, double amp, const LegacyHost::Consts &) { return amp * exp(-.5 * sum); }
+};
+template <> struct Radial<2> {                       // Matern-3/2 in s = sqrt 3 * sqrt(sum (d_d / h)^2)
+    static double step(double sum, double diff, double h) { return Radial<1>::step(sum, diff, h); }
+    static double shape(double sum, double amp, const LegacyHost::Consts &c)
+    {
+        const double s = c.root3 * sqrt(sum);
+        return amp * (1.0 + s) * exp(-s);
+    }
+};
+template <> struct Radial<3> {                       // Matern-5/2 in the unscaled distance: amp (1 + a + 5 r^2 / (3 h^2)) e^-a, a = sqrt 5 r / h
+    static double step(double sum, double diff, double) { return sum + diff * diff; }
+    static double shape(double sum, double amp, const LegacyHost::Consts &c)
+    {
+        const double dist = sqrt(sum);
+        const double a = c.root5 * dist / c.h;
+        const double quad = 5.0 * dist * dist / c.three_h2;
+        return amp * (1.0 + a + quad) * exp(-a);
+    }
+};
+
+template <int FAMILY>
+void kstar_rows(const LegacyHost::Consts &c, double amp, int dim, const double *obs, int row0, int row1, const double *pt, double *out)
 {
-    for (int i = 0; i < NX; i++) {
-        double z = 0;
-        switch (kerneltype) {
-        case 0:
-            for (int j = 0; j < NA; j++) z += 1 / sq(hyperparams[j]) * sq(X[NA * i + j] - x[j]);
-            r[i] = sf2 * exp(-.5 * z);
-            break;
-        case 1:
-            for (int j = 0; j < NA; j++) z += sq((X[NA * i + j] - x[j]) / hyperparams[0]);
-            r[i] = sf2 * exp(-.5 * z);
-            break;
-        case 2:
-            for (int j = 0; j < NA; j++) z += sq((X[NA * i + j] - x[j]) / hyperparams[0]);
-            z = sqrt(3) * sqrt(z);
-            r[i] = sf2 * (1.0 + z) * exp(-z);
-            break;
-        default:
-            for (int j = 0; j < NA; j++) z += sq(X[NA * i + j] - x[j]);
-            z = sqrt(z);
-            r[i] = sf2 * (1.0 + sqrt(5) * z / hyperparams[0] + 5 * z * z / (3 * hyperparams[0] * hyperparams[0])) * exp(-(sqrt(5) * z / hyperparams[0]));
-            break;
+    for (int row = row0; row < row1; row++) {
+        const double *o = obs + (size_t)row * dim;
+        double sum = 0;
+        for (int d = 0; d < dim; d++) sum = Radial<FAMILY>::step(sum, o[d] - pt[d], c.per_dim[FAMILY == 0 ? d : 0]);
+        out[row] = Radial<FAMILY>::shape(sum, amp, c);
+    }
+}
+
+// the cores this process may actually use: the affinity mask cut down to the cgroup's CPU quota (a GPU box shows 256 CPUs and grants 16)
+int usable_cores()
+{
+    if (const char *e = getenv("IBO_HOST_THREADS")) { const int n = atoi(e); if (n >= 1) return n > 64 ? 64 : n; }
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) { const int q = (int)((quota + period - 1) / period); if (q < n) n = q; }
+        fclose(f);
+    }
+    return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+
+}   // namespace
+
+// A crew of host threads that lives as long as one acqmaxGP call: run(count, fn) hands the items 0 .. count-1 to whoever is free
+// (the caller included) and returns when all are done.  Every item writes its own outputs, so the result does not depend on who ran what.
+struct LegacyHost::Crew {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable wake, done;
+    const std::function<void(int)> *job = nullptr;
+    std::atomic<int> next{0};
+    int count = 0, round = 0, working = 0;
+    bool stop = false;
+
+    explicit Crew(int helpers)
+    {
+        for (int t = 0; t < helpers; t++) threads.emplace_back([this] { loop(); });
+    }
+    ~Crew()
+    {
+        { std::lock_guard<std::mutex> l(mu); stop = true; }
+        wake.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    void drain()
+    {
+        for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) (*job)(i);
+    }
+    void loop()
+    {
+        int seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(mu);
+                wake.wait(l, [&] { return stop || round != seen; });
+                if (stop) return;
+                seen = round;
+            }
+            drain();
+            { std::lock_guard<std::mutex> l(mu); if (--working == 0) done.notify_one(); }
         }
     }
-}
-
-// the prior mean at x (cpp/optimizeGP.cpp:118-136)
-double legacy_prior_mean(int NA, const double *x, int npbases, const double *pbasismeans, const double *pbasisbeta, double pbasistheta,
-                         const double *pbasislowerb, const double *pbasiswidth)
-{
-    double mu = 0.0;
-    for (int i = 0; i < npbases; i++) {
-        double d = 0;
-        for (int j = 0; j < NA; j++) d += sq((x[j] - pbasislowerb[j]) / pbasiswidth[j] - pbasismeans[i * NA + j]);
-        mu += pbasisbeta[i] * exp(-pbasistheta * d);
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (threads.empty() || n < 2) { for (int i = 0; i < n; i++) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            job = &fn; count = n; next = 0; working = (int)threads.size(); round++;
+        }
+        wake.notify_all();
+        drain();
+        std::unique_lock<std::mutex> l(mu);
+        done.wait(l, [&] { return working == 0; });
     }
-    return mu;
+};
+
+LegacyHost::LegacyHost(const LegacySpec &spec) : m(spec)
+{
+    k.per_dim.assign(m.dim, 0.0);
+    if (m.family == 0) for (int d = 0; d < m.dim; d++) k.per_dim[d] = 1 / (m.hyper[d] * m.hyper[d]);      // 1 / pow(h, 2): powi(h, 2) = h * h
+    else k.per_dim[0] = m.hyper[0];
+    k.h = m.hyper[0];
+    k.root3 = sqrt(3.0);
+    k.root5 = sqrt(5.0);
+    k.three_h2 = 3.0 * k.h * k.h;
+    best = m.targets[0];
+    for (int i = 0; i < m.rows; i++) if (m.targets[i] > best) best = m.targets[i];
+    root2 = sqrt(2.);
+    root2pi = sqrt(2. * M_PI);
+    crew = new Crew(usable_cores() - 1);
 }
 
-// -EI / -PI / -UCB from the two contractions (cpp/optimizeGP.cpp:139-236): ypred = m + x1, sig2 = clamp(1 + noise - x2)
-double legacy_neg_acq(int acqfunc, double prior_mu, double x1, double x2, double noise, double maxY, double parm)
+LegacyHost::~LegacyHost() { delete crew; }
+
+int LegacyHost::threads() const { return (int)crew->threads.size() + 1; }
+
+// the RBF network's value at one point: sum_b beta_b exp(-theta |(pt - origin) / extent - centre_b|^2)
+double LegacyHost::prior_at(const double *pt) const
 {
-    const double ypred = prior_mu + x1;               // (without a prior the reference has no addition: prior_mu is then +0.0 -- exact)
-    double sig2 = 1. + noise - x2;
-    if (sig2 < 1e-8) sig2 = 1e-8;
-    else if (sig2 > 10.) sig2 = 10.;
-    const double sigma = sqrt(sig2), mu = ypred;
-    if (acqfunc == 2) return -(mu + parm * sigma);
-    const double ydiff = mu - maxY - parm;
-    const double Z = ydiff / sigma;
-    const double cdf = 0.5 * (1. + erf(Z / sqrt(2.)));
-    if (acqfunc == 1) return -cdf;
-    const double pdf = exp(-(Z * Z / 2.)) / (sqrt(2. * M_PI));
-    const double EI = ydiff * cdf + sigma * pdf;
-    return -EI;
+    double total = 0.0;
+    for (int b = 0; b < m.nbasis; b++) {
+        const double *centre = m.centres + (size_t)b * m.dim;
+        double dist2 = 0;
+        for (int d = 0; d < m.dim; d++) { const double u = (pt[d] - m.origin[d]) / m.extent[d] - centre[d]; dist2 = dist2 + u * u; }
+        total = total + m.weights[b] * exp(-m.sharpness * dist2);
+    }
+    return total;
+}
+
+// For n sample points: vecs[p] = k*(pt_p) (n vectors of `rows`), and under a mean prior prior_mu[p] and vecs[n + p] = targets - prior_mu[p].
+// The work is cut into (point, 512-row slice) items for the crew.
+void LegacyHost::prepare(const double *pts, int n, double *vecs, double *prior_mu) const
+{
+    const int slice = 512, per_pt = (m.rows + slice - 1) / slice;
+    const bool prior = m.nbasis > 0;
+    const std::function<void(int)> item = [&](int it) {
+        const int p = it / per_pt, r0 = (it % per_pt) * slice, r1 = r0 + slice < m.rows ? r0 + slice : m.rows;
+        const double *pt = pts + (size_t)p * m.dim;
+        double *out = vecs + (size_t)p * m.rows;
+        switch (m.family) {
+        case 0: kstar_rows<0>(k, m.amp, m.dim, m.obs, r0, r1, pt, out); break;
+        case 1: kstar_rows<1>(k, m.amp, m.dim, m.obs, r0, r1, pt, out); break;
+        case 2: kstar_rows<2>(k, m.amp, m.dim, m.obs, r0, r1, pt, out); break;
+        default: kstar_rows<3>(k, m.amp, m.dim, m.obs, r0, r1, pt, out); break;
+        }
+    };
+    if (prior) {
+        const std::function<void(int)> means = [&](int p) { prior_mu[p] = prior_at(pts + (size_t)p * m.dim); };
+        crew->run(n, means);
+        const std::function<void(int)> both = [&](int it) {
+            item(it);
+            const int p = it / per_pt, r0 = (it % per_pt) * slice, r1 = r0 + slice < m.rows ? r0 + slice : m.rows;
+            double *resid = vecs + (size_t)(n + p) * m.rows;
+            for (int i = r0; i < r1; i++) resid[i] = m.targets[i] - prior_mu[p];
+        };
+        crew->run(n * per_pt, both);
+    } else {
+        for (int p = 0; p < n; p++) prior_mu[p] = 0.0;       // (+0.0 added to the first contraction: exact)
+        crew->run(n * per_pt, item);
+    }
+}
+
+// the NEGATED acquisition from the two contractions: mean = prior_mu + c_mean, variance = clamp(1 + noise - c_var, 1e-8, 10)
+double LegacyHost::negated(double prior_mu, double c_mean, double c_var) const
+{
+    const double mean = prior_mu + c_mean;
+    double var = 1. + m.noise - c_var;
+    var = var < 1e-8 ? 1e-8 : (var > 10. ? 10. : var);
+    const double sd = sqrt(var);
+    if (m.acq == 2) return -(mean + m.parm * sd);
+    const double gain = mean - best - m.parm;
+    const double u = gain / sd;
+    const double Phi = 0.5 * (1. + erf(u / root2));
+    if (m.acq == 1) return -Phi;
+    const double phi = exp(-(u * u / 2.)) / root2pi;
+    return -(gain * Phi + sd * phi);
 }

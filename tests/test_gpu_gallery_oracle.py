@@ -337,6 +337,128 @@ def test_legacy_acqmaxGP_reproduces_libego_where_conditioning_is_worst(ibo, orac
         _lib.check(_lib.lib.ibo_set_option(b"legacy_exact", 1))
 
 
+def _legacy_call(_lib, libc, ogp, invR, lb, ub, acq, parm, maxiter, maxsample=10000):
+    """acqmaxGP of libibo_hip.so through the reference's own argument list (ego/acquisition/__init__.py:343-364)"""
+    from oracle import oracle as oracle_mod
+    f64, dp = _lib.f64, _lib.dp
+    D = ogp.X.shape[1]
+    lb, ub = f64(lb), f64(ub)
+    Xc, Yc, hy = f64(ogp.X), f64(ogp.Y), f64(ogp.kern.c_hyper)
+    pa = oracle_mod._prior_cargs(ogp.prior)
+    r = _lib.lib.acqmaxGP(D, dp(lb), dp(ub), dp(invR), dp(Xc), dp(Yc), len(Yc), acq, int(ogp.kern.ktype), dp(hy), *pa,
+                          float(parm), float(ogp.noise), maxiter, 30, maxsample)
+    assert bool(r)
+    res = np.array([r[i] for i in range(D + 1)])
+    libc.free(r)
+    return -res[0], res[1:]
+
+
+class _quiet_stdout(object):
+    """libego prints every Matern-5/2 covariance to stdout (cpp/optimizeGP.cpp:109): file descriptor 1 to /dev/null for the call"""
+    def __enter__(self):
+        import os, sys
+        sys.stdout.flush()
+        self.saved = os.dup(1); self.null = os.open(os.devnull, os.O_WRONLY); os.dup2(self.null, 1)
+    def __exit__(self, *a):
+        import os
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1); os.close(self.null); os.close(self.saved)
+
+
+def test_legacy_acqmaxGP_matern52(ibo, oracle):
+    """Kernel type 3 behind the legacy symbol (csrc/legacy.hip Radial<3>, csrc/abi.hip acqmaxGP), the branch C3's caller takes
+    (ego/acquisition/__init__.py:329-333,385-436).  D >= 2: the compiled reference cannot be the comparator -- it reads its
+    magnitude from hyperparams[ndim], out of bounds (cpp/optimizeGP.cpp:313) -- so the oracle's restatement is
+    (oracle.sweep_native per point, oracle.acqmax_native over a DIRECT run), at the 1e-6 bar, with and without a mean prior,
+    both routes (legacy_exact 1 and 0).  D = 1: hyperparams[1] IS the magnitude there, and the exact route returns the compiled
+    reference's numbers bit for bit."""
+    from ibo_amd import _lib
+    libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+    f64 = _lib.f64
+    rs = np.random.RandomState(91)
+    for D, N, hyp, noise in ((2, 700, [.5, 1.0], .05), (8, 900, [.7, 0.8], .1), (3, 640, [.4, 0.9], .01)):
+        X = rs.rand(N, D); Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
+        prior = oracle.Prior(rs.rand(4, D), rs.randn(4) * .3, 1.5, np.zeros(D), np.ones(D))
+        for pr in (None, prior):
+            ogp = oracle.GP(oracle.Kern("m5", hyp), X, Y, noise=noise, prior=pr)
+            invR = f64(np.linalg.inv(ogp.R))
+            probes = np.vstack([rs.rand(6, D), np.clip(X[rs.randint(0, N, 3)] + 1e-2 * rs.randn(3, D), 0, 1)])
+            for exact in (1, 0):
+                _lib.check(_lib.lib.ibo_set_option(b"legacy_exact", exact))
+                try:
+                    for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_PI, .05), (oracle.ACQ_UCB, 1.3)):
+                        want = oracle.sweep_native(ogp, probes, acq, parm, invR=invR)["acq"]
+                        for x, w in zip(probes, want):
+                            a, _ = _legacy_call(_lib, libc, ogp, invR, x, x, acq, parm, 0)
+                            close(a, w, rtol=1e-6, atol=ACQ_ATOL)
+                        a, ax = _legacy_call(_lib, libc, ogp, invR, [0.] * D, [1.] * D, acq, parm, 8)
+                        b, bx, _ = oracle.acqmax_native(ogp, [[0., 1.]] * D, acq, parm, maxiter=8, invR=invR)
+                        close(a, b, rtol=1e-6, atol=ACQ_ATOL); close(ax, bx, rtol=1e-9, atol=1e-12)
+                finally:
+                    _lib.check(_lib.lib.ibo_set_option(b"legacy_exact", 1))
+    if not oracle.RefLib.available():
+        return
+    ref = oracle.RefLib()
+    N, D = 500, 1
+    X = np.clip(np.vstack([.3 + .01 * rs.randn(200, 1), rs.rand(300, 1)]), 0, 1); Y = np.sin(5 * X[:, 0]) + .01 * rs.randn(N)
+    ogp = oracle.GP(oracle.Kern("m5", [.4, 1.2]), X, Y, noise=1e-4)
+    invR = f64(np.linalg.inv(ogp.R))
+    for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_PI, .05), (oracle.ACQ_UCB, 1.3)):
+        for x in rs.rand(6, 1):
+            a, _ = _legacy_call(_lib, libc, ogp, invR, x, x, acq, parm, 0)
+            with _quiet_stdout():
+                b, _ = ref.acqmax(ogp, [[x[0], x[0]]], acq, parm, maxiter=0, invR=invR)
+            assert a == b, (acq, x, a, b)
+        a, ax = _legacy_call(_lib, libc, ogp, invR, [0.], [1.], acq, parm, 10)
+        with _quiet_stdout():
+            b, bx = ref.acqmax(ogp, [[0., 1.]], acq, parm, maxiter=10, invR=invR)
+        assert a == b and np.array_equal(ax, bx), (acq, a, b, ax, bx)
+
+
+@pytest.mark.parametrize("N", [2049, 3000, 4096])
+def test_legacy_acqmaxGP_beyond_one_lds_chunk(ibo, oracle, N):
+    """N > 2048: legacy_matvec_kernel's and legacy_dot_kernel's second (and third) 2048-entry LDS chunk (csrc/legacy.hip), the
+    size C3's caller hands over and beyond (ego/acquisition/__init__.py:385-436 with N = 2048 + the gallery's hallucinations).
+    SE-ARD with and without a mean prior on clustered noise-1e-4 data, against the reference's own compiled library: BIT FOR BIT
+    per point and over a short DIRECT run."""
+    from ibo_amd import _lib
+    if not oracle.RefLib.available():
+        pytest.skip("oracle/_ref/libego.so not present on this box")
+    ref = oracle.RefLib()
+    libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+    f64 = _lib.f64
+    D = 3
+    rs = np.random.RandomState(N)
+    c = rs.rand(3, D)
+    X = np.clip(np.vstack([c[i] + 0.02 * rs.randn(N // 5, D) for i in range(3)] + [rs.rand(N - 3 * (N // 5), D)]), 0, 1)
+    Y = np.sin(3 * X.sum(1)) + .01 * rs.randn(N)
+    prior = oracle.Prior(rs.rand(5, D), rs.randn(5) * .3, 2.0, np.zeros(D), np.ones(D))
+    for pr in (None, prior):
+        ogp = oracle.GP(oracle.Kern("ard", [.3, .25, .35]), X, Y, noise=1e-4, prior=pr)
+        invR = f64(np.linalg.inv(ogp.R))
+        for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_UCB, 1.3)):
+            for x in np.vstack([rs.rand(2, D), np.clip(X[rs.randint(0, N, 1)] + 1e-3 * rs.randn(1, D), 0, 1)]):
+                a, _ = _legacy_call(_lib, libc, ogp, invR, x, x, acq, parm, 0)
+                b, _ = ref.acqmax(ogp, [[v, v] for v in x], acq, parm, maxiter=0, invR=invR)
+                assert a == b, (N, acq, x, a, b)
+        a, ax = _legacy_call(_lib, libc, ogp, invR, [0.] * D, [1.] * D, oracle.ACQ_EI, .01, 2)
+        b, bx = ref.acqmax(ogp, [[0., 1.]] * D, oracle.ACQ_EI, .01, maxiter=2, invR=invR)
+        assert a == b and np.array_equal(ax, bx), (N, a, b, ax, bx)
+
+
+def test_legacy_acqmaxGP_refuses_what_the_reference_cannot_evaluate(ibo, oracle):
+    """acqfunc outside 0..2: the reference prints and returns NULL (cpp/optimizeGP.cpp:342-345).  kerneltype outside 0..3: the
+    reference's switch leaves k* uninitialised (cpp/optimizeGP.cpp:67-113); here NULL."""
+    from ibo_amd import _lib
+    f64, dp = _lib.f64, _lib.dp
+    X = f64(np.random.RandomState(1).rand(10, 2)); Y = f64(np.arange(10.)); iR = f64(np.eye(10)); hy = f64([.3, .3]); one = f64([0.])
+    lb, ub = f64([0., 0.]), f64([1., 1.])
+    for acq, kt in ((3, 0), (-1, 0), (0, 4), (0, -1)):
+        r = _lib.lib.acqmaxGP(2, dp(lb), dp(ub), dp(iR), dp(X), dp(Y), 10, acq, kt, dp(hy), 0, dp(one), dp(one), 0., dp(one), dp(one),
+                              .01, .1, 2, 30, 100)
+        assert not bool(r), (acq, kt)
+
+
 def test_two_threads_two_handles_one_device(ibo):
     """The ABI's re-entrancy claim (include/ibo_abi.h, ibo_set_option's note; the reference keeps its model in process-wide
     statics, cpp/optimizeGP.cpp:36-55): two Python threads on device 0 -- ctypes releases the GIL for the duration of every

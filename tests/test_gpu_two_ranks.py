@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-@pytest.mark.parametrize("world,shape", [(2, "c3"), (3, "small")])
+@pytest.mark.parametrize("world,shape", [(2, "c3"), (3, "small"), (8, "small8")])
 def test_sharded_paths_with_several_ranks_on_one_gpu(launch_ranks, world, shape):
     import two_rank_worker as W
     from ibo_amd import DeviceArray, _lib
@@ -56,6 +56,11 @@ def test_sharded_paths_with_several_ranks_on_one_gpu(launch_ranks, world, shape)
     assert sw[0] == one["best_val"] and int(sw[1]) == one["best_idx"]
     owner = [r for r in range(world) if ranks[r]["start"] <= one["best_idx"] < ranks[r]["stop"]][0]
     assert int(sw[2]) == owner
+    if world == 8:
+        # eight uneven blocks; seven of the eight ranks lose the exchange in every round, and all of them know who won
+        sizes = sorted(int(ranks[r]["stop"]) - int(ranks[r]["start"]) for r in range(world))
+        assert sizes[0] + 1 == sizes[-1] and sum(sizes) == sh["M"]
+        assert sum(1 for r in range(world) if int(ranks[r]["local_idx"]) == one["best_idx"]) == 1
     np.testing.assert_array_equal(sw[3:], cand[one["best_idx"]])
     trace = []
     gal = np.array(fastUCBGallery(GP, [[0., 1.]] * sh["D"], sh["picks"], candidates=dc, maxiter=sh["maxiter"], trace=trace))
@@ -106,3 +111,25 @@ def test_bench_line_with_two_ranks_on_one_device(launch_ranks):
     # the same global arg-max as ONE process sweeping the two ranks' candidates: bench.py --gpus 1 over 2^21 candidates is not a config, so
     # the check is on the index range and the value's sign here; bit-equality of sharded and single-process results is the test above
     assert 0 <= j["best"]["index"] < 2 * (1 << 20)
+
+
+def test_bench_line_with_eight_ranks_on_one_device(launch_ranks):
+    """The exact command line the driver issues on the 8-GPU node -- `python bench.py --gpus 8 --steps 2 --warmup 1` -- minus RCCL:
+    IBO_BENCH_ONE_DEVICE=1 puts the eight rank processes on device 0 and the exchange on the socket transport.  Eight slots in every
+    exchange, seven of eight ranks losing each one, the C3 gallery over eight 2^19-candidate shards (= BASELINE configs[2]'s 4M candidates)
+    and the C5 grid with 64 theta-points per rank (= configs[4]'s 512) of the `configs` block.  Numbers mean nothing (the ranks share the GPU)."""
+    import json
+    env = {"IBO_BENCH_ONE_DEVICE": "1"}
+    res = launch_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], 1, env=env,
+                       timeout=1500, rank_env=False)
+    assert res["rc"] == [0], res["err"][0][-3000:]
+    lines = [l for l in res["out"][0].splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_nranks"] == 8 and j["transport"].startswith("socket") and j["launcher"] == "self (bench.py children)"
+    assert j["scaling"] == "weak" and j["value"] > 0 and j["steps"] == 2
+    assert 0 <= j["best"]["index"] < 8 * (1 << 20)
+    c = j["configs"]
+    assert c["c3_gallery8"]["min_pairwise_distance"] > 0.5 and c["c3_shard_sweep"]["value"] > 0
+    assert "x8" in c["c3_shard_sweep"]["workload"] and "x8" in c["c5_nlml_grid"]["workload"]
+    assert c["c5_nlml_grid"]["n_not_pd"] == 0 and 0 <= c["c5_nlml_grid"]["argmin"] < 512

@@ -8,7 +8,7 @@ seeds, keeps its contiguous block of rows in HBM and runs
   3. sharded_nlml_grid    (theta-points in contiguous blocks, one sum exchange, a theta that is not positive definite)
 
 and writes what it got to <out>.rank<r>.npz.  The test compares the ranks with each other and with the single-process run.
-usage: two_rank_worker.py <socket path> <out prefix> <shape: c3 | small>
+usage: two_rank_worker.py <socket path> <out prefix> <shape: c3 | small | small8>
 """
 import os
 import sys
@@ -22,6 +22,8 @@ import numpy as np
 def shapes(name):
     if name == "c3":      # BASELINE config 3's model on half a GPU-shard per rank; 2 x 8 theta-points at N = 1024
         return dict(N=2048, D=8, kind="m5", hyp=[.5, 1.0], M=1 << 19, picks=8, gN=1024, gD=4, T=16, bad=11, maxiter=50)
+    if name == "small8":  # eight uneven blocks: 80003 rows and 19 theta-points over 8 ranks (blocks of 10001 / 10000 rows and 3 / 2 points)
+        return dict(N=600, D=3, kind="ard", hyp=[.25, .3, .35], M=80003, picks=5, gN=300, gD=3, T=19, bad=11, maxiter=12)
     return dict(N=600, D=3, kind="ard", hyp=[.25, .3, .35], M=30001, picks=5, gN=300, gD=3, T=7, bad=4, maxiter=12)
 
 
