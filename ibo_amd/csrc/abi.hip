@@ -50,35 +50,23 @@ void ibo_internal_set_error(const char *msg)
     } while (0)
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
-extern std::atomic<int> g_sweep_variant;     // sweep.hip
-static std::atomic<int> g_host_pipeline{1};  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches
-static std::atomic<int> g_chol_fused{1};     // ibo_set_option("chol_fused", 0/1): fit path, N <= 2048
-static std::atomic<int> g_cov_fit{1};         // ibo_set_option("cov_fit", 0/1): the fit's own covariance pass (cov_fit_kernel) or the general kernel; same bits
-static std::atomic<int> g_fused2_min_nb{104};  // ibo_set_option("fused2_min_nb"): block columns from which a fit takes the two-level order
-static std::atomic<int> g_chol_fused2{1};    // ibo_set_option("chol_fused2", 0/1): fit path, N > 2048 (two-level order, fused in-panel steps)
-static std::atomic<int> g_zero_copy{1};      // ibo_set_option("zero_copy", 0/1): small host batches are read from / written to pinned host memory by the kernels
-static std::atomic<int> g_small_trace{0};    // ibo_set_option("small_trace", 1: start / 2: print to stderr): host-side split of the zero-copy small batches
-static double g_st_launch = 0.0, g_st_wait = 0.0, g_st_copy = 0.0; static long g_st_n = 0;
-static std::atomic<int> g_gallery_prune{1};  // ibo_set_option("gallery_prune", 0/1/2): kept-state sweeps in two parts of W's rows, the second only where a
+static std::atomic<int> g_host_pipeline{1};  // ibo_set_option("host_pipeline", 0/1): chunked, overlapped host batches (0: one shot -- the test's comparator)
+static std::atomic<int> g_fused2_min_nb{104};  // ibo_set_option("fused2_min_nb"): block columns from which a single matrix takes the two-level order
+static std::atomic<int> g_gallery_prune{1};  // ibo_set_option("gallery_prune", 0/1/2): kept-state sweeps in levels of W's rows, the later ones only where a
                                  // tile's bound can still win (1); the same launches with every tile completed (2); the one-kernel sweep (0)
-static std::atomic<int> g_gallery_lazy{1};   // ibo_set_option("gallery_lazy", 0/1): a two-part state's later rounds refresh only the tiles whose bound can matter
-static std::atomic<int> g_flag_poll{1};      // ibo_set_option("flag_poll", 0/1): small batches signal completion through a pinned word
-static std::atomic<int> g_gemv_max{0};       // ibo_set_option("gemv_max", m): batches up to m candidates take the GEMV kernel even where small2.hip applies
-static std::atomic<int> g_small2{1};         // ibo_set_option("small2", 0/1): small-batch path of small2.hip (else the panel-split kernel)
-static std::atomic<int> g_chol_ride{1};      // ibo_set_option("chol_ride", 0/1): W = L^-1 computed inside the fused factorisation's launches
-static std::atomic<int> g_nlml_batch{0};     // 0 = choose (memory-bounded), else matrices per batched factorisation
-static std::atomic<int> g_cov_fast{1};       // ibo_set_option("cov_fast", 0/1): ibo_nlml_grid's covariance pass with scaled coordinates and the sweep's exp (see cov_matrix_kernel)
-static std::atomic<int> g_chol_left{1};      // ibo_set_option("chol_left", 0/1): ibo_nlml_grid factors in the left-looking outer order (update3.hip)
-static std::atomic<int> g_nlml_groups{2};    // ibo_set_option("nlml_groups", g): a batch of theta-points runs as g sub-batches on g streams (the latency-bound
-                                 // in-panel chain and the launch tails of one overlap the MFMA-bound updates of the other); values do not depend on it
-static std::atomic<int> g_dot_override{-1};  // -1 auto, 0/1 force (tests)
-static std::atomic<int> g_legacy_exact{1};  // ibo_set_option("legacy_exact", 0/1): acqmaxGP evaluates libego's formulas in libego's operation order (legacy.hip)
-static std::atomic<int> g_force_path{0};   // 0 auto, 1 gemv, 2 mfma (IBO_SWEEP_IMPL env / tests)
+static std::atomic<int> g_nlml_batch{0};     // ibo_set_option("nlml_batch", b): matrices per batched factorisation of ibo_nlml_grid (0: as many as 12 GB hold)
+static std::atomic<int> g_chol_left{1};      // ibo_set_option("chol_left", 0/1): ibo_nlml_grid factors in the left-looking outer order (update3.hip); 0: the
+                                 // right-looking order of launch_cholesky_batched -- the same bits, the test's comparator
+static std::atomic<int> g_dot_override{-1};  // ibo_set_option("dot_form", -1/0/1): -1 auto, 0/1 force the difference / dot form of k* (tests)
+static std::atomic<int> g_legacy_exact{1};   // ibo_set_option("legacy_exact", 0/1): acqmaxGP evaluates libego's formulas in libego's operation order (legacy.hip)
+static std::atomic<int> g_force_path{0};     // ibo_set_option("sweep_path"): 0 auto, 1 gemv, 2 mfma, 3 panel-split (IBO_SWEEP_IMPL env / tests)
+static const int kNlmlGroups = 2;            // a batch of theta-points runs as two sub-batches on two streams (one's latency-bound in-panel chain and launch
+                                 // tails beside the other's MFMA-bound updates; three or four measured slower); values do not depend on it
 
 // The option switches above are process-wide configuration (atomics: setting one while another thread computes is a defined,
-// if unspecified-moment, change); the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad, the exp table and ibo_trim are
-// serialised by g_dev_mu; handles are independent of each other (own stream, events, buffers) -- two threads may drive two
-// handles on one device at once.  ONE handle is for one thread at a time.  (small_trace's counters are a single-threaded diagnostic.)
+// if unspecified-moment, change); the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad and ibo_trim are serialised by
+// g_dev_mu (the exp table has its own lock, held only while it is created); handles are independent of each other (own stream,
+// events, buffers) -- two threads may drive two handles on one device at once.  ONE handle is for one thread at a time.
 static std::mutex g_dev_mu[16];
 static std::atomic<size_t> g_pool_limit{(size_t)2 << 30};    // ibo_set_option("pool_limit_mb", n) / env IBO_POOL_LIMIT_MB
 
@@ -299,51 +287,17 @@ extern "C" int ibo_device_name(int device, char *buf, size_t buflen)
 
 extern "C" int ibo_set_option(const char *key, int value)
 {
-    if (key && !strcmp(key, "sweep_path")) { g_force_path = value; return IBO_OK; }
-    if (key && !strcmp(key, "sweep_variant")) { g_sweep_variant = value; return IBO_OK; }
-    if (key && !strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
-    if (key && !strcmp(key, "chol_panel")) { set_chol_panel(value); return IBO_OK; }
-    if (key && !strcmp(key, "chol_fused")) { g_chol_fused = value; return IBO_OK; }
-    if (key && !strcmp(key, "chol_fused2")) { g_chol_fused2 = value; return IBO_OK; }
-    if (key && !strcmp(key, "fused2_min_nb")) { g_fused2_min_nb = value; return IBO_OK; }
-    if (key && !strcmp(key, "chol_update2")) { set_chol_update2(value); return IBO_OK; }
-    if (key && !strcmp(key, "update2_min_tiles")) { set_chol_update2_min_tiles(value); return IBO_OK; }
-    if (key && !strcmp(key, "trinv_wide")) { set_trinv_wide(value); return IBO_OK; }
-    if (key && !strcmp(key, "step_split")) { set_step_split(value); return IBO_OK; }
-    if (key && !strcmp(key, "step_waves")) { set_step_waves(value); return IBO_OK; }
-    if (key && !strcmp(key, "pipe_pairs")) { set_pipe_pairs(value); return IBO_OK; }
-    if (key && !strcmp(key, "cov_fit")) { g_cov_fit = value; return IBO_OK; }
-    if (key && !strcmp(key, "wtw_waves")) { set_wtw_waves(value); return IBO_OK; }
-    if (key && !strcmp(key, "wtw_xcd")) { set_wtw_xcd(value); return IBO_OK; }
-    if (key && !strcmp(key, "grad_ard")) { set_grad_ard(value); return IBO_OK; }
-    if (key && !strcmp(key, "chol_pipe")) { set_chol_pipe(value); return IBO_OK; }
-    if (key && !strcmp(key, "chol_panel_rows")) { set_chol_panel_rows(value); return IBO_OK; }
-    if (key && !strcmp(key, "chol_panel_diag")) { set_chol_panel_diag(value); return IBO_OK; }
-    if (key && !strcmp(key, "chol_tail")) { set_chol_tail(value); return IBO_OK; }
-    if (key && !strcmp(key, "chol_ride")) { g_chol_ride = value; return IBO_OK; }
-    if (key && !strcmp(key, "small2")) { g_small2 = value; return IBO_OK; }
-    if (key && !strcmp(key, "gemv_max")) { g_gemv_max = value; return IBO_OK; }
-    if (key && !strcmp(key, "flag_poll")) { g_flag_poll = value; return IBO_OK; }
-    if (key && !strcmp(key, "small_inline")) { set_small_inline(value); return IBO_OK; }
-    if (key && !strcmp(key, "small_local")) { set_small_local(value); return IBO_OK; }
-    if (key && !strcmp(key, "small_split")) { set_small_split(value); return IBO_OK; }
-    if (key && !strcmp(key, "gallery_prune")) { g_gallery_prune = value; return IBO_OK; }
-    if (key && !strcmp(key, "part_means")) { set_part_means(value); return IBO_OK; }
-    if (key && !strcmp(key, "part_levels")) { set_part_levels(value); return IBO_OK; }
-    if (key && !strcmp(key, "gallery_lazy")) { g_gallery_lazy = value; return IBO_OK; }
-    if (key && !strcmp(key, "legacy_exact")) { g_legacy_exact = value; return IBO_OK; }
-    if (key && !strcmp(key, "small_trace")) {
-        if (value == 2 && g_st_n) fprintf(stderr, "[ibo] small batches: %ld, staging + launches %.2f us, wait %.2f us, results %.2f us each\n", g_st_n, g_st_launch / g_st_n, g_st_wait / g_st_n, g_st_copy / g_st_n);
-        g_small_trace = value == 1; g_st_launch = g_st_wait = g_st_copy = 0.0; g_st_n = 0;
-        return IBO_OK;
-    }
-    if (key && !strcmp(key, "zero_copy")) { g_zero_copy = value; return IBO_OK; }
-    if (key && !strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
-    if (key && !strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
-    if (key && !strcmp(key, "chol_left")) { g_chol_left = value; return IBO_OK; }
-    if (key && !strcmp(key, "cov_fast")) { g_cov_fast = value; return IBO_OK; }
-    if (key && !strcmp(key, "nlml_groups")) { if (value < 1 || value > 4) return fail(IBO_ERR_ARG, "nlml_groups: 1..4"); g_nlml_groups = value; return IBO_OK; }
-    if (key && !strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
+    if (!key) return fail(IBO_ERR_ARG, "key is NULL");
+    if (!strcmp(key, "sweep_path")) { g_force_path = value; return IBO_OK; }
+    if (!strcmp(key, "dot_form")) { g_dot_override = value; return IBO_OK; }
+    if (!strcmp(key, "gallery_prune")) { g_gallery_prune = value; return IBO_OK; }
+    if (!strcmp(key, "part_levels")) { set_part_levels(value); return IBO_OK; }
+    if (!strcmp(key, "legacy_exact")) { g_legacy_exact = value; return IBO_OK; }
+    if (!strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
+    if (!strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
+    if (!strcmp(key, "chol_left")) { g_chol_left = value; return IBO_OK; }
+    if (!strcmp(key, "fused2_min_nb")) { if (value < 1) return fail(IBO_ERR_ARG, "fused2_min_nb < 1"); g_fused2_min_nb = value; return IBO_OK; }
+    if (!strcmp(key, "pool_limit_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "pool_limit_mb < 0"); g_pool_limit = (size_t)value << 20; return IBO_OK; }
     return fail(IBO_ERR_ARG, "unknown option");
 }
 
@@ -543,9 +497,10 @@ static int dot_form_ok(const KParams &kp, const double *X, int N, int D)
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // Which order factors an Np-row matrix: the single-level right-looking order with pipelined block columns and W = L^-1 riding along
 // (launch_cholesky_fused) below g_fused2_min_nb block columns, the two-level order (panels of four, K = 256 updates, recursive-doubling
-// inversion) from there on.  Round 4 moved the switch from 33 to 86 block columns: with the eight-wave pipelined column the single-level order
-// wins up to ~5400 rows (N = 2304: 1.19 -> 0.72 ms, 3072: 1.65 -> 1.18, 4096: 2.49 -> 2.25, 5120: 4.06 -> 3.83; 5632: 4.70 against 4.85).
-static inline bool single_level_order(int Np) { return Np / 64 < (g_fused2_min_nb > 33 ? g_fused2_min_nb.load() : 33); }
+// inversion) from there on: 104 block columns (6656 rows) by default -- with the eight-wave pipelined column and two steps per pass the
+// single-level order wins up to there (N = 4096: 2.49 -> 2.07 ms; 6400 rows: 6.20 against 6.50; 7040: 8.18 against 7.70).  ONE predicate for
+// ibo_gp_fit, the preference GP's factorisations and ibo_nlml_grad: the order fixes the last bits of L and W.
+static inline bool single_level_order(int Np) { return Np / 64 < g_fused2_min_nb; }
 static int ensure_pinned(ibo_gp *g, size_t need);
 
 // stage observations (optionally in reverse order) and size every buffer
@@ -612,8 +567,7 @@ static int ensure_R(ibo_gp *g)
 {
     if (g->R_valid) return IBO_OK;
     IBO_TRY(g->R.ensure((size_t)g->Npad * g->Npad));             // N x N with row stride Npad (room to extend)
-    KERNEL_TRY(launch_cov_matrix(g->kp_fit, g->N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, g->noise, g->R.p, g->Npad,
-                                 g->stream, nullptr, 0, 0, nullptr, nullptr));
+    KERNEL_TRY(launch_cov_matrix(g->kp_fit, g->N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, g->noise, g->R.p, g->Npad, g->stream));
     g->R_valid = true;
     return IBO_OK;
 }
@@ -627,52 +581,32 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     const double *A_host = have_A ? g->A.p : nullptr;      // (only tested for presence below)
     HIP_TRY(hipEventRecord(g->fit0, s));
     // R, and in the same pass the identity-padded copy the factorisation works on
-    const bool fused2 = Np / 64 >= g_fused2_min_nb && g_chol_fused && g_chol_fused2;      // the two-level order, out of place as well
-    const bool fused = !fused2 && single_level_order(Np) && g_chol_fused;
-    double *work = (fused || fused2) ? g->T.p : g->L.p;          // T is free until launch_trinv uses it as scratch
+    const bool fused = single_level_order(Np);                   // (else the two-level order; both out of place: the matrix in T, the factor into L)
+    double *work = g->T.p;                                       // T is free until launch_trinv uses it as scratch
     // (with the working copy the same pass writes the identity the ride-along starts from and clears the info word)
-    const bool ride = fused && g_chol_ride != 0;
-    const bool one_pass = ride && !A_host;
+    const bool one_pass = fused && !A_host;
     // (GP.R itself is not written here: 33 MB of stores at N = 2048 that only ibo_gp_get_R and ibo_pref_finish read -- ensure_R;
     // stage_data marked it stale)
     if (!A_host)
-    {
-        if (g_cov_fit)
-            KERNEL_TRY(launch_cov_fit(kp, N, g->Xp.p, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, work, Np, one_pass ? g->W.p : nullptr,
-                                      (one_pass || fused2) ? g->info.p : nullptr, s));
-        else
-            KERNEL_TRY(launch_cov_matrix(kp, N, g->Xp.p, 0, nullptr, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, nullptr, Np, s,
-                                         work, Np, 0, one_pass ? g->W.p : nullptr, (one_pass || fused2) ? g->info.p : nullptr));
-    }
+        KERNEL_TRY(launch_cov_fit(kp, N, g->Xp.p, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, work, Np, one_pass ? g->W.p : nullptr, g->info.p, s));
     else {
-        if (fused2) HIP_TRY(hipMemsetAsync(g->info.p, 0, sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(g->info.p, 0, sizeof(int), s));
         KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
     }
-    bool packed = false;
     if (fused) {
-        // small enough for the plain right-looking order: one fused launch per block column, out of place, with
-        // W = L^-1 riding along (E = I in W's buffer turns into (L^-1)^T in Wp's, which is transposed into W and packed
-        // into T's buffer -- free by then -- in one pass; T and Wp then trade places)
-        // (a step's trailing + extra tiles number at most nb (nb + 1) / 2 - 1: 527 at N = 2048, two per workgroup)
-        if (ride && !one_pass) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, g->W.p, Np, 1.0, s));       // identity
-        KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s, ride ? g->W.p : nullptr,
-                                         ride ? g->Wp.p : nullptr, one_pass));
-        g->L_upper_dirty = true;    // the strict upper blocks of L are scratch until someone asks for L
-        if (ride) {
-            KERNEL_TRY(launch_transpose_pack(g->Wp.p, N, Np, g->W.p, g->T.p, s));
-            std::swap(g->T, g->Wp);
-            packed = true;
-        } else KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
-    } else if (fused2) {
-        KERNEL_TRY(launch_cholesky_fused2(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, 4, s, true, g->W.p));    // W: free until launch_trinv     // (the covariance pass cleared the info word)
-        g->L_upper_dirty = true;
-        KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
+        // the plain right-looking order: one launch per block column, out of place, with W = L^-1 riding along (E = I in W's buffer
+        // turns into (L^-1)^T in Wp's, which is transposed into W and packed into T's buffer -- free by then -- in one pass; T and
+        // Wp then trade places)
+        if (!one_pass) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, g->W.p, Np, 1.0, s));       // identity
+        KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s, g->W.p, g->Wp.p, true));
+        KERNEL_TRY(launch_transpose_pack(g->Wp.p, N, Np, g->W.p, g->T.p, s));
+        std::swap(g->T, g->Wp);
     } else {
-        KERNEL_TRY(launch_cholesky(g->L.p, Np, g->diag64.p, g->info.p, s, g->T.p));      // T: free until launch_trinv
-        g->L_upper_dirty = true;
+        KERNEL_TRY(launch_cholesky_fused2(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, 4, s, true, g->W.p));    // W: free until launch_trinv
         KERNEL_TRY(launch_trinv(g->L.p, Np, g->diag64.p, g->W.p, g->T.p, s, false));
+        KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));
     }
-    if (!packed) KERNEL_TRY(launch_pack_w(g->W.p, N, Np, 0, g->W.p, g->Wp.p, s));
+    g->L_upper_dirty = true;        // the strict upper blocks of L are scratch until someone asks for L
     KERNEL_TRY(launch_alpha(g->W.p, N, Np, g->Y.p, g->tmp.p, g->alphaY.p, g->alpha1.p, s));
     HIP_TRY(hipEventRecord(g->fit1, s));
     IBO_TRY(check_info(g, info));
@@ -870,7 +804,7 @@ static int pref_factor(ibo_gp *g, int *info)
     auto &pw = g->pw;
     const int N = g->N, Np = g->Npad;
     hipStream_t s = g->stream;
-    if (single_level_order(Np) && g_chol_fused && g_chol_ride) {
+    if (single_level_order(Np)) {
         KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, pw.E.p, Np, 1.0, s));                  // identity
         KERNEL_TRY(launch_cholesky_fused(pw.A.p, pw.Lh.p, Np, pw.d64.p, pw.info.p, s, pw.E.p, pw.Et.p));
         KERNEL_TRY(launch_transpose_lower(pw.Et.p, pw.E.p, Np, s));
@@ -1072,7 +1006,7 @@ extern "C" int ibo_cov_matrix(int device, int ktype, int D, const double *hyper,
         IBO_TRY(a2.ensure((size_t)n2 * D));
         HIP_TRY(hipMemcpy(a2.p, A2, sizeof(double) * n2 * D, hipMemcpyHostToDevice));
     }
-    KERNEL_TRY(launch_cov_matrix(kp, n1, a1.p, n2, A2 ? a2.p : nullptr, D, diag_rule, noise, k.p, m2, nullptr));
+    KERNEL_TRY(launch_cov_matrix(kp, n1, a1.p, n2, A2 ? a2.p : nullptr, D, diag_rule, noise, k.p, m2, nullptr, 0));
     HIP_TRY(hipMemcpy(K_host, k.p, sizeof(double) * (size_t)n1 * m2, hipMemcpyDeviceToHost));
     return IBO_OK;
 }
@@ -1149,16 +1083,21 @@ extern "C" int ibo_spd_inverse(int device, int N, const double *A_host, double *
 }
 
 // 2^(j/2048), j < 2048: the table behind sweep2's exp (one per device, created on first use)
-static double *g_exp_tab[16];
+static std::atomic<double *> g_exp_tab[16];
+static std::mutex g_exp_mu;                          // held only while a device's table is being created (never across a grid or a gradient)
 static int exp_table(int device, const double **out)
 {
-    std::lock_guard<std::mutex> lk(g_dev_mu[device & 15]);      // created once per device, by whichever handle sweeps first
-    double *&p = g_exp_tab[device & 15];
+    double *p = g_exp_tab[device & 15].load(std::memory_order_acquire);
     if (!p) {
-        std::vector<double> h(2048);
-        for (int j = 0; j < 2048; j++) h[j] = exp2((double)j / 2048.0);
-        HIP_TRY(hipMalloc((void **)&p, sizeof(double) * 2048));
-        HIP_TRY(hipMemcpy(p, h.data(), sizeof(double) * 2048, hipMemcpyHostToDevice));
+        std::lock_guard<std::mutex> lk(g_exp_mu);     // created once per device, by whichever handle sweeps first
+        p = g_exp_tab[device & 15].load(std::memory_order_relaxed);
+        if (!p) {
+            std::vector<double> h(2048);
+            for (int j = 0; j < 2048; j++) h[j] = exp2((double)j / 2048.0);
+            HIP_TRY(hipMalloc((void **)&p, sizeof(double) * 2048));
+            HIP_TRY(hipMemcpy(p, h.data(), sizeof(double) * 2048, hipMemcpyHostToDevice));
+            g_exp_tab[device & 15].store(p, std::memory_order_release);
+        }
     }
     *out = p;
     return IBO_OK;
@@ -1205,13 +1144,13 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     // from ~8192 candidates on the panel-split kernel's tiles fill the chip by themselves and it is the faster one).
     // They beat the GEMV kernel down to a single candidate (N = 2048: 22 us against 87; N = 1024: 16 against 38), which
     // is left with the models they do not take (no dot form, rows beyond sweep2's LDS budget).
-    const bool small2_ok = g_force_path == 0 && g_small2 && M <= 4096 && a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad);
-    bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16 && (!small2_ok || M <= g_gemv_max));
+    const bool small2_ok = g_force_path == 0 && M <= 4096 && a.dot_form && sweep2_fits(a.Npad);
+    bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16 && !small2_ok);
     // small batches: spread the IBO_SPLIT_PANEL-row panels over the grid too (one tile per 64 candidates alone
     // would leave most of the 256 CUs idle); above ~128 tiles the plain kernel fills the chip
     // (4097 .. 8192 candidates are at most 256 tiles of the large-batch kernel -- one round of the chip, 134 us at N = 1024 and
     // 495 us at N = 2048 whatever their number, where the panel-split kernel takes 142 .. 221 and 478 .. 842 us)
-    const bool sweep2_ok = a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad);
+    const bool sweep2_ok = a.dot_form && sweep2_fits(a.Npad);
     bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256 && !(sweep2_ok && M > 4096)));
     const bool small2 = split && small2_ok;
     if (small2) {
@@ -1241,7 +1180,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
         a.qpart = g->qpart.p; a.mupart = g->mupart.p;
         KERNEL_TRY(launch_sweep_gemv(a, s, g->ev0, g->ev1));
         g->sweep_kernel = "sweep_gemv_kernel";
-    } else if (a.dot_form && g_sweep_variant == 4 && sweep2_fits(a.Npad)) {
+    } else if (sweep2_ok) {
         IBO_TRY(exp_table(g->device, &a.exp_tab));
         if (incremental) {
             // the state of this candidate array is kept on the handle; if the model has only grown by a few rows
@@ -1280,7 +1219,7 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
                 // moves the means of stale tiles by more than any margin allows) has every tile refreshed and completed instead
                 a.tile_done = g->tile_done.p; a.tile_ub = g->tile_ub.p; a.part_best = g->part_words.p; a.part_thresh = g->part_words.p + 1;
                 a.tile_rows = g->tile_rows.p; a.tile_sel = g->tile_sel.p; a.part_nlev = g->st_nlev;
-                a.part_lazy = monotone && g_gallery_prune == 1 && g_gallery_lazy && g->nb == 0 && nu_bounded;
+                a.part_lazy = monotone && g_gallery_prune == 1 && g->nb == 0 && nu_bounded;
             }
             if (usable) {
                 KERNEL_TRY(launch_sweep2_refresh(a, g->st_N, g->N - 1, s, g->ev0, g->ev1));
@@ -1515,12 +1454,10 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     IBO_TRY(ensure_pinned(g, (size_t)M * (g->D + 3)));
     hipStream_t s = g->stream;
     double *pin_in = g->pin, *pin_out = g->pin + (size_t)M * g->D;
-    struct timespec tr0, tr1, tr2, tr3;
-    if (g_small_trace) clock_gettime(CLOCK_MONOTONIC, &tr0);
     memcpy(pin_in, Q_host, sizeof(double) * M * g->D);
     // Batches of at most 8192 points skip the copy launches altogether: pinned host memory is device-visible, the
     // kernels read the few KB of candidates from it and store the results into it (two ~10 us launches per batch).
-    const bool zero_copy = M <= 8192 && g_zero_copy;
+    const bool zero_copy = M <= 8192;
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(g->cand.p, pin_in, sizeof(double) * M * g->D, hipMemcpyHostToDevice, s));
     // outputs are contiguous in the order (mu, s2, acq) restricted to the wanted ones
     int nout = 0;
@@ -1531,9 +1468,8 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
     if (acq_host) dacq = obase + (size_t)M * nout++;
     g->signal_pending = false;
     IBO_TRY(run_sweep(g, M, zero_copy ? pin_in : g->cand.p, acq, parm, erf_mode, clamp_lo, ymax, 0, nullptr, 0.0, 0, dmu, ds2, dacq,
-                      nullptr, nullptr, false, !zero_copy, zero_copy && g_flag_poll, zero_copy ? pin_in : nullptr));    // small batches: no kernel-time events either
+                      nullptr, nullptr, false, !zero_copy, zero_copy, zero_copy ? pin_in : nullptr));    // small batches: no kernel-time events either
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(pin_out, g->outs.p, sizeof(double) * M * nout, hipMemcpyDeviceToHost, s));
-    if (g_small_trace) clock_gettime(CLOCK_MONOTONIC, &tr1);
     if (zero_copy) {
         // a batch of this size is back in tens of microseconds: spin for a moment before handing the thread to the runtime's
         // blocking wait (whose wake-up alone costs about as much as the batch) -- on the word small2.hip's last kernel stores
@@ -1555,16 +1491,10 @@ static int eval_host_points(ibo_gp *g, int64_t M, const double *Q_host, int acq,
             if ((w1.tv_sec - w0.tv_sec) * 1e6 + (w1.tv_nsec - w0.tv_nsec) * 1e-3 > 300.0) { HIP_TRY(hipStreamSynchronize(s)); break; }
         }
     } else HIP_TRY(hipStreamSynchronize(s));
-    if (g_small_trace) clock_gettime(CLOCK_MONOTONIC, &tr2);
     nout = 0;
     if (mu_host) memcpy(mu_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
     if (s2_host) memcpy(s2_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
     if (acq_host) memcpy(acq_host, pin_out + (size_t)M * nout++, sizeof(double) * M);
-    if (g_small_trace && zero_copy) {
-        clock_gettime(CLOCK_MONOTONIC, &tr3);
-        auto us = [](const timespec &a, const timespec &b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
-        g_st_launch += us(tr0, tr1); g_st_wait += us(tr1, tr2); g_st_copy += us(tr2, tr3); g_st_n++;
-    }
     return IBO_OK;
 }
 
@@ -1723,13 +1653,13 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         const int nb = n_theta - t0 < B ? n_theta - t0 : B;
         // sub-batches of at least 8 matrices, each on its own stream: one's in-panel chain (64 workgroups at a time, latency)
         // and launch tails run beside the other's long-K updates
-        int G = left ? g_nlml_groups.load() : 1;
+        int G = left ? kNlmlGroups : 1;
         while (G > 1 && nb / G < 8) G--;
         for (int g = 0; g < G; g++) {
             if (G > 1 && !ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
             hipStream_t sg = G > 1 ? ws.streams[g] : s;
             const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
-            KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg, g_cov_fast));
+            KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg));
             KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
             // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
             if (left) KERNEL_TRY(launch_cholesky_batched_left(dL.p + nn * k0, Np, d64.p + (size_t)(Np / 64) * 4096 * k0, dinfo.p + t0 + k0, ng, nn, 4, sg,
@@ -1789,21 +1719,14 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     HIP_TRY(hipMemcpy(dY.p, yp.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
     // up to 2048 rows: the fit's route -- fused steps with W = L^-1 riding along (dT: the matrix being reduced, dKi: (L^-1)^T
     // until the transpose) -- instead of the three-kernel columns and the recursive-doubling inversion
-    const bool fused = single_level_order(Np) && g_chol_fused && g_chol_ride;
+    const bool fused = single_level_order(Np);
     if (fused) {
-        if (g_cov_fit) KERNEL_TRY(launch_cov_fit(kp, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dT.p, Np, dW.p, dinfo.p, s));
-        else
-            KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np, 0,
-                                         dW.p, dinfo.p));
+        KERNEL_TRY(launch_cov_fit(kp, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dT.p, Np, dW.p, dinfo.p, s));
         KERNEL_TRY(launch_cholesky_fused(dT.p, dL.p, Np, d64.p, dinfo.p, s, dW.p, dKi.p, true));
-    } else if (!single_level_order(Np) && g_chol_fused && g_chol_fused2) {
-        // beyond: the two-level order with fused in-panel columns, out of place
-        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, nullptr, Np, s, dT.p, Np));
-        KERNEL_TRY(launch_cholesky_fused2(dT.p, dL.p, Np, d64.p, dinfo.p, 4, s));
     } else {
-        KERNEL_TRY(launch_pad_copy(dX.p, 0, 1, dL.p, Np, 1.0, s));                     // identity pad
-        KERNEL_TRY(launch_cov_matrix(kp, N, dX.p, 0, nullptr, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p, Np, s));
-        KERNEL_TRY(launch_cholesky(dL.p, Np, d64.p, dinfo.p, s));
+        // beyond: the two-level order with fused in-panel columns, out of place
+        KERNEL_TRY(launch_cov_fit(kp, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dT.p, Np, nullptr, dinfo.p, s));
+        KERNEL_TRY(launch_cholesky_fused2(dT.p, dL.p, Np, d64.p, dinfo.p, 4, s, true));
     }
     // no look at the info word until everything is queued: a failed factorisation only turns the rest into NaNs
     if (fused) KERNEL_TRY(launch_transpose_pack(dKi.p, N, Np, dW.p, nullptr, s));      // W, pad rows zero (no packed copy: nothing sweeps here)

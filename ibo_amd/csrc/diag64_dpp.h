@@ -20,15 +20,6 @@
 // the waves that idle while wave 0 factors the next panel, as do the trailing-update tiles the next panel does not
 // need; after the last panel three 16x16x16 products remain.
 #pragma once
-#include <cstddef>
-// IBO_DIAG_SPLIT = 1 builds the panel on two waves (below: diag64_panel_a / diag64_panel_w).  Measured in round 4 and NOT the default: identical bits
-// (tools/check_split.py), the chain by itself 24.9 k -> 23.3 k cycles per 64 columns (tools/chol_diag_bench), but fits 3-5 % SLOWER -- in the
-// pipelined column every SIMD but the chain's own has a wave doing fp64 MFMAs during the chain (the row block's update), and the follower's
-// fp64 DPP instructions queue behind them on the shared pipe.
-#ifndef IBO_DIAG_SPLIT
-#define IBO_DIAG_SPLIT 0
-#endif
-
 #define DPP_TAIL "row_mask:0xf bank_mask:0xf"
 // Hazards.  Two wait states must lie between a VALU write of a VGPR and a DPP read of it, one between a
 // transcendental result and its first use, and the hazard recogniser does not look inside inline asm.  s_nop costs
@@ -150,163 +141,6 @@ __device__ __forceinline__ void diag64_panel(double *S, double *V, const double 
     }
 }
 
-// ---- the panel on TWO waves (round 4).  Of a pivot's 2 (15 - J) + 10 instructions, (15 - J) + 1 belong to the rows below the diagonal block
-// and to the identity rows (w): they need the pivot column a[J] and 1/L_JJ, nothing else, and nothing of the diagonal block's own
-// elimination needs them before the panel is over.  Wave 0 therefore keeps only the diagonal block (a) and PUBLISHES each scaled pivot column
-// and its 1/L_JJ in LDS with a sequence number; a second wave (wave 3, on another SIMD) follows one pivot behind and applies them to w with
-// the very instructions the one-wave panel used -- v_mul_f64 by the broadcast 1/L_JJ, v_fmac_f64_dpp with the pivot column as the
-// row_newbcast operand -- so every value is the result of the same operation on the same operands: identical bits.  The chain's wave
-// issues ~17 instead of ~25 instructions per pivot.  The follower's wait is a bounded spin on the LDS word (the two waves are resident
-// together; a bound so that nothing a bug could do turns into a hang).
-struct Diag64Pub { double v[16][17]; int seq; };
-template <int N>
-__device__ __forceinline__ void dpp_fnma1(double &a, double x, double ya)          // a -= x[lane N of this 16-lane row] * ya
-{
-    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 " DPP_TAIL : "+v"(a) : "v"(x), "v"(ya), "i"(N));
-}
-template <int J, int K, int KEND>
-__device__ __forceinline__ void panel_pairs_a(double (&a)[16])
-{
-    if constexpr (K < KEND) {
-        dpp_fnma1<K>(a[K], a[J], a[J]);
-        panel_pairs_a<J, K + 1, KEND>(a);
-    }
-}
-template <int J, int NOPS>
-__device__ __forceinline__ void panel_scale_publish(double (&a)[16], double s, unsigned pub_lane, unsigned pub_base, int seqval)
-{
-    double sb;
-    int tmp;
-    dpp_wait<NOPS>();
-    // scale, then publish column J, 1 / L_JJ and the sequence word from inside the statement (compiler-made LDS stores between the volatile
-    // statements cost the chain more than the w instructions they replaced: address arithmetic, exec masks and the hazard recogniser's
-    // s_nops around inline asm).  Every lane stores: the four DPP rows hold the same values and sb is uniform.  The stores also are the two
-    // wait states between the write of a[J] and its DPP reads by the pairs that follow.
-    asm volatile("v_mov_b64_dpp %0, %3 row_newbcast:%4 " DPP_TAIL "\n\tv_mul_f64 %1, %1, %0\n\tv_mov_b32 %2, %7\n\t"
-                 "ds_write_b64 %5, %1 offset:%8\n\tds_write_b64 %6, %0 offset:%9\n\tds_write_b32 %6, %2 offset:%10"
-                 : "=&v"(sb), "+v"(a[J]), "=&v"(tmp)
-                 : "v"(s), "i"(J), "v"(pub_lane), "v"(pub_base), "s"(seqval), "i"(J * 136), "i"(J * 136 + 128), "i"(16 * 136)
-                 : "memory");
-}
-template <int J>
-__device__ __forceinline__ void panel_from_a(double (&a)[16], unsigned pub_lane, unsigned pub_base, int base)
-{
-    if constexpr (J < 15) {
-        panel_pairs_a<J, J + 1, J + 2>(a);
-        const double y0 = panel_rsq(a[J + 1]);
-        if constexpr (J + 2 < 16) panel_pairs_a<J, J + 2, J + 3>(a);
-        else dpp_wait<1>();
-        const double s = panel_chain(a[J + 1], y0);
-        panel_pairs_a<J, J + 3, 16>(a);
-        constexpr int filled = (J + 3 < 16 ? 16 - (J + 3) : 0);       // instructions between the chain and the broadcast
-        panel_scale_publish<J + 1, (filled >= 2 ? 0 : 2 - filled)>(a, s, pub_lane, pub_base, base + J + 2);
-        panel_from_a<J + 1>(a, pub_lane, pub_base, base);
-    }
-}
-__device__ __forceinline__ void diag64_panel_a(double *S, int o, int pivot0, int *info, volatile Diag64Pub *pub, int base)
-{
-    const int lane = threadIdx.x & 63, dr = lane & 15;
-    static_assert(sizeof(double) * 17 == 136 && offsetof(Diag64Pub, seq) == 16 * 136, "the publishing statement's offsets");
-    const unsigned pub_base = (unsigned)(size_t)pub, pub_lane = pub_base + 8u * (unsigned)dr;      // LDS byte addresses
-    double a[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = S[(o + dr) * SD + o + k];
-    {
-        const double y0 = panel_rsq(a[0]);
-        dpp_wait<1>();
-        panel_scale_publish<0, 2>(a, panel_chain(a[0], y0), pub_lane, pub_base, base + 1);
-    }
-    panel_from_a<0>(a, pub_lane, pub_base, base);
-    if (info) {
-        const double last = a[15];
-        if (__builtin_amdgcn_readlane((int)(last != last), 15)) {
-            int bad = 15;
-#pragma unroll
-            for (int k = 14; k >= 0; k--)
-                if (__builtin_amdgcn_readlane((int)(a[k] != a[k]), 15)) bad = k;
-            if (lane == 0) atomicCAS(info, 0, pivot0 + o + bad + 1);
-        }
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) S[(o + dr) * SD + o + k] = a[k];
-    }
-}
-template <int J, int K>
-__device__ __forceinline__ void panel_pairs_w(double (&w)[16], double aJ)
-{
-    if constexpr (K < 16) {
-        dpp_fnma1<K>(w[K], aJ, w[J]);
-        panel_pairs_w<J, K + 1>(w, aJ);
-    }
-}
-// The follower's pivot J as one statement: (sq, aJ, sb) is a read attempt for pivot J that the previous statement issued (sequence word first, then
-// the column and 1 / L_JJ: LDS serves a wave's reads in order, so a sequence word that says "published" vouches for the data read after it);
-// wait for it, retry -- a bounded number of times -- until the word says so, issue the attempt for pivot J + 1 into (nsq, naJ, nsb), scale w[J].
-template <int J>
-__device__ __forceinline__ void panel_w_pivot(double &wJ, int &sq, double &aJ, double &sb, int &nsq, double &naJ, double &nsb,
-                                              unsigned pub_lane, unsigned pub_base, int target)
-{
-    int ss, cnt;
-    constexpr int JN = J + 1 < 16 ? J + 1 : J;                   // (the last pivot re-reads its own slot: harmless)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b32 %[cnt], 0x10000\n"
-                 "L_try%=:\n\t"
-                 "v_readfirstlane_b32 %[ss], %[sq]\n\t"
-                 "s_cmp_ge_i32 %[ss], %[tgt]\n\t"
-                 "s_cbranch_scc1 L_ok%=\n\t"
-                 "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-                 "s_cmp_eq_u32 %[cnt], 0\n\t"
-                 "s_cbranch_scc1 L_ok%=\n\t"
-                 "ds_read_b32 %[sq], %[pb] offset:%[oq]\n\t"
-                 "ds_read_b64 %[aj], %[pl] offset:%[oa]\n\t"
-                 "ds_read_b64 %[sb], %[pb] offset:%[os]\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "s_branch L_try%=\n"
-                 "L_ok%=:\n\t"
-                 "ds_read_b32 %[nsq], %[pb] offset:%[oq]\n\t"
-                 "ds_read_b64 %[naj], %[pl] offset:%[ona]\n\t"
-                 "ds_read_b64 %[nsb], %[pb] offset:%[ons]\n\t"
-                 "v_mul_f64 %[wj], %[wj], %[sb]"
-                 : [sq] "+v"(sq), [aj] "+v"(aJ), [sb] "+v"(sb), [nsq] "=&v"(nsq), [naj] "=&v"(naJ), [nsb] "=&v"(nsb), [wj] "+v"(wJ),
-                   [ss] "=&s"(ss), [cnt] "=&s"(cnt)
-                 : [pb] "v"(pub_base), [pl] "v"(pub_lane), [tgt] "s"(target), [oq] "i"(16 * 136), [oa] "i"(J * 136), [os] "i"(J * 136 + 128),
-                   [ona] "i"(JN * 136), [ons] "i"(JN * 136 + 128)
-                 : "scc", "memory");
-}
-template <int J>
-__device__ __forceinline__ void panel_from_w(double (&w)[16], unsigned pub_lane, unsigned pub_base, int base, int sq, double aJ, double sb)
-{
-    if constexpr (J < 16) {
-        int nsq;
-        double naJ, nsb;
-        panel_w_pivot<J>(w[J], sq, aJ, sb, nsq, naJ, nsb, pub_lane, pub_base, base + J + 1);
-        panel_pairs_w<J, J + 1>(w, aJ);
-        panel_from_w<J + 1>(w, pub_lane, pub_base, base, nsq, naJ, nsb);
-    }
-}
-__device__ __forceinline__ void diag64_panel_w(double *S, double *V, const double *Id, int o, volatile Diag64Pub *pub, int base)
-{
-    const int lane = threadIdx.x & 63, dr = lane & 15;
-    const int rb = min(o + 16 + lane, 63);
-    const double *wrow = (lane >= 48) ? Id + (lane - 48) * SD : S + rb * SD + o;
-    double w[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = wrow[k];
-    const unsigned pub_base = (unsigned)(size_t)pub, pub_lane = pub_base + 8u * (unsigned)dr;      // LDS byte addresses
-    // (the first attempt: a sequence word of 0 -- "not published" -- makes pivot 0's statement read for itself)
-    panel_from_w<0>(w, pub_lane, pub_base, base, 0, 0.0, 0.0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the last statement's look-ahead reads
-    if (o + 16 + lane < 64) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) S[rb * SD + o + k] = w[k];
-    }
-    if (lane >= 48) {       // identity row i = lane - 48 became column i of the inverse (its entries k < i are still exact zeros)
-#pragma unroll
-        for (int k = 0; k < 16; k++) V[(o + k) * SD + o + lane - 48] = w[k];
-    }
-}
-
 // one wave: 16x16 tiles out of LDS
 template <int K>
 __device__ __forceinline__ d4_t diag64_mm(const double *Am, const double *Bm) { return lds_mm16<false, K>(Am, Bm); }
@@ -339,39 +173,18 @@ template <typename Side = Diag64NoSide>
 __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info, Side side = Side())
 {
     const int t = threadIdx.x, wv = t >> 6;
-#if IBO_DIAG_SPLIT
-    __shared__ Diag64Pub pub;
-    if (t == 0) pub.seq = 0;
-    __syncthreads();
-#endif
     for (int b = 0; b < 4; b++) {
         const int o = 16 * b;
         if (wv == 0) {
-#if IBO_DIAG_SPLIT
-            diag64_panel_a(S, o, pivot0, info, &pub, 16 * b);
-#else
             diag64_panel(S, V, T, o, pivot0, info);
-#endif
-            CSTAMP(2 + 5 * b);
         } else if (wv > 3) {
             // (an eight-wave workgroup: waves 4..7 keep the barriers' count -- chol_step8_kernel -- or do the caller's side work)
             side(b);
-#if IBO_DIAG_SPLIT
-        } else if (wv == 3) {
-            diag64_panel_w(S, V, T, o, &pub, 16 * b);           // the rows below and the identity rows, one pivot behind wave 0
-        } else if (b == 1) {
-            // the tiles of panel 0's update that panel 1 does not read: (1,1), (2,1), (2,2) -- on waves 1 and 2 (wave 3 follows the panel)
-            if (wv == 1) { diag64_update_tile(S, 0, 1, 1); diag64_update_tile(S, 0, 2, 2); }
-            else diag64_update_tile(S, 0, 2, 1);
-        } else if (b == 2) {
-            if (wv == 2) diag64_update_tile(S, 16, 1, 1);
-#else
         } else if (b == 1) {
             // the tiles of panel 0's update that panel 1 does not read: (1,1), (2,1), (2,2)
             diag64_update_tile(S, 0, wv == 1 ? 1 : 2, wv == 3 ? 2 : 1);
         } else if (b == 2) {
             if (wv == 3) diag64_update_tile(S, 16, 1, 1);
-#endif
             if (wv == 1) {                          // upper-left 32x32 node: V[16..31][0..15] = -V1 (L10 V0)
                 diag64_put(T, 16, 0, diag64_mm<16>(S + 16 * SD, V));
                 diag64_put(V, 16, 0, -diag64_mm<16>(V + 16 * SD + 16, T + 16 * SD));
@@ -393,15 +206,12 @@ __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, doubl
                 T[(16 + MM16_ROW(r)) * SD + c + MM16_COL] = T[(48 + MM16_ROW(r)) * SD + c + MM16_COL] - q[r];
         }
         __syncthreads();
-        CSTAMP(4 + 5 * b);
         // the part of the trailing update the next panel reads: tiles (it, 0)
         if (wv < 3 - b) diag64_update_tile(S, o, wv, 0);
         if (b < 3) __syncthreads();
-        CSTAMP(6 + 5 * b);
     }
     // V3 is in place: V[48..63][32..47] = -V3 T32,  V[48..63][c..] = -V3 Q
     if (wv == 0) diag64_put(V, 48, 32, -diag64_mm<16>(V + 48 * SD + 48, T + 48 * SD + 32));
     else if (wv < 3) diag64_put(V, 48, 16 * (wv - 1), -diag64_mm<16>(V + 48 * SD + 48, T + 16 * SD + 16 * (wv - 1)));
-    CSTAMP(21);
     __syncthreads();
 }

@@ -161,7 +161,7 @@ __device__ __forceinline__ double acq_value_dev(int acq, int erf_mode, double mu
     return ydiff * cdf + sigma * pdf;
 }
 
-// ---- host-side launch API of the kernels (defined in linalg.hip / sweep.hip)
+// ---- host-side launch API of the kernels (defined in linalg.hip / assemble.hip / update3.hip / sweep*.hip / small2.hip)
 #define IBO_SPLIT_PANEL 64      // rows per workgroup of the small-batch (SPLIT) sweep
 #define IBO_S2_TCAND 32         // candidates per workgroup of sweep2_kernel (sweep2.hip)
 
@@ -229,28 +229,24 @@ int launch_sweep2_pruned(const SweepArgs &a, bool prune, hipStream_t s, hipEvent
 int launch_sweep2_complete(const SweepArgs &a, hipStream_t s);
 int launch_sweep2_pruned_finish_all(const SweepArgs &a, hipStream_t s);
 bool sweep2_part_fits(int Npad, int D);
-void set_part_means(int v);
 int sweep2_part_nlev(int Npad);                   // levels a new kept state gets (<= ibo_set_option("part_levels"))
 void set_part_levels(int v);
 int sweep2_part_levels(int Npad, int *h);        // the row splits h[0] < h[1] < .. (multiples of 128, at most 3): level l covers rows [h[l-1], h[l]); returns the number of levels
 bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);
-void set_small_inline(int v);
-void set_small_split(int v);         // small batches of <= 8 tiles: one 16-candidate block per product workgroup (small2.hip)
-void set_small_local(int v);         // small batches: every wave makes the k* it multiplies, one launch for k* and W K* (small2.hip)
 // small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
 int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 size_t small_sweep_workspace(int Npad, int64_t M);      // its LDS budget holds both alpha vectors (N <= ~5000)
 int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, int D, double *XA, hipStream_t s);
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 
+// K[i][j] = k(A1_i, A2_j) (A2 = NULL: the square matrix K(A1, A1) with the diagonal rule applied; lower_only: only its blocks on and below the diagonal)
 int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const double *A2,
-                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, double *K2 = nullptr, int np2 = 0, int lower_only = 0,
-                      double *Eye = nullptr, int *zero_word = nullptr, int fast = 0);     // Eye: np2 x np2 identity written in the same pass (with K2); fast: see cov_matrix_kernel
+                      int lda_pts, int diag_rule, double noise, double *K, int ldk, hipStream_t s, int lower_only = 0);
 int launch_cov_fit(const KParams &kp, int n, const double *X, int ldp, int diag_rule, double noise, double *K2, int np2, double *Eye,
-                   int *zero_word, hipStream_t s);          // the fit's own pass: working copy (lower blocks), ride-along identity, info word
+                   int *zero_word, hipStream_t s);          // the fit's own pass: working copy (lower blocks, identity pad), ride-along identity, info word
 int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const double *A1, int ldp, int diag_rule, double noise,
-                              double *K, int ldk, size_t kstride, hipStream_t s, int fast);
+                              double *K, int ldk, size_t kstride, hipStream_t s);
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the
 // inverses of the 64x64 diagonal blocks; info (device int) gets the 1-based failing pivot or 0
 // ws (optional): Npad * Npad doubles per matrix (wstride apart), the packed store of the packed-operand trailing update
@@ -270,20 +266,6 @@ int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int b
 // the same kernel on any region that starts on the diagonal (rows >= c0, columns [c0, c0 + width)) and any range [kbeg, kend) of packed columns
 int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
                               const double *Pk, size_t pstride, hipStream_t s);
-void set_chol_tail(int blocks);
-void set_chol_panel(int p);
-void set_chol_update2(int v);
-void set_chol_update2_min_tiles(int v);
-void set_trinv_wide(int v);
-void set_step_split(int v);
-void set_step_waves(int v);
-void set_pipe_pairs(int v);
-void set_wtw_waves(int v);
-void set_wtw_xcd(int v);
-void set_grad_ard(int v);
-void set_chol_pipe(int v);
-void set_chol_panel_rows(int v);
-void set_chol_panel_diag(int v);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
 // Ework (identity on entry) / Eout, optional: W = L^-1 rides along -- Eout receives (L^-1)^T, blocks on and above the diagonal
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s,

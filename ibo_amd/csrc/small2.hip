@@ -22,8 +22,6 @@
 #include <cstdlib>
 #include <vector>
 
-static std::atomic<int> g_small_inline{1};                       // ibo_set_option("small_inline", 0/1)
-void set_small_inline(int v) { g_small_inline = v; }
 
 #ifdef IBO_STAMPS   // diagnostic build (tools/stamp_small.py): the GPU-side timeline of a small batch, 100 MHz s_memrealtime ticks
 __device__ unsigned long long g_sst[3][1024][4];
@@ -341,7 +339,7 @@ static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, in
 {
     InlineCand ic;
     int inl = 0;
-    if (a.cand_host && a.M * a.kp.D <= SM_INLINE && g_small_inline) {
+    if (a.cand_host && a.M * a.kp.D <= SM_INLINE) {
         memcpy(ic.v, a.cand_host, sizeof(double) * (size_t)(a.M * a.kp.D));
         inl = 1;
     }
@@ -359,17 +357,12 @@ static int launch_kstar_small(const SweepArgs &a, double *Kf, double *mupart, in
     return (int)hipGetLastError();
 }
 
-static std::atomic<int> g_small_split{1};                        // ibo_set_option("small_split", 0/1): one 16-candidate block per product workgroup where the batch has <= 8 tiles
-void set_small_split(int v) { g_small_split = v; }
-static std::atomic<int> g_small_local{1};                        // ibo_set_option("small_local", 0/1): wkl_small_kernel (wave-local k*)
-void set_small_local(int v) { g_small_local = v; }
-
 template <int FAM>
 static int launch_wkl_small(const SweepArgs &a, double *qpart, double *mupart, int Mp, dim3 grid, hipStream_t s)
 {
     InlineCand ic;
     int inl = 0;
-    if (a.cand_host && a.M * a.kp.D <= SM_INLINE && g_small_inline) {
+    if (a.cand_host && a.M * a.kp.D <= SM_INLINE) {
         memcpy(ic.v, a.cand_host, sizeof(double) * (size_t)(a.M * a.kp.D));
         inl = 1;
     }
@@ -401,7 +394,7 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     // 4.4 us at N = 64, but 15 us at N = 1024 and 28-34 us at N = 2048 against 6 + 8.6 / 6 + 16 for the two separate kernels --
     // its 14-instruction exp() chains are then the throughput of the 128 CUs it occupies.  (A stage-by-stage fusion through an
     // LDS stage and a barrier per 128 rows was measured too: 0.6 us per stage, slower from N = 512 on, and removed.)
-    const bool local = g_small_local && ctiles <= 4 && (nrb <= 32 || g_small_local > 1) && a.kp.D <= 10;
+    const bool local = ctiles <= 4 && nrb <= 32 && a.kp.D <= 10;
     if (local) {
         const dim3 gl(ctiles, nrb);
         if (a.kp.family == FAM_SE) rc = launch_wkl_small<FAM_SE>(a, qpart, mupart, Mp, gl, s);
@@ -415,7 +408,8 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
         else if (a.kp.family == FAM_M3) rc = launch_kstar_small<FAM_M3>(a, Kf, mupart, Mp, g1, s);
         else rc = launch_kstar_small<FAM_M5>(a, Kf, mupart, Mp, g1, s);
         if (rc) return rc;
-        if (ctiles <= 8 && g_small_split) hipLaunchKernelGGL(wk_small_kernel<1>, dim3(2 * ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
+        if (ctiles <= 8) hipLaunchKernelGGL(wk_small_kernel<1>      // (one 16-candidate block per workgroup: twice the workgroups on a half-empty chip)
+           , dim3(2 * ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
         else hipLaunchKernelGGL(wk_small_kernel<2>, dim3(ctiles, nrb), dim3(SM_NW * 64), 0, s, a, Kf, qpart, Mp);
     }
     if (e1) (void)hipEventRecord(e1, s);

@@ -495,8 +495,6 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const double *__restr
     }
 }
 
-std::atomic<int> g_sweep_variant{4};     // 4 (default): sweep2_kernel (sweep2.hip) where the dot form is admissible and the alpha vectors fit its LDS;
-                             // anything else: sweep_mfma_kernel<16,2,4,64> for every large batch  (ibo_set_option("sweep_variant"))
 
 template <int FAM, int NW, int RBW, int CBW, int KCH, bool DOT>
 static int launch_mfma_cfg(const SweepArgs &a, int64_t ntiles, hipStream_t s)

@@ -796,16 +796,6 @@ static int launch_s2_part(const SweepArgs &a, int lo, int hi, unsigned long long
     if (a.kp.family == FAM_M3) return launch_s2_part_fam<FAM_M3>(b, ntiles, s);
     return launch_s2_part_fam<FAM_M5>(b, ntiles, s);
 }
-static int launch_s2_means(const SweepArgs &a0, hipStream_t s)
-{
-    const int64_t ntiles = (a0.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
-    SweepArgs a = a0;
-    a.rank1_row = -1;
-    a.tile_rows = nullptr; a.tile_sel = nullptr;     // every tile, no row
-    if (a.kp.family == FAM_SE) return launch_s2_rank1_fam<FAM_SE>(a, ntiles, s);
-    if (a.kp.family == FAM_M3) return launch_s2_rank1_fam<FAM_M3>(a, ntiles, s);
-    return launch_s2_rank1_fam<FAM_M5>(a, ntiles, s);
-}
 static int launch_s2_bound(const SweepArgs &a0, hipStream_t s)
 {
     SweepArgs a = a0;
@@ -816,8 +806,6 @@ static int launch_s2_bound(const SweepArgs &a0, hipStream_t s)
     return (int)hipGetLastError();
 }
 
-static std::atomic<int> g_part_means{1};                         // ibo_set_option("part_means", 0/1): the first part of a kept state forms the means itself
-void set_part_means(int v) { g_part_means = v; }
 // the part kernel has no moving alpha window and the means come from the refresh kernel: both must fit
 bool sweep2_part_fits(int Npad, int D) { return Npad >= 512 && ((Npad + 127) & ~127) <= s2_awin((D + 2 + 3) / 4) && sweep2_rank1_fits(Npad, D); }
 // The levels of a kept state (round 4; rounds 2-3 had two: rows [0, h) and [h, N) with h = N/2).  q = |W k*|^2 is a sum over W's rows
@@ -884,9 +872,8 @@ int launch_sweep2_pruned(const SweepArgs &a_in, bool prune, hipStream_t s, hipEv
     part_splits(a.Npad, nlev, h);
     const int64_t ntiles = (a.M + IBO_S2_TCAND - 1) / IBO_S2_TCAND;
     if (e0) (void)hipEventRecord(e0, s);
-    int rc = launch_s2_part(a, 0, h[0], a.part_thresh, s, g_part_means);        // (the means ride along with the first level)
+    int rc = launch_s2_part(a, 0, h[0], a.part_thresh, s, 1);        // (the means ride along with the first level)
     if (rc) return rc;
-    if (!g_part_means && (rc = launch_s2_means(a, s))) return rc;
     if (prune) {
         if ((rc = launch_s2_bound(a, s))) return rc;                               // bounds; nothing complete yet
         hipLaunchKernelGGL(part_select_kernel, dim3(1), dim3(1024), 0, s, (const double *)a.tile_ub, ntiles, a.part_thresh);

@@ -81,32 +81,23 @@ int         ibo_device_name(int device, char *buf, size_t buflen);
 /* self-test of the fp64 MFMA fragment layout on the device (returns IBO_OK or
  * IBO_ERR_HIP with a message); cheap, used by smoke() */
 int         ibo_selftest_mfma(int device, double *max_abs_err);
-/* tuning/testing knobs: "sweep_path" = 0 auto (the three small-batch kernels up to 4096 candidates, the MFMA tile kernel
- * above; GEMV / panel-split kernels where the dot form is not admissible), 1 force GEMV, 2 force MFMA tile,
- * 3 force panel-split; "sweep_variant" picks the tile shape; "dot_form" -1 auto / 0 / 1;
- * "chol_panel" P forces the Cholesky panel width in 64-blocks (0 = choose: 1 plain right-looking,
- * 4 two-level); "nlml_batch" B forces the matrices per batched factorisation in ibo_nlml_grid.
- * A/B switches of the fit path, every setting giving the same bits: "chol_fused" (one launch per block column up to
- * 2048 rows), "chol_fused2" (the same inside the panels of the two-level order beyond), "chol_ride" (W = L^-1 formed during
- * the factorisation), "chol_pipe" (software-pipelined block columns from ~1300 rows), "step_split" T (without it: block columns with more
- * than T tiles as two launches, row blocks then updates; 256),
- * "trinv_wide" (eight-wave tiles in the small levels of the triangular inversion), "update2_min_tiles", "fused2_min_nb" (block columns from which a fit takes the two-level order: 104; the order fixes
- * the rounding of L and W, so results at 2049 .. 6592 rows differ from ABI 5's in the last bits), "pipe_pairs" (block columns from which the
- * pipelined order applies two steps per pass over the trailing tiles: 12; same bits either way), "cov_fit" (the fit's own covariance pass; same bits).
- * ibo_nlml_grad: "wtw_waves" 4/8 (waves per tile of K^-1 = W^T W; same bits), "wtw_xcd" (block rows from which its tiles are dealt to the XCDs in
- * 8 x 8 super-blocks: 32; same bits), "grad_ard" 0/1 (the round-4 gradient kernel; 0: the first one --
- * the same value, the gradient to rounding).
- * ibo_nlml_grid (same values whatever the setting, except "cov_fast", which changes the covariance entries by a rounding error):
- * "chol_left" (left-looking outer order from one packed copy of the factor), "nlml_groups" (sub-batches on their own streams),
- * "chol_panel_rows" 0..3 (which kernel takes the rows below a panel), "cov_fast".  Small batches: "small_local" 0/1/2 (the
- * wave-local k* kernel: never / up to 512 observations / always; up to 10 dimensions).  Kept-state sweeps: "gallery_prune" 0/1/2
- * (see ibo_acq_sweep_incremental).  Diagnostics: "small_trace" 1 / 2 (start / print the host-side split of the small batches' time).
- * Env IBO_SWEEP_IMPL=gemv|mfma too.
+/* The ten option keys (everything else is decided by the data: sizes, dimensions, what the caller asks for).
+ * Functional:  "legacy_exact" 1/0 -- acqmaxGP in libego's operation order (default) or on the MFMA sweep kernels (see acqmaxGP);
+ *   "nlml_batch" B -- matrices per batched factorisation in ibo_nlml_grid (0: as many as 12 GB hold; the values do not depend on it);
+ *   "pool_limit_mb" n -- the per-device free list of recycled buffers (ibo_trim);
+ *   "fused2_min_nb" nb -- block columns (of 64 rows) from which a single matrix is factored in the two-level order (104; the order fixes the
+ *   last bits of L and W -- one rule for ibo_gp_fit, the preference GP and ibo_nlml_grad).
+ * Comparators kept for the tests (a second route to the same numbers):  "sweep_path" 0 auto (small2.hip's three kernels up to 4096
+ *   candidates, sweep2_kernel above; GEMV / panel-split / first-generation tile kernels where the dot form is not admissible) / 1 GEMV /
+ *   2 MFMA tile / 3 panel-split;  "dot_form" -1 auto / 0 / 1 (k* by differences or by the exponent GEMM);  "gallery_prune" 0/1/2 and
+ *   "part_levels" 2..4 (see ibo_acq_sweep_incremental);  "host_pipeline" 1/0 (large host batches in overlapped chunks or in one shot);
+ *   "chol_left" 1/0 (ibo_nlml_grid's left-looking order or the right-looking one: identical bits).
+ * Env: IBO_SWEEP_IMPL=gemv|mfma, IBO_DOT_FORM, IBO_POOL_LIMIT_MB, IBO_HOST_THREADS (the legacy symbol's host crew), IBO_DEVICE (legacy symbols).
  * Threading (the reference's library keeps its whole model in process-wide statics, cpp/optimizeGP.cpp:36-55,240-259, and is not
  * re-entrant; this one is): handles are independent of each other -- each has its own stream, events, staging and buffers --
  * so several threads may drive several handles on one device at the same time (one handle belongs to one thread at a time);
- * the buffer pool and the allocation table are mutexed; the per-device workspaces behind ibo_nlml_grid / ibo_nlml_grad, the
- * sweep's exp table and ibo_trim are serialised by a per-device mutex (concurrent grids on one device take turns); the last
+ * the buffer pool and the allocation table are mutexed; the per-device workspaces behind ibo_nlml_grid / ibo_nlml_grad and
+ * ibo_trim are serialised by a per-device mutex (concurrent grids on one device take turns; a sweep on another handle never waits for them); the last
  * error is thread-local.  The option switches are process-wide CONFIGURATION held in atomics: changing one while another
  * thread computes is defined but takes effect at an unspecified call boundary -- set them before the threads start.
  * (tests/test_gpu_gallery_oracle.py::test_two_threads_two_handles_one_device.) */
@@ -307,7 +298,7 @@ int ibo_acq_sweep(ibo_gp_t *gp, int64_t M, const double *cand_dev,
  * sf2_k / sqrt(sf2_fit) bounds |W k*|; no lazy mode where the fitted matrix admits no such bound):
  * nothing for observations on the posterior mean (the gallery's), everything for real ones -- reaches it are refreshed and
  * completed.  A call that wants per-candidate outputs (or IBO_ACQ_PI / IBO_ACQ_NONE), or a model with a mean prior, refreshes
- * and completes every tile first.  ibo_set_option("gallery_lazy", 0) refreshes and completes every tile on the first later call.
+ * and completes every tile first.
  * 512 <= padded rows <= 4096; 40 bytes of state per candidate.  ibo_set_option("gallery_prune", 0) restores the one-kernel
  * first sweep, 2 runs the same launches with every tile completed (what the pruned run is tested against, bit for bit).
  */
@@ -417,7 +408,9 @@ typedef double (*objective_t)(int, double *);
  * acquisition with the host's libm; aMb's two sequential sums per contraction on the device, products and sums rounded
  * separately), so fmin and xmin equal libego's BIT FOR BIT, whatever the conditioning of invR (csrc/legacy.hip).
  * Differences kept on purpose: kerneltype 3 takes its magnitude from hyperparams[1] (the reference reads hyperparams[ndim],
- * out of bounds for ndim > 1) and prints nothing.  ibo_set_option("legacy_exact", 0): the fast route (invR factored on the
+ * out of bounds for ndim > 1) and prints nothing; a kerneltype outside 0..3 (the reference's switch leaves k* uninitialised) returns NULL.
+ * The host half (k*, prior mean, acquisition: O(N D) per sample point) runs on a crew of host threads over the batch's points
+ * (IBO_HOST_THREADS, default min(16, the cores the process may use)).  ibo_set_option("legacy_exact", 0): the fast route (invR factored on the
  * device, MFMA sweep kernels; within 1e-6 of libego on well-conditioned data only).  Re-entrant: own handle per call. */
 const double *acqmaxGP(int ndim, double *lb, double *ub, double *invR, double *X, double *Y,
                        int nx, int acqfunc, int kerneltype, double *hyperparams,

@@ -401,7 +401,7 @@ def test_legacy_acqmaxGP_matern52(ibo, oracle):
     ref = oracle.RefLib()
     N, D = 500, 1
     X = np.clip(np.vstack([.3 + .01 * rs.randn(200, 1), rs.rand(300, 1)]), 0, 1); Y = np.sin(5 * X[:, 0]) + .01 * rs.randn(N)
-    ogp = oracle.GP(oracle.Kern("m5", [.4, 1.2]), X, Y, noise=1e-4)
+    ogp = oracle.GP(oracle.Kern("m5", [.4, 1.0]), X, Y, noise=1e-4)
     invR = f64(np.linalg.inv(ogp.R))
     for acq, parm in ((oracle.ACQ_EI, .01), (oracle.ACQ_PI, .05), (oracle.ACQ_UCB, 1.3)):
         for x in rs.rand(6, 1):

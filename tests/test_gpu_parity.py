@@ -259,9 +259,9 @@ def test_sweep_vs_oracle_ragged(ibo, oracle, N, D, kind, M):
     assert r["best_idx"] == sw["best_idx"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
-def test_sweep_tile_variants_agree(ibo, oracle, variant):
-    """every tile configuration of the MFMA kernel against the oracle (N spans 3 panels)"""
+def test_panel_split_kernel_in_dot_form_against_oracle(ibo, oracle):
+    """the panel-split form of the first-generation MFMA kernel in its dot form -- by default what takes small batches on models beyond
+    sweep2's LDS budget -- forced with sweep_path = 3 on a model of three 512-row panels, against the oracle"""
     from ibo_amd.gaussianprocess import GaussianProcess, kernel as K
     from ibo_amd.acquisition import sweep
     from ibo_amd import _lib
@@ -272,11 +272,12 @@ def test_sweep_tile_variants_agree(ibo, oracle, variant):
     ogp = oracle.GP(oracle.Kern("ard", hyper), X, Y, noise=.1)
     o_mu, o_s2 = ogp.posteriors(cand)
     GP = GaussianProcess(K.GaussianKernel_ard(hyper), X, Y, noise=.1)
-    _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", variant))
+    _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 3))
     try:
         r = sweep(GP, cand, acq='ucb', parm=1.2, native=True, outputs=("mu", "s2", "acq"))
     finally:
-        _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 2))
+        _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 0))
+    assert r["kernel"] == "sweep_mfma_kernel<split>"
     close(r["mu"], o_mu, atol=1e-9); close(r["s2"], o_s2)
     o = o_mu + 1.2 * np.sqrt(o_s2)
     close(r["acq"], o); assert r["best_idx"] == int(np.argmax(o))
@@ -410,11 +411,11 @@ def test_sweep2_kernel_against_oracle_and_the_other_kernels(ibo, oracle):
             cand = np.random.RandomState(N).rand(M, D)
             cand[77] = X[5]                                          # a candidate on top of an observation
             cand[M - 1] = cand[0]                                    # ragged last tile (M % 32 != 0) with a duplicate
-            _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 4))
             r = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
             assert r["kernel"] == "sweep2_kernel"
-            _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 2))
+            _lib.check(_lib.lib.ibo_set_option(b"dot_form", 0))      # k* by differences: the first-generation tile kernel
             r1 = sweep(GP, cand, acq='ei', xi=.01, native=True)
+            _lib.check(_lib.lib.ibo_set_option(b"dot_form", -1))
             assert r1["kernel"] == "sweep_mfma_kernel" and r1["best_idx"] == r["best_idx"]
             _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 1))
             rg = sweep(GP, cand[:600], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
@@ -428,7 +429,7 @@ def test_sweep2_kernel_against_oracle_and_the_other_kernels(ibo, oracle):
             close(r["mu"][idx], o["mu"], atol=1e-9); close(r["s2"][idx], o["s2"]); close(r["acq"][idx], o["acq"], atol=ACQ_ATOL)
             assert r["best_idx"] == int(np.argmax(r["acq"])) and r["s2"][77] < 1 / 1.1
     finally:
-        _lib.check(_lib.lib.ibo_set_option(b"sweep_variant", 4))
+        _lib.check(_lib.lib.ibo_set_option(b"dot_form", -1))
         _lib.check(_lib.lib.ibo_set_option(b"sweep_path", 0))
 
 
@@ -452,19 +453,12 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
             X, Y = synth(N + D, N, D)
             GP = GaussianProcess(kern, X, Y, noise=.1)
             cand = np.random.RandomState(N).rand(M, D); cand[min(M - 1, 7)] = X[5]
-            opt(b"small2", 1); r = sweep(GP, cand, outputs=("mu", "s2", "acq"))
+            # (up to 512 observations and 128 candidates the wave-local kernel runs -- k* made by the wave that multiplies it -- beyond,
+            # the separate k* / product kernels: the cases cover both)
+            r = sweep(GP, cand, outputs=("mu", "s2", "acq"))
             assert r["kernel"] == "wk_small_kernel"
-            if M <= 128 and N <= 4096:
-                # the wave-local kernel (k* made by the wave that multiplies it: the default up to 512 observations) forced on,
-                # and the separate k* / product kernels forced: same values to rounding
-                opt(b"small_local", 2); rl = sweep(GP, cand, outputs=("mu", "s2", "acq"))
-                opt(b"small_local", 0); rs = sweep(GP, cand, outputs=("mu", "s2", "acq"))
-                opt(b"small_local", 1)
-                for k in ("mu", "s2", "acq"):
-                    close(rl[k], rs[k], rtol=1e-9, atol=1e-11); close(rl[k], r[k], rtol=1e-9, atol=1e-11)
-                assert rl["best_idx"] == rs["best_idx"] == r["best_idx"]
-            opt(b"small2", 0); r0 = sweep(GP, cand, outputs=("mu", "s2", "acq"))
-            assert r0["kernel"] == ("sweep_gemv_kernel" if M <= 16 else "sweep_mfma_kernel<split>") and r0["best_idx"] == r["best_idx"]
+            opt(b"sweep_path", 3); r0 = sweep(GP, cand, outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
+            assert r0["kernel"] == "sweep_mfma_kernel<split>" and r0["best_idx"] == r["best_idx"]
             opt(b"sweep_path", 1); rg = sweep(GP, cand[:40], outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
             for k in ("mu", "s2", "acq"):
                 close(r[k], r0[k], rtol=1e-9, atol=1e-11); close(r[k][:40], rg[k], rtol=1e-9, atol=1e-11)
@@ -475,13 +469,13 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
         X, Y = synth(21, 300, 3)
         GP = GaussianProcess(K.GaussianKernel_ard([.25, .3, .35]), X, Y)
         runs = []
-        for s2, zc in ((1, 1), (0, 1), (1, 0), (0, 0)):
-            opt(b"small2", s2); opt(b"zero_copy", zc)
+        for path in (0, 3, 1):                             # small2.hip's kernels, the panel-split kernel, the GEMV kernel
+            opt(b"sweep_path", path)
             runs.append(gpuDirectGP(GP, [[0., 1.]] * 3, 30, 30, 10000, acqfunc='ei', xi=.01, return_samples=True))
         for v, x, ns in runs[1:]:
             assert ns == runs[0][2] and np.array_equal(x, runs[0][1]); close(v, runs[0][0], rtol=1e-9)
     finally:
-        opt(b"small2", 1); opt(b"zero_copy", 1); opt(b"sweep_path", 0); opt(b"small_local", 1)
+        opt(b"sweep_path", 0)
 
 
 def test_incremental_sweep_state_equals_full_sweeps(ibo):
@@ -1244,64 +1238,35 @@ def test_c5_nlml_full_size(ibo, oracle):
     assert np.array_equal(nlml_grid(GaussianKernel_ard, thetas[1:2], X, Y, noise=1e-3)[0], vals[1:2])   # deterministic
 
 
-def test_trinv_wave_layouts_agree(ibo):
-    """W = L^-1 by recursive doubling (fits beyond 2048 rows, the NLML gradient): levels with at most 512 tiles run
-    8-wave tiles, the others 4-wave tiles, tiles in longest-K-first order -- every element is the same chain of MFMAs, so
-    the two layouts give the same bits; and W L = I"""
-    from ibo_amd import _lib
-    from ibo_amd.gaussianprocess import GaussianProcess
-    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
-    for N in (2300, 3000):                                    # 36 / 47 blocks: ragged last nodes at every level
-        X, Y = synth(N, N, 6)
-        Ws = []
-        for wide in (1, 0):
-            _lib.check(_lib.lib.ibo_set_option(b"trinv_wide", wide))
-            try:
-                GP = GaussianProcess(GaussianKernel_ard([.5] * 6), X, Y, noise=.1)
-                W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
-                Ws.append(W)
-            finally:
-                _lib.check(_lib.lib.ibo_set_option(b"trinv_wide", 1))
-        assert np.array_equal(Ws[0], Ws[1])
-        assert np.abs(Ws[0] @ GP.L - np.eye(N)).max() < 1e-10 and np.abs(np.triu(Ws[0], 1)).max() == 0.0
-
-
-def test_two_level_fused_fit_equals_the_unfused_order(ibo):
-    """fits of more than 2048 rows: panels of four block columns, inside a panel one fused launch per column (out of place),
-    against the diagonal / row-block / update launches in place -- the same arithmetic in the same order, so L and W agree
-    bit for bit; also ragged sizes (a last panel of one, two, three columns) and a matrix that is not positive definite"""
+def test_two_level_order_agrees_with_the_single_level_order(ibo):
+    """A single matrix is factored in the pipelined single-level order (W riding along) below 104 block columns and in the two-level order
+    (panels of four block columns, K = 256 updates, recursive-doubling inversion) from there on; ibo_set_option("fused2_min_nb") moves
+    the switch.  Both against NumPy's Cholesky of GP.R at 1e-11 and against each other at 1e-12 (another order of the same sums), W L = I,
+    ragged sizes (a last panel of one, two, three columns), a matrix that is not positive definite in both orders; and one size in the
+    default two-level range (6720 rows: in-panel columns with more tiles than CUs take the rows-then-updates launches)."""
     from ibo_amd import _lib, NotPositiveDefinite
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+
+    def fit(X, Y, N, noise=.05):
+        GP = GaussianProcess(GaussianKernel_ard([.45] * X.shape[1]), X, Y, noise=noise)
+        W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+        return GP, GP.L.copy(), W
     for N in (2113, 2200, 2250, 3000):                        # 34, 35, 36, 47 blocks
         X, Y = synth(N + 1, N, 5)
-        res = []
-        # (fused2_min_nb = 33: the two-level order from 2049 rows on, as until round 4; since then it starts at 104 block columns and these
-        # sizes take the pipelined single-level order by default -- compared below, to rounding: another order of the same sums)
-        for fused2, split in ((1, 256), (0, 256), (1, 40)):      # split 40: in-panel columns as row blocks + updates (as beyond 5400 rows)
-            _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 33))
-            _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", fused2)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
-            try:
-                GP = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)
-                W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
-                res.append((GP.L.copy(), W))
-            finally:
-                _lib.check(_lib.lib.ibo_set_option(b"chol_fused2", 1)); _lib.check(_lib.lib.ibo_set_option(b"step_split", 256))
-                _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 104))
-        for L, W in res[1:]:
-            assert np.array_equal(res[0][0], L) and np.array_equal(res[0][1], W)
-        assert np.abs(res[0][0] - np.linalg.cholesky(GP.R)).max() < 1e-11 and np.abs(np.triu(res[0][0], 1)).max() == 0.0
-        GP = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)          # the default order at these sizes
-        W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
-        assert np.abs(GP.L - res[0][0]).max() < 1e-12 and np.abs(W - res[0][1]).max() < 1e-9 * max(1.0, np.abs(W).max())
-        assert np.abs(W.dot(GP.L) - np.eye(N)).max() < 1e-10 and np.all(np.triu(W, 1) == 0.0)
-        _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", 0))                         # ... with one step per pass over the trailing tiles: the same bits
+        _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 33))
         try:
-            GP1 = GaussianProcess(GaussianKernel_ard([.45] * 5), X, Y, noise=.05)
-            W1 = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP1._handle(), _lib.dp(W1)))
+            GP2, L2, W2 = fit(X, Y, N)
         finally:
-            _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", 12))
-        assert np.array_equal(GP1.L, GP.L) and np.array_equal(W1, W)
+            _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 104))
+        GP1, L1, W1 = fit(X, Y, N)                            # the default order at these sizes
+        R = np.array(GP1.R)
+        assert np.array_equal(R, R.T) and np.all(np.diag(R) == 1.05)
+        Lr = np.linalg.cholesky(R)
+        for L, W in ((L2, W2), (L1, W1)):
+            assert np.abs(L - Lr).max() < 1e-11 and np.abs(np.triu(L, 1)).max() == 0.0
+            assert np.abs(W.dot(L) - np.eye(N)).max() < 1e-10 and np.all(np.triu(W, 1) == 0.0)
+        assert np.abs(L1 - L2).max() < 1e-12 and np.abs(W1 - W2).max() < 1e-9 * max(1.0, np.abs(W1).max())
     Xd = np.vstack([X[:2199], X[77:78]])                      # a duplicate point and no noise
     for min_nb in (33, 104):                                   # in both orders
         _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", min_nb))
@@ -1310,186 +1275,70 @@ def test_two_level_fused_fit_equals_the_unfused_order(ibo):
                 GaussianProcess(GaussianKernel_ard([.45] * 5), Xd, Y[:2200], noise=0.0)
         finally:
             _lib.check(_lib.lib.ibo_set_option(b"fused2_min_nb", 104))
+    N = 6720                                                   # 105 block columns: two-level by default
+    X, Y = synth(N + 1, N, 6)
+    GP, L, W = fit(X, Y, N, noise=.1)
+    Lr = np.linalg.cholesky(np.array(GP.R))
+    assert np.abs(L - Lr).max() < 1e-11 and np.abs(np.triu(L, 1)).max() == 0.0
+    probe = np.random.RandomState(5).randint(0, N, 300)
+    assert np.abs(W[probe].dot(L) - np.eye(N)[probe]).max() < 1e-10 and np.all(np.triu(W, 1) == 0.0)
 
 
-def test_fit_covariance_pass_equals_the_general_kernel(ibo):
-    """the fit's own covariance pass (cov_fit_kernel: working copy, ride-along identity and info word, 32 x 32 tiles up to 2560 rows) leaves the
-    factor the general kernel's pass leaves, bit for bit; GP.R, formed on request since round 4, is the matrix that was factored"""
-    from ibo_amd import _lib
-    from ibo_amd.gaussianprocess import GaussianProcess
-    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard, MaternKernel3
-    for N, D in ((97, 2), (700, 5), (1024, 4), (2600, 9)):
-        X, Y = synth(N + 5, N, D)
-        for kern in (GaussianKernel_ard([.35] * D), MaternKernel3([.6] * D)):
-            res = []
-            for cf in (0, 1):
-                _lib.check(_lib.lib.ibo_set_option(b"cov_fit", cf))
-                try:
-                    GP = GaussianProcess(kern, X, Y, noise=1e-3)
-                    W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
-                    res.append((GP.L.copy(), W, np.array(GP.R)))
-                finally:
-                    _lib.check(_lib.lib.ibo_set_option(b"cov_fit", 1))
-            for a, b in zip(res[0], res[1]):
-                assert np.array_equal(a, b)
-            L, R = res[1][0], res[1][2]
-            assert np.abs(L @ L.T - R).max() < 1e-12 * N and np.array_equal(R, R.T) and np.all(np.diag(R) == 1.0 + 1e-3)
-    # ibo_nlml_grad takes the same pass: same value and gradient either way
-    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
-    X, Y = synth(1203, 1200, 3)
-    out = []
-    for cf in (0, 1):
-        _lib.check(_lib.lib.ibo_set_option(b"cov_fit", cf))
-        try:
-            out.append(marginalLikelihood(GaussianKernel_ard([.3, .4, .5]), X, Y, 3, True, noise=1e-2))
-        finally:
-            _lib.check(_lib.lib.ibo_set_option(b"cov_fit", 1))
-    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
-
-
-def test_se_ard_gradient_kernel_equals_the_general_one(ibo):
-    """dnlml runs in the round-4 kernel (the pairs' coordinates shared over a thread's 4 x 4 pairs, one short loop per derivative, lower tiles
-    counted twice): the first kernel's gradient to rounding, the same value, and the oracle's gradient -- SE-ARD here, the other families below"""
+def test_nlml_gradient_against_the_oracle_every_family(ibo):
+    """dnlml (csrc/assemble.hip nlml_grad_fast_kernel: the pairs' coordinates shared over a thread's 4 x 4 pairs, one short loop per
+    derivative, lower tiles counted twice) against the oracle's value and gradient (ego/gaussianprocess/trainhyper.py:47-95): SE-ARD in
+    2, 5 and 20 dimensions, SE-iso with signal variance, Matern-3/2, Matern-5/2, plain SE-iso"""
     import oracle.oracle as orc
-    from ibo_amd import _lib
-    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess import kernel as K
     from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
-    for N, theta in ((130, [.3, .6]), (700, [.3, .4, .5, .6, .7]), (1100, list(np.linspace(.8, 1.6, 20)))):
+    for N, theta in ((130, [.3, .6]), (700, [.3, .4, .5, .6, .7]), (500, list(np.linspace(.8, 1.6, 20)))):
         D = len(theta)
         X, Y = synth(N + D, N, D)
-        out = []
-        for fast in (0, 1):
-            _lib.check(_lib.lib.ibo_set_option(b"grad_ard", fast))
-            try:
-                out.append(marginalLikelihood(GaussianKernel_ard(theta), X, Y, D, True, noise=1e-2))
-            finally:
-                _lib.check(_lib.lib.ibo_set_option(b"grad_ard", 1))
-        g0, g1 = np.asarray(out[0][1]), np.asarray(out[1][1])
-        assert out[0][0] == out[1][0] and np.abs(g0 - g1).max() <= 1e-11 * np.abs(g0).max()
-        if N <= 700:
-            ov, od = orc.marginal_likelihood(orc.Kern("ard", theta), X, Y, D, True, 1e-2)
-            assert abs(out[1][0] - ov) <= 1e-9 * abs(ov) and np.abs(g1 - np.asarray(od)).max() <= 1e-8 * np.abs(od).max()
-    # SE-iso with signal variance, Matern-3/2, Matern-5/2 (one length scale each; test_g2_g8_marginal_likelihood holds them to the reference's values)
-    from ibo_amd.gaussianprocess import kernel as K
-    X, Y = synth(905, 900, 4)
-    for k, nh in ((K.SVGaussianKernel_iso([.7, 1.3]), 2), (K.MaternKernel3([.8, 1.1]), 2), (K.MaternKernel5([.9, 1.2]), 2), (K.GaussianKernel_iso([.6]), 1)):
-        out = []
-        for fast in (0, 1):
-            _lib.check(_lib.lib.ibo_set_option(b"grad_ard", fast))
-            try:
-                out.append(marginalLikelihood(k, X, Y, nh, True, noise=1e-2))
-            finally:
-                _lib.check(_lib.lib.ibo_set_option(b"grad_ard", 1))
-        g0, g1 = np.atleast_1d(out[0][1]), np.atleast_1d(out[1][1])
-        assert out[0][0] == out[1][0] and np.abs(g0 - g1).max() <= 1e-11 * np.abs(g0).max()
+        v, g = marginalLikelihood(K.GaussianKernel_ard(theta), X, Y, D, True, noise=1e-2)
+        ov, od = orc.marginal_likelihood(orc.Kern("ard", theta), X, Y, D, True, 1e-2)
+        assert abs(v - ov) <= 1e-9 * abs(ov) and np.abs(np.asarray(g) - np.asarray(od)).max() <= 1e-8 * np.abs(od).max()
+    X, Y = synth(405, 400, 4)
+    for k, ok, nh in ((K.SVGaussianKernel_iso([.7, 1.3]), orc.Kern("sviso", [.7, 1.3]), 2), (K.MaternKernel3([.8, 1.1]), orc.Kern("m3", [.8, 1.1]), 2),
+                      (K.MaternKernel5([.9, 1.2]), orc.Kern("m5", [.9, 1.2]), 2), (K.GaussianKernel_iso([.6]), orc.Kern("iso", [.6]), 1)):
+        v, g = marginalLikelihood(k, X, Y, nh, True, noise=1e-2)
+        ov, od = orc.marginal_likelihood(ok, X, Y, nh, True, 1e-2)
+        assert abs(v - ov) <= 1e-9 * abs(ov) and np.abs(np.atleast_1d(g) - np.atleast_1d(od)).max() <= 1e-7 * np.abs(od).max(), (type(k).__name__, g, od)
 
 
-def test_split_steps_equal_fused_steps(ibo):
-    """fits of up to 2048 rows: software-pipelined block columns (a launch holds column j's row blocks and the rest of step
-    j - 1's tiles), block columns as two launches (row blocks with the chain, then one product per tile), fused steps with two
-    tiles per workgroup: same arithmetic, same bits in L and W; and the same L as the three-kernel sequence in place; a
-    failed pivot is reported from each"""
-    from ibo_amd import _lib
+def test_single_level_fit_at_every_launch_shape(ibo):
+    """fits below 104 block columns: fused steps (up to three block columns), pipelined block columns with one step per pass over the trailing
+    tiles (4 .. 11 block columns) and with two (from 12), W = L^-1 riding along: L against NumPy's Cholesky of GP.R, W L = I; the NLML
+    gradient, which takes the same route (K^-1 = W^T W from the ride-along), against the oracle; a failed pivot in an early and a late
+    block column is reported"""
+    from ibo_amd import _lib, NotPositiveDefinite
     from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
-    for N in (1500, 2048, 1985, 1024, 700, 257):
+    for N in (60, 64, 129, 192, 193, 257, 700, 704, 768, 1024, 1500, 1985, 2048):
         X, Y = synth(N + 2, N, 4)
-        res = []
-        # software-pipelined columns on eight waves (the default: the row workgroups' own update runs under the chain) and on four;
-        # split / fused steps on eight and four waves
-        # (pairs: the pipelined order applying two steps per pass over the trailing tiles -- the default from 12 block columns on --, one
-        # step per pass, and two steps per pass forced from the first column)
-        for pipe, split, waves, pairs in ((1, 256, 8, 12), (1, 256, 8, 0), (1, 256, 8, 1), (1, 256, 4, 12), (0, 256, 8, 12), (0, 256, 4, 12), (0, 1 << 30, 8, 12),
-                                          (0, 1 << 30, 4, 12), (0, 64, 4, 12)):
-            _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
-            _lib.check(_lib.lib.ibo_set_option(b"step_waves", waves)); _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", pairs))
-            try:
-                GP = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05)
-                W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
-                res.append((GP.L.copy(), W))
-            finally:
-                _lib.check(_lib.lib.ibo_set_option(b"step_split", 256)); _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
-                _lib.check(_lib.lib.ibo_set_option(b"step_waves", 8)); _lib.check(_lib.lib.ibo_set_option(b"pipe_pairs", 12))
-        for L, W in res[1:]:
-            assert np.array_equal(L, res[0][0]) and np.array_equal(W, res[0][1])
-        _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 0))
-        try:
-            L0 = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05).L
-        finally:
-            _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 1))
-        assert np.array_equal(L0, res[0][0])
-        assert np.abs(res[0][1] @ res[0][0] - np.eye(N)).max() < 1e-10
-    # the NLML gradient takes the same route (K^-1 = W^T W from the ride-along): same value and gradient either way, and the oracle's
+        GP = GaussianProcess(GaussianKernel_ard([.4] * 4), X, Y, noise=.05)
+        W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+        L = GP.L
+        assert np.abs(L - np.linalg.cholesky(np.array(GP.R))).max() < 1e-11 and np.abs(np.triu(L, 1)).max() == 0.0, N
+        assert np.abs(W @ L - np.eye(N)).max() < 1e-10 and np.all(np.triu(W, 1) == 0.0), N
     import oracle.oracle as orc
     from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
     X, Y = synth(1603, 1600, 3)
-    out = []
-    for pipe, split in ((1, 256), (0, 256), (0, 1 << 30)):
-        _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe)); _lib.check(_lib.lib.ibo_set_option(b"step_split", split))
-        try:
-            out.append(marginalLikelihood(GaussianKernel_ard([.3, .4, .5]), X, Y, 3, True, noise=1e-2))
-        finally:
-            _lib.check(_lib.lib.ibo_set_option(b"step_split", 256)); _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
-    for o in out[1:]:
-        assert out[0][0] == o[0] and np.array_equal(out[0][1], o[1])
+    v, g = marginalLikelihood(GaussianKernel_ard([.3, .4, .5]), X, Y, 3, True, noise=1e-2)
     ov, od = orc.marginal_likelihood(orc.Kern("ard", [.3, .4, .5]), X, Y, 3, True, 1e-2)
-    close(out[0][0], ov); close(out[0][1], od, atol=1e-8)
-    # a failed pivot in a split step (an early and a late block column) is reported like anywhere else
-    from ibo_amd import NotPositiveDefinite
-    for pipe in (1, 0):
-        _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", pipe))
-        try:
-            for dup in (40, 1590):
-                Xd = X.copy(); Xd[dup + 5] = Xd[dup]
-                with pytest.raises(NotPositiveDefinite):
-                    GaussianProcess(GaussianKernel_ard([.3, .4, .5]), Xd, Y, noise=0.0)
-        finally:
-            _lib.check(_lib.lib.ibo_set_option(b"chol_pipe", 1))
+    close(v, ov); close(g, od, atol=1e-8)
+    for dup in (40, 1590):
+        Xd = X.copy(); Xd[dup + 5] = Xd[dup]
+        with pytest.raises(NotPositiveDefinite):
+            GaussianProcess(GaussianKernel_ard([.3, .4, .5]), Xd, Y, noise=0.0)
 
 
-def test_cholesky_panel_orders_agree(ibo):
-    """the two-level (panel = 4 block columns, K = 256 updates) and the plain right-looking factorisation give
-    the same factor to rounding; the batched NLML grid does not depend on what shares its launches"""
+def test_nlml_grid_does_not_depend_on_what_shares_its_launches(ibo):
+    """the batched NLML grid: the same values whatever the batch size, alone or together; a theta whose matrix is not positive definite
+    leaves nothing behind"""
     from ibo_amd import _lib
-    from ibo_amd.gaussianprocess import GaussianProcess
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
     from ibo_amd.gaussianprocess.trainhyper import nlml_grid
     X, Y = synth(9, 1000, 5)
-    Ls = []
-    for panel in (1, 4, 3):
-        _lib.check(_lib.lib.ibo_set_option(b"chol_panel", panel))
-        try:
-            Ls.append(GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05).L)
-        finally:
-            _lib.check(_lib.lib.ibo_set_option(b"chol_panel", 0))
-    Lr = np.linalg.cholesky(GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05).R)
-    for L in Ls:
-        assert np.abs(L - Lr).max() < 1e-12
-    # the fit path's fused one-launch-per-column factorisation rounds at the same points as the three-kernel
-    # sequence with panel = 1: same bits
-    fused = GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05)
-    _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 0))
-    try:
-        plain = GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05)
-        Lp, Wp = plain.L, plain.posteriors(X[:7] + .01)
-    finally:
-        _lib.check(_lib.lib.ibo_set_option(b"chol_fused", 1))
-    assert np.array_equal(fused.L, Lp) and np.array_equal(Ls[0], Lp)
-    # W = L^-1 comes out of the fused launches themselves (identity rows appended below the matrix) or, with
-    # chol_ride = 0 and beyond 24 block columns, from the recursive-doubling inversion: same W to rounding, and
-    # the latter is the very sequence the unfused path runs
-    close(np.array(fused.posteriors(X[:7] + .01)), np.array(Wp), rtol=1e-11, atol=1e-13)
-    _lib.check(_lib.lib.ibo_set_option(b"chol_ride", 0))
-    try:
-        noride = GaussianProcess(GaussianKernel_ard([.35] * 5), X, Y, noise=.05)
-        assert np.array_equal(noride.L, Lp)
-        assert np.array_equal(np.array(noride.posteriors(X[:7] + .01)), np.array(Wp))
-    finally:
-        _lib.check(_lib.lib.ibo_set_option(b"chol_ride", 1))
-    Wa = np.empty((1000, 1000)); Wb = np.empty((1000, 1000))
-    _lib.check(_lib.lib.ibo_gp_get_W(fused._handle(), _lib.dp(Wa))); _lib.check(_lib.lib.ibo_gp_get_W(noride._handle(), _lib.dp(Wb)))
-    close(Wa, Wb, rtol=1e-10, atol=1e-12)
-    assert np.all(np.triu(Wa, 1) == 0.0) and np.abs(Wa.dot(fused.L) - np.eye(1000)).max() < 1e-11
     thetas = np.exp(np.random.RandomState(3).uniform(np.log(.2), np.log(2), size=(7, 5)))
     vals, _ = nlml_grid(GaussianKernel_ard, thetas, X[:300], Y[:300], noise=.01)
     for b in (1, 2, 7):
@@ -1511,16 +1360,16 @@ def test_cholesky_panel_orders_agree(ibo):
         _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 0))
     assert not np.isfinite(v3[0]) or v3[0] == 100.0
     assert np.all(np.isfinite(ref)) and np.array_equal(v3[1:], ref)
-    # the rows below a panel in one launch (chol_panel_rows_kernel, taken when rows x batch fill the chip) or as the
-    # per-column trsm / update launches it replaces: the same bits
+    # the rows below a panel in one launch (chol_panel_rows8r_kernel, taken when rows x batch fill the chip: 24 matrices) or as the
+    # per-column trsm / update launches it replaces (one matrix at a time): the same bits
     Xb, Yb = synth(12, 1100, 4)
     tb = np.exp(np.random.RandomState(4).uniform(np.log(.2), np.log(2), size=(24, 4)))
     va, _ = nlml_grid(GaussianKernel_ard, tb, Xb, Yb, noise=.01)
-    _lib.check(_lib.lib.ibo_set_option(b"chol_panel_rows", 0))
+    _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 1))
     try:
         vb, _ = nlml_grid(GaussianKernel_ard, tb, Xb, Yb, noise=.01)
     finally:
-        _lib.check(_lib.lib.ibo_set_option(b"chol_panel_rows", 1))
+        _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 0))
     assert np.all(np.isfinite(va)) and np.array_equal(va, vb)
 
 
@@ -1747,7 +1596,6 @@ def test_seventeen_to_thirty_two_dimensions(ibo, oracle):
                 close(GP.R, ogp.R, rtol=1e-12); close(GP.L, ogp.L, rtol=1e-8, atol=1e-12)
             M = 8300
             cand = np.random.RandomState(N).rand(M, D); cand[77] = X[5]; cand[M - 1] = cand[0]
-            opt(b"sweep_variant", 4)
             r = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
             assert r["kernel"] == "sweep2_kernel"
             idx = np.r_[np.arange(0, M, M // 40), 77, M - 1, r["best_idx"]]
@@ -1755,24 +1603,24 @@ def test_seventeen_to_thirty_two_dimensions(ibo, oracle):
             close(r["mu"][idx], o["mu"], atol=1e-9); close(r["s2"][idx], o["s2"]); close(r["acq"][idx], o["acq"], atol=ACQ_ATOL)
             assert r["best_idx"] == int(np.argmax(r["acq"]))
             # the first-generation tile kernel (difference form), the GEMV kernel, the small-batch kernels and the split form
-            opt(b"sweep_variant", 2)
+            opt(b"dot_form", 0)
             r1 = sweep(GP, cand, acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
-            opt(b"sweep_variant", 4)
+            opt(b"dot_form", -1)
             assert r1["kernel"] == "sweep_mfma_kernel" and r1["best_idx"] == r["best_idx"]
             close(r1["mu"], r["mu"], rtol=1e-9, atol=1e-10); close(r1["s2"], r["s2"], rtol=1e-9)
             opt(b"sweep_path", 1); rg = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
             assert rg["kernel"] == "sweep_gemv_kernel"
             rs = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq"))
             assert rs["kernel"] == "wk_small_kernel"
-            opt(b"small2", 0); rp = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq")); opt(b"small2", 1)
+            opt(b"sweep_path", 3); rp = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
             assert rp["kernel"] == "sweep_mfma_kernel<split>"
             for k in ("mu", "s2", "acq"):
                 for other in (rg, rs, rp):
                     close(other[k], r[k][:300], rtol=1e-9, atol=1e-11)
             for form in (0, 1):                                   # the split kernel in both distance forms
-                opt(b"dot_form", form); opt(b"small2", 0)
+                opt(b"dot_form", form); opt(b"sweep_path", 3)
                 rf = sweep(GP, cand[:300], acq='ei', xi=.01, native=True, outputs=("mu", "s2"))
-                opt(b"dot_form", -1); opt(b"small2", 1)
+                opt(b"dot_form", -1); opt(b"sweep_path", 0)
                 close(rf["mu"], r["mu"][:300], rtol=1e-9, atol=1e-10); close(rf["s2"], r["s2"][:300], rtol=1e-9)
             # one point (posterior(x): inline candidates), Python-flavoured acquisition
             mu1, s21 = GP.posterior(cand[3]); o1 = ogp.posteriors(cand[3:4])
@@ -1824,7 +1672,7 @@ def test_seventeen_to_thirty_two_dimensions(ibo, oracle):
         with pytest.raises(Exception):
             GaussianProcess(K.GaussianKernel_iso([1.5]), np.random.rand(10, 65), np.random.rand(10), noise=.1).posterior(np.zeros(65))
     finally:
-        opt(b"sweep_variant", 4); opt(b"sweep_path", 0); opt(b"small2", 1); opt(b"dot_form", -1)
+        opt(b"sweep_path", 0); opt(b"dot_form", -1)
 
 
 def test_thirty_three_to_sixty_four_dimensions(ibo, oracle):
@@ -1905,4 +1753,4 @@ def test_thirty_three_to_sixty_four_dimensions(ibo, oracle):
         o, ox, _ = oracle.acqmax_native(ogp, [[0., 1.]] * 36, oracle.ACQ_EI, .01, maxiter=4)
         close(opt_v, o, atol=ACQ_ATOL); close(opt_x, ox, rtol=1e-9, atol=1e-12)
     finally:
-        opt(b"sweep_variant", 4); opt(b"sweep_path", 0); opt(b"small2", 1); opt(b"dot_form", -1)
+        opt(b"sweep_path", 0); opt(b"dot_form", -1)

@@ -9,7 +9,7 @@ from ibo_amd.gaussianprocess.trainhyper import nlml_grid
 rs = np.random.RandomState(5); X = rs.rand(4096, 16); Y = np.sin(3 * X.sum(1)) + 0.01 * rs.randn(4096)
 th = np.exp(np.random.RandomState(105).uniform(np.log(.1), np.log(3), size=(64, 16)))
 settings = sys.argv[1:] or ["nlml_batch=0"]
-DEFAULTS = dict(nlml_batch=0, chol_left=1, cov_fast=1, nlml_groups=2, chol_panel_rows=3, chol_panel=0, chol_panel_diag=1, chol_tail=20)
+DEFAULTS = dict(nlml_batch=0, chol_left=1)
 ref = None
 res = {s: [] for s in settings}
 for rnd in range(4):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # every rNN artefact under profiles/ from one GPU-box session (run from the repo root):  bash tools/profile_all.sh rNN
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/final_$TAG profiles
 O=gpurun_out/final_$TAG
@@ -10,15 +10,12 @@ python3 bench.py --steps 20 --warmup 3 > profiles/${TAG}_bench_n1.json 2> $O/ben
 python3 bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > profiles/${TAG}_bench_c3_n1.json 2> $O/bench_c3.err
 python3 bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > profiles/${TAG}_bench_c5_n1.json 2> $O/bench_c5.err
 python3 tools/run_configs.py c2 c3 c4 c5 > profiles/${TAG}_configs_c2_c5.jsonl 2> $O/configs.err
-{ python3 tools/time_fit.py; python3 tools/time_direct.py; python3 tools/time_single_calls.py; python3 tools/time_learn.py; python3 tools/sweep_vs_dim.py; } > profiles/${TAG}_latencies.txt 2> $O/lat.err
+{ python3 tools/time_fit.py; python3 tools/time_direct.py; python3 tools/time_single_calls.py; python3 tools/time_learn.py; } > profiles/${TAG}_latencies.txt 2> $O/lat.err
 python3 tools/time_incremental.py > profiles/${TAG}_time_incremental.txt 2> $O/inc.err
 { for c in c2 c3 c4; do for l in 4 3 2; do python3 tools/argmax_only.py $c $l; done; done; } > profiles/${TAG}_argmax_only.txt 2> $O/argmax.err
 { python3 tools/legacy_probe.py 1e-4 1 2>&1 | grep -a "per-point\|maxiter 10\|legacy_exact" | cut -c1-260; python3 tools/legacy_probe.py 1e-4 0 2>&1 | grep -a "per-point\|maxiter 10\|legacy_exact" | cut -c1-260; } > profiles/${TAG}_legacy_probe.txt
-python3 tools/check_step8.py > profiles/${TAG}_fit_wave_ab.txt 2> $O/step8.err
-python3 tools/check_pairs.py > profiles/${TAG}_fit_pairs_ab.txt 2> $O/pairs.err
 bash tools/pipe_columns.sh 4096 > profiles/${TAG}_pipe8_n4096_columns_pairs.txt 2>&1
-[ -f tools/libibo_hip_stamps.so ] && { IBO_HIP_LIB=tools/libibo_hip_stamps.so IBO_PIPE_STAMPS=1 python3 tools/time_fit.py 1024 2048 2>&1 | tail -8; } > profiles/${TAG}_pipe8_stamps.txt
-{ [ -x tools/launch_floor ] && tools/launch_floor; python3 tools/time_small_split.py 2>&1; } > profiles/${TAG}_direct_batch_floor.txt 2> $O/floor.err
+{ [ -x tools/launch_floor ] && tools/launch_floor; } > profiles/${TAG}_direct_batch_floor.txt 2> $O/floor.err
 timeout 600 python3 tools/fuzz_nlml.py 60 7 > $O/fuzz_nlml.txt 2>&1; tail -4 $O/fuzz_nlml.txt > profiles/${TAG}_fuzz_nlml_summary.txt
 timeout 900 python3 tools/fuzz_gallery.py 400 7 > $O/fuzz_gallery.txt 2>&1; { grep -c " ok:" $O/fuzz_gallery.txt; grep "FAIL" $O/fuzz_gallery.txt | head; tail -1 $O/fuzz_gallery.txt; } > profiles/${TAG}_fuzz_gallery_summary.txt
 for n in 1024 2048 4096; do bash tools/fit_trace.sh $n > profiles/${TAG}_fit_trace_$n.txt 2>&1; done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""one maximizeEI (DIRECT, 50 iterations) at three model sizes; key=value arguments are ibo_set_option switches, e.g. small_local=2 (GPU box)"""
+"""one maximizeEI (DIRECT, 50 iterations) at three model sizes; key=value arguments are ibo_set_option switches, e.g. sweep_path=3 (GPU box)"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
