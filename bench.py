@@ -566,6 +566,30 @@ def worker(args):
                                                          kernels="batched cov_matrix + left-looking chol_update3 (dominant) + chol_panel_rows8 + in-panel chain + reduce"),
                                            "c5")}
             _lib.trim(local_rank)
+            # hyper-parameter learning's inner loop (ego/gaussianprocess/trainhyper.py:77-95,130-136): one NLML value + gradient
+            # w.r.t. every log length scale = fit chain with W riding along, K^-1 = W^T W, the contraction with dK/dtheta.  Host X, Y in,
+            # value + gradient out; rank 0 (single-GPU, replicated)
+            if rank == 0:
+                from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+                ng = {}
+                for n, d in ((1024, 16), (4096, 16)):
+                    Xg, Yg = synth(9, n, d)
+                    kern = GaussianKernel_ard([.5] * d)
+                    ms = []
+                    for _ in range(6):
+                        t0 = time.perf_counter()
+                        marginalLikelihood(kern, Xg, Yg, d, True, noise=1e-3)
+                        ms.append((time.perf_counter() - t0) * 1e3)
+                    per = float(np.median(ms[1:]))
+                    fl = f_nlml(n, d) + 2.0 * n ** 3 / 3.0 + d * 2.0 * n * n          # with gradient add 2N^3/3 + D 2N^2
+                    ng["N%d_D%d" % (n, d)] = {"ms": per, "first_call_ms": ms[0],
+                                              "roofline": attach_pmc(roofline_mfma(fl, per * 1e-3, flops_per_evaluation=fl,
+                                                                                   algorithmic_bytes_per_evaluation=8 * n * d + 4 * 8 * n * n,
+                                                                                   kernels="cov_fit + chol_pipe8 (W riding along) + transpose_pack + wtw_kernel (K^-1 = W^T W, lower blocks) + nlml_grad_fast + reductions"),
+                                                                     "learn%d" % n)}
+                cfgs["nlml_grad"] = {"workload": "one marginalLikelihood(..., computeGradient=True) evaluation, SE-ARD, D = 16 length scales, host X, Y in, value + gradient out (wall, median of 5)",
+                                     "results": ng}
+                _lib.trim(local_rank)
             # C4: preference GP, one GPU only (the MAP is a sequential Newton iteration)
             if world == 1:
                 rs = np.random.RandomState(4)

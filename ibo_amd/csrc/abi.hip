@@ -60,9 +60,7 @@ static std::atomic<int> g_chol_left{1};      // ibo_set_option("chol_left", 0/1)
 static std::atomic<int> g_dot_override{-1};  // ibo_set_option("dot_form", -1/0/1): -1 auto, 0/1 force the difference / dot form of k* (tests)
 static std::atomic<int> g_legacy_exact{1};   // ibo_set_option("legacy_exact", 0/1): acqmaxGP evaluates libego's formulas in libego's operation order (legacy.hip)
 static std::atomic<int> g_force_path{0};     // ibo_set_option("sweep_path"): 0 auto, 1 gemv, 2 mfma, 3 panel-split (IBO_SWEEP_IMPL env / tests)
-static const int kNlmlGroups = 2;            // a batch of theta-points runs as two sub-batches on two streams (one's latency-bound in-panel chain and launch
-                                 // tails beside the other's MFMA-bound updates; three or four measured slower); values do not depend on it
-
+static std::atomic<int> g_nlml_groups{2};    // IBO_NLML_GROUPS=1..4 (env): a batch of theta-points runs as that many sub-batches, each on its own stream(s); values do not depend on it
 // The option switches above are process-wide configuration (atomics: setting one while another thread computes is a defined,
 // if unspecified-moment, change); the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad and ibo_trim are serialised by
 // g_dev_mu (the exp table has its own lock, held only while it is created); handles are independent of each other (own stream,
@@ -84,6 +82,8 @@ static int use_device(int device)
         const char *s = getenv("IBO_SWEEP_IMPL");
         if (s && !strcmp(s, "gemv")) g_force_path = 1;
         if (s && !strcmp(s, "mfma")) g_force_path = 2;
+        set_left_tail(getenv("IBO_NLML_TAIL") ? atoi(getenv("IBO_NLML_TAIL")) : -1, getenv("IBO_NLML_TAIL_KC") ? atoi(getenv("IBO_NLML_TAIL_KC")) : -1);
+        if (const char *a = getenv("IBO_NLML_GROUPS")) { const int v = atoi(a); if (v >= 1 && v <= 4) g_nlml_groups = v; }
         const char *pl = getenv("IBO_POOL_LIMIT_MB");
         if (pl && atoll(pl) >= 0) g_pool_limit = (size_t)atoll(pl) << 20;
     });
@@ -1653,21 +1653,22 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
         const int nb = n_theta - t0 < B ? n_theta - t0 : B;
         // sub-batches of at least 8 matrices, each on its own stream: one's in-panel chain (64 workgroups at a time, latency)
         // and launch tails run beside the other's long-K updates
-        int G = left ? kNlmlGroups : 1;
+        int G = left ? g_nlml_groups.load() : 1;
         while (G > 1 && nb / G < 8) G--;
+        CholGroup grp[4];
         for (int g = 0; g < G; g++) {
-            if (G > 1 && !ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
-            hipStream_t sg = G > 1 ? ws.streams[g] : s;
+            if (!ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
+            hipStream_t sg = ws.streams[g];
             const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
+            grp[g] = CholGroup{dL.p + nn * k0, d64.p + (size_t)(Np / 64) * 4096 * k0, ws.dP.p + pws * k0, dinfo.p + t0 + k0, ng, sg};
             KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg));
             KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
-            // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
-            if (left) KERNEL_TRY(launch_cholesky_batched_left(dL.p + nn * k0, Np, d64.p + (size_t)(Np / 64) * 4096 * k0, dinfo.p + t0 + k0, ng, nn, 4, sg,
-                                                              ws.dP.p + pws * k0, pws, N + 1, N % 64 == 0 ? Np / 64 - 1 : Np / 64, N / 64));
-            else KERNEL_TRY(launch_cholesky_batched(dL.p + nn * k0, Np, d64.p + (size_t)(Np / 64) * 4096 * k0, dinfo.p + t0 + k0, ng, nn, 4, sg, ws.dP.p + pws * k0, pws));
-            KERNEL_TRY(launch_nlml_reduce(dL.p + nn * k0, Np, N, dout.p + 2 * (t0 + k0), sg, ng, nn));
         }
-        if (G > 1) for (int g = 0; g < G; g++) HIP_TRY(hipStreamSynchronize(ws.streams[g]));      // the next batch reuses the matrix slots
+        // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
+        if (left) KERNEL_TRY(launch_cholesky_batched_left(grp, G, Np, nn, 4, pws, N + 1, N % 64 == 0 ? Np / 64 - 1 : Np / 64, N / 64));
+        else KERNEL_TRY(launch_cholesky_batched(grp[0].L, Np, grp[0].diag64, grp[0].info, grp[0].batch, nn, 4, grp[0].stream, grp[0].Pk, pws));      // (G = 1)
+        for (int g = 0; g < G; g++) KERNEL_TRY(launch_nlml_reduce(grp[g].L, Np, N, dout.p + 2 * (size_t)(grp[g].info - dinfo.p), grp[g].stream, grp[g].batch, nn));
+        for (int g = 0; g < G; g++) HIP_TRY(hipStreamSynchronize(ws.streams[g]));      // the next batch reuses the matrix slots 
     }
     HIP_TRY(hipStreamSynchronize(s));
     std::vector<double> out(2 * (size_t)n_theta);

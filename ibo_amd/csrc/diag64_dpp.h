@@ -98,12 +98,13 @@ __device__ __forceinline__ void panel_from(double (&a)[16], double (&w)[16])
 }
 // Factor the panel of 16 columns at o: S[o.., o..o+15] becomes the factor's columns (the diagonal block's strict
 // upper triangle is left with by-products of the elimination: scratch), V[o..o+15][o..o+15] the inverse of the
-// diagonal block.  `Id`: a 16x16 identity in LDS (row stride SD).  One wave.
+// diagonal block.  `Id`: a 16x16 identity in LDS (row stride TD).  One wave.
+template <int TD>
 __device__ __forceinline__ void diag64_panel(double *S, double *V, const double *Id, int o, int pivot0, int *info)
 {
     const int lane = threadIdx.x & 63, dr = lane & 15;
     const int rb = min(o + 16 + lane, 63);
-    const double *wrow = (lane >= 48) ? Id + (lane - 48) * SD : S + rb * SD + o;
+    const double *wrow = (lane >= 48) ? Id + (lane - 48) * TD : S + rb * SD + o;
     double a[16], w[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -142,13 +143,14 @@ __device__ __forceinline__ void diag64_panel(double *S, double *V, const double 
 }
 
 // one wave: 16x16 tiles out of LDS
-template <int K>
-__device__ __forceinline__ d4_t diag64_mm(const double *Am, const double *Bm) { return lds_mm16<false, K>(Am, Bm); }
+template <int K, int LDA = SD, int LDB = SD>
+__device__ __forceinline__ d4_t diag64_mm(const double *Am, const double *Bm) { return lds_mm16<false, K, LDA, LDB>(Am, Bm); }
+template <int LD = SD>
 __device__ __forceinline__ void diag64_put(double *Dst, int r0, int c0, d4_t v)
 {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int r = 0; r < 4; r++) Dst[(r0 + MM16_ROW(r)) * SD + c0 + MM16_COL] = v[r];
+    for (int r = 0; r < 4; r++) Dst[(r0 + MM16_ROW(r)) * LD + c0 + MM16_COL] = v[r];
 }
 // trailing-update tile (it, kt) of the panel at o:  S[o+16+16 it.., o+16+16 kt..] -= X_it X_kt^T
 __device__ __forceinline__ void diag64_update_tile(double *S, int o, int it, int kt)
@@ -161,7 +163,8 @@ __device__ __forceinline__ void diag64_update_tile(double *S, int o, int it, int
 }
 
 // S: the 64x64 block (row stride SD), V: zeros, T: a 16x16 identity in its first 16 rows (diag64_load leaves them
-// so).  On return S holds the factor (lower triangle; the strict upper
+// so); T has row stride TD >= 49 (the chain touches its columns 0..47 only: a kernel that uses T for nothing else gives it 64 x 49 doubles and
+// stays under the 96 KB of LDS that fit beside a 64 KB workgroup of another kernel on the same CU).  On return S holds the factor (lower triangle; the strict upper
 // part of the off-diagonal 16-blocks is scratch), V its inverse.  T is scratch.  Called by all threads of the workgroup (waves 0..3 work); ends
 // with a barrier.  With 16-blocks L_ij of the factor and V_i = L_ii^-1:
 //   [L11 0; L21 L22]^-1 = [V11 0; -V22 L21 V11, V22]   at the 32- and at the 64-level.
@@ -169,14 +172,14 @@ __device__ __forceinline__ void diag64_update_tile(double *S, int o, int it, int
 // the barriers: it must be short enough (~3 k cycles) not to hold the chain's barriers up, and it must stay off wave 4, which shares
 // its SIMD -- hence the fp64 pipe -- with wave 0.
 struct Diag64NoSide { __device__ __forceinline__ void operator()(int) const {} };
-template <typename Side = Diag64NoSide>
+template <int TD = SD, typename Side = Diag64NoSide>
 __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, double *T, int pivot0, int *info, Side side = Side())
 {
     const int t = threadIdx.x, wv = t >> 6;
     for (int b = 0; b < 4; b++) {
         const int o = 16 * b;
         if (wv == 0) {
-            diag64_panel(S, V, T, o, pivot0, info);
+            diag64_panel<TD>(S, V, T, o, pivot0, info);
         } else if (wv > 3) {
             // (an eight-wave workgroup: waves 4..7 keep the barriers' count -- chol_step8_kernel -- or do the caller's side work)
             side(b);
@@ -186,8 +189,8 @@ __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, doubl
         } else if (b == 2) {
             if (wv == 3) diag64_update_tile(S, 16, 1, 1);
             if (wv == 1) {                          // upper-left 32x32 node: V[16..31][0..15] = -V1 (L10 V0)
-                diag64_put(T, 16, 0, diag64_mm<16>(S + 16 * SD, V));
-                diag64_put(V, 16, 0, -diag64_mm<16>(V + 16 * SD + 16, T + 16 * SD));
+                diag64_put<TD>(T, 16, 0, diag64_mm<16>(S + 16 * SD, V));
+                diag64_put(V, 16, 0, -diag64_mm<16, SD, TD>(V + 16 * SD + 16, T + 16 * TD));
             }
         } else if (b == 3 && wv < 3) {
             // everything of the 64-level that does not need V3, for the column half c = 0 / 16 of this wave:
@@ -196,14 +199,14 @@ __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, doubl
             //   T32 = L32 V2  (both waves form it; same values)   (T[48..63][32..47])
             //   Q = T'[48..63] - T32 T'[32..47]                   (T[16..31][c..]);  what remains is -V3 Q
             const int c = 16 * (wv - 1), lane = t & 63;
-            diag64_put(T, 32, c, diag64_mm<32>(S + 32 * SD, V + c));
-            diag64_put(T, 48, c, diag64_mm<32>(S + 48 * SD, V + c));
-            diag64_put(T, 48, 32, diag64_mm<16>(S + 48 * SD + 32, V + 32 * SD + 32));
-            diag64_put(V, 32, c, -diag64_mm<16>(V + 32 * SD + 32, T + 32 * SD + c));
-            const d4_t q = diag64_mm<16>(T + 48 * SD + 32, T + 32 * SD + c);
+            diag64_put<TD>(T, 32, c, diag64_mm<32>(S + 32 * SD, V + c));
+            diag64_put<TD>(T, 48, c, diag64_mm<32>(S + 48 * SD, V + c));
+            diag64_put<TD>(T, 48, 32, diag64_mm<16>(S + 48 * SD + 32, V + 32 * SD + 32));
+            diag64_put(V, 32, c, -diag64_mm<16, SD, TD>(V + 32 * SD + 32, T + 32 * TD + c));
+            const d4_t q = diag64_mm<16, TD, TD>(T + 48 * TD + 32, T + 32 * TD + c);
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                T[(16 + MM16_ROW(r)) * SD + c + MM16_COL] = T[(48 + MM16_ROW(r)) * SD + c + MM16_COL] - q[r];
+                T[(16 + MM16_ROW(r)) * TD + c + MM16_COL] = T[(48 + MM16_ROW(r)) * TD + c + MM16_COL] - q[r];
         }
         __syncthreads();
         // the part of the trailing update the next panel reads: tiles (it, 0)
@@ -211,7 +214,7 @@ __device__ __forceinline__ void diag64_factor_invert(double *S, double *V, doubl
         if (b < 3) __syncthreads();
     }
     // V3 is in place: V[48..63][32..47] = -V3 T32,  V[48..63][c..] = -V3 Q
-    if (wv == 0) diag64_put(V, 48, 32, -diag64_mm<16>(V + 48 * SD + 48, T + 48 * SD + 32));
-    else if (wv < 3) diag64_put(V, 48, 16 * (wv - 1), -diag64_mm<16>(V + 48 * SD + 48, T + 16 * SD + 16 * (wv - 1)));
+    if (wv == 0) diag64_put(V, 48, 32, -diag64_mm<16, SD, TD>(V + 48 * SD + 48, T + 48 * TD + 32));
+    else if (wv < 3) diag64_put(V, 48, 16 * (wv - 1), -diag64_mm<16, SD, TD>(V + 48 * SD + 48, T + 16 * TD + 16 * (wv - 1)));
     __syncthreads();
 }

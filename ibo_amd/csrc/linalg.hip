@@ -16,6 +16,7 @@
 //   * the likelihood grid: left-looking from a packed copy of the factor (launch_cholesky_batched_left, update3.hip).
 // Covariance assembly, packing, the alpha vectors, the gradient contraction and the small per-model kernels: assemble.hip.
 #include "ibo_common.h"
+#include <atomic>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -122,7 +123,7 @@ __device__ __forceinline__ double lane_bcast(double x, int l)          // value 
 // one wave: 16x16 (+)= A(16xK) * B(Kx16) with both operands in LDS (row stride SD).
 // A element (r,k) = Am[r*SD + k];  B element (k,c) = TB ? Bm[c*SD + k] : Bm[k*SD + c].
 // Result element r of the returned vector is row (lane>>4)+4r, column lane&15.
-template <bool TB, int K>
+template <bool TB, int K, int LDA = SD, int LDB = SD>
 __device__ __forceinline__ d4_t lds_mm16(const double *Am, const double *Bm)
 {
     const int lane = threadIdx.x & 63, ar = lane & 15, q = lane >> 4;
@@ -130,8 +131,8 @@ __device__ __forceinline__ d4_t lds_mm16(const double *Am, const double *Bm)
     double a[K / 4], b[K / 4];
 #pragma unroll
     for (int s = 0; s < K / 4; s++) {               // all LDS reads in flight before the first MFMA
-        a[s] = Am[ar * SD + 4 * s + q];
-        b[s] = TB ? Bm[ar * SD + 4 * s + q] : Bm[(4 * s + q) * SD + ar];
+        a[s] = Am[ar * LDA + 4 * s + q];
+        b[s] = TB ? Bm[ar * LDB + 4 * s + q] : Bm[(4 * s + q) * LDB + ar];
     }
 #pragma unroll
     for (int s = 0; s < K / 4; s++) acc = mfma_f64(a[s], b[s], acc);
@@ -166,6 +167,7 @@ __device__ __forceinline__ void diag64_fetch(const double *Lb, int Npad, double 
 #pragma unroll
     for (int u = 0; u < 16; u++) v[u] = Lb[(size_t)(4 * u + (t >> 6)) * Npad + (t & 63)];
 }
+template <int TD = SD>
 __device__ __forceinline__ void diag64_stash(const double (&v)[16], double *S, double *V, double *T)
 {
     const int t = threadIdx.x;
@@ -174,13 +176,14 @@ __device__ __forceinline__ void diag64_stash(const double (&v)[16], double *S, d
         S[(4 * u + (t >> 6)) * SD + (t & 63)] = v[u];
         V[(4 * u + (t >> 6)) * SD + (t & 63)] = 0.0;
     }
-    T[(t >> 4) * SD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;       // diag64_dpp.h: the identity rows
+    T[(t >> 4) * TD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;       // diag64_dpp.h: the identity rows
 }
+template <int TD = SD>
 __device__ __forceinline__ void diag64_load(const double *Lb, int Npad, double *S, double *V, double *T)
 {
     double v[16];
     diag64_fetch(Lb, Npad, v);
-    diag64_stash(v, S, V, T);
+    diag64_stash<TD>(v, S, V, T);
 }
 
 __device__ __forceinline__ void diag64_store(double *Lb, int Npad, double *Db, const double *S, const double *V)
@@ -196,19 +199,24 @@ __device__ __forceinline__ void diag64_store(double *Lb, int Npad, double *Db, c
 
 #include "diag64_dpp.h"
 
+// Row stride of the chain's scratch array where nothing else uses it (chol_diag_kernel, chol_panel_diag_kernel): with 64 x 65 doubles each
+// for S, V and T a workgroup needs 99 840 bytes of LDS, 1 536 more than fit beside a 65 536-byte workgroup of chol_update3_kernel on one CU
+// (163 840): in the likelihood grid these one-workgroup-per-matrix kernels -- the sequential part of a panel -- then wait for a CU to drain
+// COMPLETELY while the other sub-batch's update keeps backfilling it (measured: 0.8 .. 1.9 ms for a 90 us launch, profiles/r05_c5_timeline_before.txt).
+#define CHAIN_TD 49
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *L, int Npad, int jb,
                                                         double *__restrict__ diag64, int *info,
                                                         size_t lstride, size_t dstride, double *Lout)
 {
     __shared__ double S[64 * SD];          // the block; ends up holding L (lower)
     __shared__ double V[64 * SD];          // its inverse
-    __shared__ double T[64 * SD];          // scratch (L21 * V11 products)
+    __shared__ double T[64 * CHAIN_TD];    // scratch (L21 * V11 products): 64 x 48 are used -- 91.6 KB in all, see CHAIN_TD
     L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride; info += blockIdx.z;      // batch member
     if (!Lout) Lout = L; else Lout += blockIdx.z * lstride;
     const size_t off = (size_t)jb * 64 * Npad + jb * 64;
-    diag64_load(L + off, Npad, S, V, T);
+    diag64_load<CHAIN_TD>(L + off, Npad, S, V, T);
     __syncthreads();
-    diag64_factor_invert(S, V, T, jb * 64, info);
+    diag64_factor_invert<CHAIN_TD>(S, V, T, jb * 64, info);
     diag64_store(Lout + off, Npad, diag64 + (size_t)jb * 4096, S, V);
 }
 
@@ -784,15 +792,15 @@ void chol_panel_diag_kernel(double *L, int Npad, int p0, int P, double *__restri
 {
     __shared__ double S[64 * SD];
     __shared__ double V[64 * SD];
-    __shared__ double T[64 * SD];
+    __shared__ double T[64 * CHAIN_TD];             // the chain's scratch only (the products below stage in S and V): 91.6 KB in all
     TILE_IDS;
     L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride; info += blockIdx.z;
     for (int j = 0; j < P; j++) {
         const int jb = p0 + j;
         double *Djj = L + (size_t)jb * 64 * Npad + (size_t)jb * 64;
-        diag64_load(Djj, Npad, S, V, T);
+        diag64_load<CHAIN_TD>(Djj, Npad, S, V, T);
         __syncthreads();
-        diag64_factor_invert(S, V, T, jb * 64, info);
+        diag64_factor_invert<CHAIN_TD>(S, V, T, jb * 64, info);
         diag64_store(Djj, Npad, diag64 + (size_t)jb * 4096, S, V);
         __syncthreads();
         for (int r = j + 1; r < P; r++) {               // X_rj = A_rj inv(L_jj)^T
@@ -826,9 +834,9 @@ void chol_panel_diag_kernel(double *L, int Npad, int p0, int P, double *__restri
 #pragma unroll
                         for (int q = 0; q < 4; q++) acc[m][n][q] = C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)];
                 tile64_stash<true, SD>(S, va);
-                tile64_stash<false, SD>(T, vb);
+                tile64_stash<false, SD>(V, vb);         // (the block's inverse has been used for the last time: the next chain starts from zeros)
                 __syncthreads();
-                tile64_mma_nt<SD>(S, T, acc);
+                tile64_mma_nt<SD>(S, V, acc);
 #pragma unroll
                 for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -899,38 +907,56 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // touched); nfactor: block columns to factor (a caller that never reads the last block column -- the likelihood's y row
 // alone in it -- passes nb - 1); rm_from: the factor's blocks BELOW a panel's diagonal block are stored row-major for block rows
 // >= rm_from only (0: all of them, i.e. the whole factor; the likelihood reads the y row and the diagonal and passes N / 64).
-int launch_cholesky_batched_left(double *L, int Npad, double *diag64, int *info_dev, int batch, size_t lstride, int panel,
-                                 hipStream_t s, double *Pk, size_t pstride, int nlive, int nfactor, int rm_from)
+// Several sub-batches (CholGroup: its matrices, its stream) advance panel by panel, their launches enqueued ALTERNATELY: with one
+// sub-batch's whole chain (~70 launches) enqueued before the next one's first, the second stream starts that much host time late.
+static std::atomic<int> g_tail_blocks{20}, g_tail_kc{512};      // IBO_NLML_TAIL / IBO_NLML_TAIL_KC (env, read once by abi.hip: set_left_tail)
+void set_left_tail(int blocks, int kc) { if (blocks >= 0) g_tail_blocks = blocks; if (kc >= 64) g_tail_kc = kc / 64 * 64; }
+int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad, size_t lstride, int panel, size_t pstride, int nlive,
+                                 int nfactor, int rm_from)
 {
     const int nb = Npad / 64;
     const int P = panel;
     if (nfactor <= 0 || nfactor > nb) nfactor = nb;
-    HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int) * batch, s));
+    for (int g = 0; g < ngroups; g++) HIPCHK(hipMemsetAsync(groups[g].info, 0, sizeof(int) * groups[g].batch, groups[g].stream));
     // THE TAIL.  Left-looking, the last panels have few tiles (17 .. 5 per matrix over the last 1024 columns) and a long K: the
     // chip runs half empty (46 .. 81 % of the update kernel's rate on panels 12 .. 15 of 16).  From block column `tail` on the
     // order changes: ONE update brings all remaining columns up to date with everything before `tail` (many tiles, long K), and
     // inside the tail the order is right-looking (after each panel a K = 256 update of the remaining tail columns: short K, but
     // the tail is small).  Every element still receives its terms in ascending k: identical bits.
+    // That one update goes out in K-CHUNKS (round 5): its region sits on the diagonal -- both operands are the same ~780 packed rows of a
+    // matrix, 3.4 MB per 128-row strip at K = 3328, 24 MB per matrix -- and a tile streamed its two strips through the fabric for 16 flop/byte:
+    // 4.1 .. 4.7 ms for the two sub-batches at N = 4096 (profiles/r05_c5_timeline_before.txt), 3 TB/s, half the MFMA rate of the panels before it.
+    // In chunks of 512 columns a matrix's strips are 3.2 MB and stay in the XCD's L2 from tile to tile; the accumulators go through C between
+    // the chunks (ascending k, a store and a reload: the same bits).
     int tail = nfactor;
-    const int kTail = 20;                                // (tails of 8 .. 32 block columns at N = 4096: 27.8 / 27.65 / 27.9 / 27.5 / 27.7 / 28.1 ms per 64-theta grid)
-    if (nfactor > kTail + P) tail = (nfactor - kTail) / P * P;
+    const int kTail = g_tail_blocks;
+    if (kTail > 0 && nfactor > kTail + P) tail = (nfactor - kTail) / P * P;
     for (int p0 = 0; p0 < nfactor; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
-        if (p0 > 0 && p0 <= tail) {
-            const int width = p0 == tail ? 64 * (nfactor - p0) : 64 * (pend - p0);
-            int rc = launch_chol_update3_range(L, Npad, 64 * p0, width, 0, 64 * p0, nlive, batch, lstride, Pk, pstride, s);
-            if (rc) return rc;
-        }
-        // the rows below the panel reach the packed store straight from chol_panel_rows_kernel's LDS where that kernel runs
-        // (and then only the block rows >= rm_from are also stored row-major), through chol_pack3_kernel otherwise
-        const bool packed = chol_inpanel(L, Npad, p0, pend, diag64, info_dev, batch, lstride, s, pend < nfactor ? Pk : nullptr, pstride, rm_from);
-        if (pend < nfactor && !packed) {
-            int rc = launch_chol_pack3(L, Npad, 64 * pend, 64 * p0, 64 * (pend - p0), batch, lstride, Pk, pstride, s);
-            if (rc) return rc;
-        }
-        if (p0 >= tail && pend < nfactor) {              // inside the tail: this panel's update of the columns still to come
-            int rc = launch_chol_update3_range(L, Npad, 64 * pend, 64 * (nfactor - pend), 64 * p0, 64 * pend, nlive, batch, lstride, Pk, pstride, s);
-            if (rc) return rc;
+        for (int g = 0; g < ngroups; g++) {
+            const CholGroup &G = groups[g];
+            if (G.batch <= 0) continue;
+            if (p0 > 0 && p0 <= tail) {
+                const bool wide = p0 == tail && nfactor - p0 > P;
+                const int width = p0 == tail ? 64 * (nfactor - p0) : 64 * (pend - p0);
+                const int kc = wide ? g_tail_kc.load() : 64 * p0;
+                for (int k0 = 0; k0 < 64 * p0; k0 += kc) {
+                    const int k1 = k0 + kc < 64 * p0 ? k0 + kc : 64 * p0;
+                    int rc = launch_chol_update3_range(G.L, Npad, 64 * p0, width, k0, k1, nlive, G.batch, lstride, G.Pk, pstride, G.stream);
+                    if (rc) return rc;
+                }
+            }
+            // the rows below the panel reach the packed store straight from chol_panel_rows8r_kernel's LDS where that kernel runs
+            // (and then only the block rows >= rm_from are also stored row-major), through chol_pack3_kernel otherwise
+            const bool packed = chol_inpanel(G.L, Npad, p0, pend, G.diag64, G.info, G.batch, lstride, G.stream, pend < nfactor ? G.Pk : nullptr, pstride, rm_from);
+            if (pend < nfactor && !packed) {
+                int rc = launch_chol_pack3(G.L, Npad, 64 * pend, 64 * p0, 64 * (pend - p0), G.batch, lstride, G.Pk, pstride, G.stream);
+                if (rc) return rc;
+            }
+            if (p0 >= tail && pend < nfactor) {              // inside the tail: this panel's update of the columns still to come
+                int rc = launch_chol_update3_range(G.L, Npad, 64 * pend, 64 * (nfactor - pend), 64 * p0, 64 * pend, nlive, G.batch, lstride, G.Pk, pstride, G.stream);
+                if (rc) return rc;
+            }
         }
     }
     return (int)hipGetLastError();
