@@ -82,7 +82,6 @@ static int use_device(int device)
         const char *s = getenv("IBO_SWEEP_IMPL");
         if (s && !strcmp(s, "gemv")) g_force_path = 1;
         if (s && !strcmp(s, "mfma")) g_force_path = 2;
-        set_left_tail(getenv("IBO_NLML_TAIL") ? atoi(getenv("IBO_NLML_TAIL")) : -1, getenv("IBO_NLML_TAIL_KC") ? atoi(getenv("IBO_NLML_TAIL_KC")) : -1);
         if (const char *a = getenv("IBO_NLML_GROUPS")) { const int v = atoi(a); if (v >= 1 && v <= 4) g_nlml_groups = v; }
         const char *pl = getenv("IBO_POOL_LIMIT_MB");
         if (pl && atoll(pl) >= 0) g_pool_limit = (size_t)atoll(pl) << 20;

@@ -258,7 +258,6 @@ int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t
                         hipStream_t s, const double *Lpanel = nullptr);
 // left-looking outer order from one packed copy of the finished block columns (update3.hip); bit-identical to the above
 struct CholGroup { double *L, *diag64, *Pk; int *info; int batch; hipStream_t stream; };      // a sub-batch of matrices (lstride / pstride apart) on its stream
-void set_left_tail(int blocks, int kc);     // experiment knobs of the left-looking order's tail (env IBO_NLML_TAIL, IBO_NLML_TAIL_KC)
 int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad, size_t lstride, int panel, size_t pstride, int nlive,
                                  int nfactor = 0, int rm_from = 0);
 int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batch, size_t lstride, double *Pk, size_t pstride,

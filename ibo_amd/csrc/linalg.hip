@@ -909,8 +909,6 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 // >= rm_from only (0: all of them, i.e. the whole factor; the likelihood reads the y row and the diagonal and passes N / 64).
 // Several sub-batches (CholGroup: its matrices, its stream) advance panel by panel, their launches enqueued ALTERNATELY: with one
 // sub-batch's whole chain (~70 launches) enqueued before the next one's first, the second stream starts that much host time late.
-static std::atomic<int> g_tail_blocks{20}, g_tail_kc{512};      // IBO_NLML_TAIL / IBO_NLML_TAIL_KC (env, read once by abi.hip: set_left_tail)
-void set_left_tail(int blocks, int kc) { if (blocks >= 0) g_tail_blocks = blocks; if (kc >= 64) g_tail_kc = kc / 64 * 64; }
 int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad, size_t lstride, int panel, size_t pstride, int nlive,
                                  int nfactor, int rm_from)
 {
@@ -923,28 +921,21 @@ int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad,
     // order changes: ONE update brings all remaining columns up to date with everything before `tail` (many tiles, long K), and
     // inside the tail the order is right-looking (after each panel a K = 256 update of the remaining tail columns: short K, but
     // the tail is small).  Every element still receives its terms in ascending k: identical bits.
-    // That one update goes out in K-CHUNKS (round 5): its region sits on the diagonal -- both operands are the same ~780 packed rows of a
-    // matrix, 3.4 MB per 128-row strip at K = 3328, 24 MB per matrix -- and a tile streamed its two strips through the fabric for 16 flop/byte:
-    // 4.1 .. 4.7 ms for the two sub-batches at N = 4096 (profiles/r05_c5_timeline_before.txt), 3 TB/s, half the MFMA rate of the panels before it.
-    // In chunks of 512 columns a matrix's strips are 3.2 MB and stay in the XCD's L2 from tile to tile; the accumulators go through C between
-    // the chunks (ascending k, a store and a reload: the same bits).
+    // (Round 5, measured and removed: that one update in K-chunks of 256 / 512 / 1024 columns, so that a matrix's ~780 packed rows stay in an
+    // XCD's L2 from tile to tile -- 28.9 / 27.5 / 27.3 ms per 64-theta grid against 27.2 in one launch: its 42 TFLOP/s are not a traffic problem.
+    // Tails of 20 / 28 / 36 block columns: 27.2 / 27.9 / 28.5 ms.)
     int tail = nfactor;
-    const int kTail = g_tail_blocks;
-    if (kTail > 0 && nfactor > kTail + P) tail = (nfactor - kTail) / P * P;
+    const int kTail = 20;
+    if (nfactor > kTail + P) tail = (nfactor - kTail) / P * P;
     for (int p0 = 0; p0 < nfactor; p0 += P) {
         const int pend = p0 + P < nb ? p0 + P : nb;
         for (int g = 0; g < ngroups; g++) {
             const CholGroup &G = groups[g];
             if (G.batch <= 0) continue;
             if (p0 > 0 && p0 <= tail) {
-                const bool wide = p0 == tail && nfactor - p0 > P;
                 const int width = p0 == tail ? 64 * (nfactor - p0) : 64 * (pend - p0);
-                const int kc = wide ? g_tail_kc.load() : 64 * p0;
-                for (int k0 = 0; k0 < 64 * p0; k0 += kc) {
-                    const int k1 = k0 + kc < 64 * p0 ? k0 + kc : 64 * p0;
-                    int rc = launch_chol_update3_range(G.L, Npad, 64 * p0, width, k0, k1, nlive, G.batch, lstride, G.Pk, pstride, G.stream);
-                    if (rc) return rc;
-                }
+                int rc = launch_chol_update3_range(G.L, Npad, 64 * p0, width, 0, 64 * p0, nlive, G.batch, lstride, G.Pk, pstride, G.stream);
+                if (rc) return rc;
             }
             // the rows below the panel reach the packed store straight from chol_panel_rows8r_kernel's LDS where that kernel runs
             // (and then only the block rows >= rm_from are also stored row-major), through chol_pack3_kernel otherwise
