@@ -965,7 +965,7 @@ int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad,
 //     chol_update_step_kernel's body.  They touch nothing the row workgroups read or write in this launch.
 // So the trailing update of a step runs BESIDE the next step's chain instead of before it: a step costs max(chain + three
 // products, tiles) instead of their sum (25 -> 17 us at N = 2048).  With 133 KB of LDS every workgroup has a CU to itself, so
-// no tile's MFMAs share a SIMD with a chain (which would slow the chain several times over, DESIGN s9).  Each tile still
+// no tile's MFMAs share a SIMD with a chain (which would slow the chain several times over: docs/notebook.md).  Each tile still
 // receives the updates of steps 0, 1, .. in that order with the same operands: identical bits (tested).
 // (The kernel is chol_pipe8_kernel below.)
 
@@ -1023,7 +1023,7 @@ struct Pipe8Side {
 
 // TMODE (which tiles ride in the launch; the row workgroups are the same in both).  0: step jp on every tile right of column jb -- one pass
 // over the trailing matrix per block column.  Beyond ~2000 rows that pass is what a column costs (44 us at N = 4096 against the chain's 18:
-// 128 KiB moved per 64^3 product, DESIGN 4.3), so there a tile gets TWO steps per pass, the accumulators staying in registers between them
+// 128 KiB moved per 64^3 product, DESIGN 4.7), so there a tile gets TWO steps per pass, the accumulators staying in registers between them
 // (the four operand blocks fill the four LDS arrays) -- 1: the launch carries `nsingle` tiles of column jb + 1 with step jp alone (odd jb:
 // the column the next launch factors) and then the tiles of columns [c_lo, c_hi) with steps q - 1 and q; the host deals the columns of a
 // pair of steps over the two launches that may carry it (launch_cholesky_fused).  A tile receives the same k4-steps in the same order on the

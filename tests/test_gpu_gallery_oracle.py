@@ -1,7 +1,7 @@
 """
 GPU parity tests, second file: the ORACLE on the paths that round 3 only compared with themselves.
 
-  * the kept-state gallery sweeps (two-part first sweep, lazy refresh rounds: csrc/sweep2.hip, DESIGN 4.1c) against the
+  * the kept-state gallery sweeps (two-part first sweep, lazy refresh rounds: csrc/sweep2.hip, DESIGN 4.2) against the
     oracle's own gallery and its own per-round sweeps on FIXED candidate arrays, with pruning verified active;
   * the full-size pieces of BASELINE configs 3, 4 and 5 that only bench.py used to run: gallery-8 on the C3 shard and on
     the 512-pair preference model over 2^20 candidates, the 64-theta batch at N = 4096;
@@ -283,7 +283,7 @@ def test_legacy_acqmaxGP_reproduces_libego_where_conditioning_is_worst(ibo, orac
     sequential, separately rounded sums -- and the test asks for what that buys: libego's numbers BIT FOR BIT, per point
     (every dimension fixed, maxiter 0: one objective evaluation, cpp/direct.cpp:116-117,355) and over DIRECT runs, against the
     reference's own compiled library (oracle/_ref/libego.so).  SE-ARD, SE-iso, Matern-3/2, with and without a mean prior;
-    Matern-5/2 is left out: the compiled reference reads its magnitude out of bounds there (DESIGN 7).  The fast route
+    Matern-5/2 is left out: the compiled reference reads its magnitude out of bounds there (DESIGN 8).  The fast route
     (legacy_exact = 0) is held to the 1e-6 bar where the data are benign (noise 0.1)."""
     from ibo_amd import _lib
     if not oracle.RefLib.available():
