@@ -250,6 +250,43 @@ def test_c3_full_size_gallery_of_eight(ibo, oracle):
     assert min(np.linalg.norm(G[i] - G[j]) for i in range(8) for j in range(i)) > .5
 
 
+def test_c3_whole_four_million_candidate_array_on_one_gpu(ibo, oracle):
+    """BASELINE config 3's candidate array as stated -- 2^22 candidates, N = 2048, D = 8, Matern-5/2 -- swept WHOLE on one GPU (what bench.py
+    --config c3 times at one GPU; the other tests take one 2^19 shard): the full EI sweep's winner against the oracle's EI at that candidate and
+    at 96 others (the winner's tile neighbours, the last candidates of the array, random ones), then a gallery of four through the kept state
+    with winners beyond index 2^19, each round against the oracle as in the shard's test.  Row indices above 2^19 (and above 2^21) come back
+    from the arg-max reduction, the tile tables and the compact lists of the levels."""
+    from ibo_amd import DeviceArray
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import MaternKernel5
+    from ibo_amd.acquisition import sweep
+    from ibo_amd.acquisition.gallery import fastUCBGallery
+    N, D, M = 2048, 8, 1 << 22
+    X, Y = synth(3, N, D)
+    GP = GaussianProcess(MaternKernel5([.5, 1.0]), X, Y, noise=.1)
+    rs = np.random.RandomState(103)
+    cand = np.concatenate([rs.rand(1 << 18, D) for _ in range(16)])          # the stream bench.py draws
+    # the best region of the first shard moved to the END of the array: the winner must come back with an index near 2^22
+    r0 = sweep(GP, cand[:1 << 19], acq='ei', xi=.01, native=True)
+    k0 = r0["best_idx"]
+    cand[M - 5], cand[k0] = cand[k0].copy(), cand[M - 5].copy()
+    dc = DeviceArray.from_host(cand)
+    r = sweep(GP, dc, acq='ei', xi=.01, native=True)
+    assert r["kernel"] == "sweep2_kernel" and r["best_val"] >= r0["best_val"] and r["best_idx"] != k0
+    assert r["best_idx"] == M - 5 or r["best_val"] > r0["best_val"]          # the moved candidate, unless another shard holds a better one
+    ogp = oracle.GP(oracle.Kern("m5", [.5, 1.0]), X, Y)
+    k = r["best_idx"]
+    probe = np.unique(np.r_[k, np.arange(max(0, k - 16), min(M, k + 16)), np.arange(M - 32, M), rs.randint(0, M, 32)])
+    o = oracle.sweep_native(ogp, cand[probe], oracle.ACQ_EI, .01)
+    close(r["best_val"], o["acq"][list(probe).index(k)], atol=ACQ_ATOL)
+    assert r["best_val"] >= o["acq"].max() * (1 - 1e-9)
+    trace = []
+    gal = fastUCBGallery(GP, [[0., 1.]] * D, 4, candidates=dc, trace=trace)
+    assert trace[0]["kernel"] == "sweep2_kernel<part>" and all(0 < tr["complete"] < tr["tiles"] for tr in trace), trace
+    assert trace[0]["tiles"] == M // 32 and any(tr["sweep_idx"] >= (1 << 19) for tr in trace), [tr["sweep_idx"] for tr in trace]
+    _check_rounds_with_the_oracle(oracle, ogp, cand, gal, trace, 32, 4)
+
+
 def test_c5_all_sixty_four_thetas_in_one_batch(ibo, oracle):
     """BASELINE config 5's batch as bench.py runs it: 64 theta-points at N = 4096, D = 16 in ONE ibo_nlml_grid call (two
     sub-batches of 32 on two streams, left-looking).  Three of the values against the oracle's marginal likelihood (NumPy

@@ -15,6 +15,8 @@ python3 tools/time_incremental.py > profiles/${TAG}_time_incremental.txt 2> $O/i
 { for c in c2 c3 c4; do for l in 4 3 2; do python3 tools/argmax_only.py $c $l; done; done; } > profiles/${TAG}_argmax_only.txt 2> $O/argmax.err
 { python3 tools/legacy_probe.py 1e-4 1 2>&1 | grep -a "per-point\|maxiter 10\|legacy_exact" | cut -c1-260; python3 tools/legacy_probe.py 1e-4 0 2>&1 | grep -a "per-point\|maxiter 10\|legacy_exact" | cut -c1-260; } > profiles/${TAG}_legacy_probe.txt
 bash tools/pipe_columns.sh 4096 > profiles/${TAG}_pipe8_n4096_columns_pairs.txt 2>&1
+bash tools/c5_timeline.sh gpurun_out/c5_timeline_$TAG > $O/c5_timeline.log 2>&1; cp gpurun_out/c5_timeline_$TAG/timeline.txt profiles/${TAG}_c5_timeline_after.txt
+python3 tools/gallery_first_call.py > $O/gallery_first_call.txt 2>&1
 { [ -x tools/launch_floor ] && tools/launch_floor; } > profiles/${TAG}_direct_batch_floor.txt 2> $O/floor.err
 timeout 600 python3 tools/fuzz_nlml.py 60 7 > $O/fuzz_nlml.txt 2>&1; tail -4 $O/fuzz_nlml.txt > profiles/${TAG}_fuzz_nlml_summary.txt
 timeout 900 python3 tools/fuzz_gallery.py 400 7 > $O/fuzz_gallery.txt 2>&1; { grep -c " ok:" $O/fuzz_gallery.txt; grep "FAIL" $O/fuzz_gallery.txt | head; tail -1 $O/fuzz_gallery.txt; } > profiles/${TAG}_fuzz_gallery_summary.txt

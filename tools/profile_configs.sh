@@ -27,6 +27,8 @@ run c5 python3 tools/c5_only.py
 run fit4096 python3 tools/time_fit.py 4096
 run fit2048 python3 tools/time_fit.py 2048
 run fit1024 python3 tools/time_fit.py 1024
+run learn4096 python3 tools/learn_only.py 4096 16 8
+run learn1024 python3 tools/learn_only.py 1024 16 8
 # kernel stats only
 timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gallery/trace -- python3 tools/run_configs.py c3 > $OUT/gallery.trace.log 2>&1
 timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4/trace -- python3 tools/run_configs.py c4 > $OUT/c4.trace.log 2>&1

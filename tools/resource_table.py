@@ -5,7 +5,7 @@ import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 rows = []
-for f in ("sweep2", "sweep", "small2", "update3", "linalg", "abi"):
+for f in ("sweep2", "sweep", "small2", "update3", "linalg", "assemble", "legacy", "comm", "abi"):
     out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
                           "-c", os.path.join(root, "ibo_amd", "csrc", f + ".hip"), "-o", "/dev/null"], capture_output=True, text=True).stderr
     cur = None

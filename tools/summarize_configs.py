@@ -34,8 +34,10 @@ SPEC = {
     "fit4096": (("chol_pipe", "chol_step"), 8, "fit (tools/time_fit.py: the constructor's fit + 7)"),
     "fit2048": (("chol_pipe", "chol_step"), 8, "fit"),           # chol_pipe8_kernel since round 4 (chol_pipe_kernel / chol_step*_kernel before)
     "fit1024": (("chol_pipe", "chol_step"), 8, "fit"),
+    "learn4096": (("chol_pipe", "chol_step", "wtw_kernel", "nlml_grad"), 8, "NLML + gradient evaluation (tools/learn_only.py 4096 16 8): factorisation, W^T W, contraction"),
+    "learn1024": (("chol_pipe", "chol_step", "wtw_kernel", "nlml_grad"), 8, "NLML + gradient evaluation (tools/learn_only.py 1024 16 8)"),
 }
-for name in ("c3", "c5", "fit4096", "fit2048", "fit1024", "gallery", "c4"):
+for name in ("c3", "c5", "fit4096", "fit2048", "fit1024", "learn4096", "learn1024", "gallery", "c4"):
     st = newest(os.path.join(out, name, "trace", "*", "*_kernel_stats.csv"))
     if st:
         shutil.copy(st[0], os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, name)))
