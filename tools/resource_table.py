@@ -5,9 +5,11 @@ import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 rows = []
-for f in ("sweep2", "sweep", "small2", "update3", "linalg", "assemble", "legacy", "comm", "abi"):
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
-                          "-c", os.path.join(root, "ibo_amd", "csrc", f + ".hip"), "-o", "/dev/null"], capture_output=True, text=True).stderr
+units = [("sweep2_fam", ["-DS2_FAM=FAM_%s" % fam, "-DS2_PIECE=%d" % pc]) for fam in ("SE", "M3", "M5") for pc in (0, 1)]
+units += [(f, []) for f in ("sweep2", "sweep", "small2", "update3", "linalg", "assemble", "legacy", "comm", "abi")]
+for f, defs in units:
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage"] + defs +
+                         ["-c", os.path.join(root, "ibo_amd", "csrc", f + ".hip"), "-o", "/dev/null"], capture_output=True, text=True).stderr
     cur = None
     for line in out.splitlines():
         m = re.search(r"remark: .*?(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\S+)", line)
@@ -15,7 +17,7 @@ for f in ("sweep2", "sweep", "small2", "update3", "linalg", "assemble", "legacy"
             continue
         k, v = m.group(1), m.group(2)
         if k == "Function Name":
-            cur = {"file": f + ".hip", "kernel": subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()}
+            cur = {"file": ("sweep2_kernels.h" if f == "sweep2_fam" else f + ".hip"), "kernel": subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()}
             rows.append(cur)
         elif cur is not None:
             cur[k] = v
