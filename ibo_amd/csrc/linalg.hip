@@ -784,65 +784,87 @@ static const int kPackedUpdateMinTiles = 1024;
 
 // The panel's (64 P)^2 DIAGONAL block in one launch, one workgroup per matrix: for each of its P block columns the diagonal
 // factorisation (chol_diag_kernel), the row blocks below it inside the block (chol_trsm_kernel) and their K = 64 updates
-// (chol_update_kernel) -- the same helpers on the same operands in the same order, identical bits -- without the 3 P - 2
+// (chol_update_kernel) -- the same k4-steps on the same operands in the same order per element, identical bits -- without the 3 P - 2
 // launches of one workgroup per matrix each (11 per panel, 1.5 ms of a 64-theta grid at N = 4096).  The blocks travel through
-// global memory (the workgroup reads back what it stored: one CU, one L1) and LDS holds the chain's three 64 x 64 stages.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// global memory (the workgroup reads back what it stored: one CU, one L1) and LDS holds the chain's three stages (91.6 KB).
+// Eight waves, the geometry of chol_panel_rows8r_kernel, the next product's operands fetched under the current one (round 5: 27.6 -> 27.3 ms
+// per 64-theta grid against the four-wave form; the launch itself stays at ~90 us -- its products wait on their own stores at every barrier).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void chol_panel_diag_kernel(double *L, int Npad, int p0, int P, double *__restrict__ diag64, int *info, size_t lstride, size_t dstride)
 {
     __shared__ double S[64 * SD];
     __shared__ double V[64 * SD];
-    __shared__ double T[64 * CHAIN_TD];             // the chain's scratch only (the products below stage in S and V): 91.6 KB in all
-    TILE_IDS;
+    __shared__ double T[64 * CHAIN_TD];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr8 = wv >> 1, wc8 = wv & 1;
     L += blockIdx.z * lstride; diag64 += blockIdx.z * dstride; info += blockIdx.z;
+    auto blk = [&](int r, int c) { return L + (size_t)(p0 + r) * 64 * Npad + (size_t)(p0 + c) * 64; };
+    d2_t va[4], vb[4];
     for (int j = 0; j < P; j++) {
         const int jb = p0 + j;
-        double *Djj = L + (size_t)jb * 64 * Npad + (size_t)jb * 64;
-        diag64_load<CHAIN_TD>(Djj, Npad, S, V, T);
+        double *Djj = blk(j, j);
+        {   // the diagonal block into the chain's layout (zeros in V, the identity rows in T)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = Djj[(size_t)(8 * u + wv) * Npad + lane];
+            if (j + 1 < P) pr8_fetch(blk(j + 1, j), Npad, va);       // the first row block: ready since the last column's updates
+#pragma unroll
+            for (int u = 0; u < 8; u++) { S[(8 * u + wv) * SD + lane] = v[u]; V[(8 * u + wv) * SD + lane] = 0.0; }
+            if (t < 256) T[(t >> 4) * CHAIN_TD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+        }
         __syncthreads();
         diag64_factor_invert<CHAIN_TD>(S, V, T, jb * 64, info);
-        diag64_store(Djj, Npad, diag64 + (size_t)jb * 4096, S, V);
-        __syncthreads();
-        for (int r = j + 1; r < P; r++) {               // X_rj = A_rj inv(L_jj)^T
-            double *Arj = L + (size_t)(p0 + r) * 64 * Npad + (size_t)jb * 64;
-            d2_t va[8];
-            tile64_fetch(Arj, Npad, va);
-            tile64_stash<false, SD>(S, va);
-            __syncthreads();
-            d4_t acc[2][2] = {};
-            tile64_mma_nt_tri<SD>(S, V, acc);
+        {
+            double *Db = diag64 + (size_t)jb * 4096;
 #pragma unroll
-            for (int m = 0; m < 2; m++)
+            for (int u = 0; u < 8; u++) {
+                const int r = 8 * u + wv, c = lane;
+                Djj[(size_t)r * Npad + c] = (c <= r) ? S[r * SD + c] : 0.0;
+                Db[r * 64 + c] = V[r * SD + c];
+            }
+        }
+        __syncthreads();
+        // X_rj = A_rj inv(L_jj)^T, r = j + 1 .. P - 1 (operand in S, the inverse in V)
+        for (int r = j + 1; r < P; r++) {
+            pr8_stash(S, va);
+            __syncthreads();
+            if (r + 1 < P) pr8_fetch(blk(r + 1, j), Npad, va);
+            d4_t x[2] = {};
+            if (wc8) pr8_mma_nt_tri_body<1, 2>(S, V, x, wr8, lane);
+            else pr8_mma_nt_tri_body<0, 3>(S, V, x, wr8, lane);
+            double *Arj = blk(r, j);
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) Arj[(size_t)PR8_ROW(q) * Npad + PR8_COL_TRI(n)] = x[n][q];
+            __syncthreads();
+        }
+        // A_rc -= X_rj X_cj^T, r >= c > j (operands in S and V: the inverse has been used for the last time)
+        bool have = false;
+        for (int c = j + 1; c < P; c++)
+            for (int r = c; r < P; r++) {
+                if (!have) { pr8_fetch(blk(r, j), Npad, va); pr8_fetch(blk(c, j), Npad, vb); }
+                double *C = blk(r, c);
+                d4_t acc[2];
 #pragma unroll
                 for (int n = 0; n < 2; n++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) Arj[(size_t)TILE_ROW(m, q) * Npad + TILE_COL_TRI(n)] = acc[m][n][q];
-            __syncthreads();
-        }
-        for (int c = j + 1; c < P; c++)                  // A_rc -= X_rj X_cj^T, r >= c
-            for (int r = c; r < P; r++) {
-                const double *Xr = L + (size_t)(p0 + r) * 64 * Npad + (size_t)jb * 64, *Xc = L + (size_t)(p0 + c) * 64 * Npad + (size_t)jb * 64;
-                double *C = L + (size_t)(p0 + r) * 64 * Npad + (size_t)(p0 + c) * 64;
-                d2_t va[8], vb[8];
-                tile64_fetch(Xr, Npad, va);
-                tile64_fetch(Xc, Npad, vb);
-                d4_t acc[2][2];
+                    for (int q = 0; q < 4; q++) acc[n][q] = C[(size_t)PR8_ROW(q) * Npad + PR8_COL(n)];
 #pragma unroll
-                for (int m = 0; m < 2; m++)
-#pragma unroll
-                    for (int n = 0; n < 2; n++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) acc[m][n][q] = C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)];
-                tile64_stash<true, SD>(S, va);
-                tile64_stash<false, SD>(V, vb);         // (the block's inverse has been used for the last time: the next chain starts from zeros)
+                for (int u = 0; u < 4; u++) va[u] = -va[u];
+                pr8_stash(S, va);
+                pr8_stash(V, vb);
                 __syncthreads();
-                tile64_mma_nt<SD>(S, V, acc);
+                {   // the next product's operands (the row blocks X were all stored before the barrier above)
+                    int r2 = r + 1, c2 = c;
+                    if (r2 >= P) { c2 = c + 1; r2 = c2; }
+                    have = c2 < P;
+                    if (have) { pr8_fetch(blk(r2, j), Npad, va); pr8_fetch(blk(c2, j), Npad, vb); }
+                }
+                pr8_mma_nt(S, V, acc, wr8, wc8, lane);
 #pragma unroll
-                for (int m = 0; m < 2; m++)
+                for (int n = 0; n < 2; n++)
 #pragma unroll
-                    for (int n = 0; n < 2; n++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) C[(size_t)TILE_ROW(m, q) * Npad + TILE_COL(n)] = acc[m][n][q];
+                    for (int q = 0; q < 4; q++) C[(size_t)PR8_ROW(q) * Npad + PR8_COL(n)] = acc[n][q];
                 __syncthreads();
             }
     }
@@ -860,7 +882,7 @@ static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
     // in the same order as the per-column sequence, which runs where the rows are few (its short launches finish sooner).
     const bool rows_fused = pend - p0 <= 4 && (size_t)(nb - pend) * batch >= 256;
     if (rows_fused)
-        hipLaunchKernelGGL(chol_panel_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, p0, pend - p0, diag64, info_dev, lstride, dstride);
+        hipLaunchKernelGGL(chol_panel_diag_kernel, dim3(1, 1, batch), dim3(512), 0, s, L, Npad, p0, pend - p0, diag64, info_dev, lstride, dstride);
     else
         for (int jb = p0; jb < pend; jb++) {
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(256), 0, s, L, Npad, jb, diag64, info_dev,
