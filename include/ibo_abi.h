@@ -92,7 +92,8 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  *   2 MFMA tile / 3 panel-split;  "dot_form" -1 auto / 0 / 1 (k* by differences or by the exponent GEMM);  "gallery_prune" 0/1/2 and
  *   "part_levels" 2..4 (see ibo_acq_sweep_incremental);  "host_pipeline" 1/0 (large host batches in overlapped chunks or in one shot);
  *   "chol_left" 1/0 (ibo_nlml_grid's left-looking order or the right-looking one: identical bits).
- * Env: IBO_SWEEP_IMPL=gemv|mfma, IBO_DOT_FORM, IBO_POOL_LIMIT_MB, IBO_HOST_THREADS (the legacy symbol's host crew), IBO_DEVICE (legacy symbols).
+ * Env: IBO_SWEEP_IMPL=gemv|mfma, IBO_DOT_FORM, IBO_POOL_LIMIT_MB, IBO_HOST_THREADS (the legacy symbol's host crew), IBO_DEVICE (legacy symbols),
+ *   IBO_NLML_GROUPS=1..4 (sub-batches of an ibo_nlml_grid batch, each on its own stream; 2; the values do not depend on it).
  * Threading (the reference's library keeps its whole model in process-wide statics, cpp/optimizeGP.cpp:36-55,240-259, and is not
  * re-entrant; this one is): handles are independent of each other -- each has its own stream, events, staging and buffers --
  * so several threads may drive several handles on one device at the same time (one handle belongs to one thread at a time);
