@@ -1576,9 +1576,11 @@ struct NlmlWorkspace {
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};     // sub-batches of a grid run side by side (created on first use, kept)
 };
 static NlmlWorkspace g_nlml_ws[16];
+static const int kSyrk3From = 2560;          // rows from which ibo_nlml_grad forms K^-1 = W^T W on the packed-operand kernel (launch_syrk3)
 struct GradWorkspace {
-    DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout;
-    DevBuf<int> dinfo;
+    DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout, dpiece;
+    DevBuf<int> dinfo, dtasks, dsums;
+    int plan_Np = 0, ntasks = 0, nsums = 0;         // launch_syrk3's lists on the device, for this Npad
 };
 static GradWorkspace g_grad_ws[16];
 
@@ -1593,6 +1595,7 @@ extern "C" int ibo_trim(int device)
     GradWorkspace &gw = g_grad_ws[device & 15];
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
     gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
+    gw.dpiece.release(); gw.dtasks.release(); gw.dsums.release(); gw.plan_Np = 0;
     pool_trim(device);
     return IBO_OK;
 }
@@ -1738,10 +1741,23 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     KERNEL_TRY(launch_alpha(dW.p, N, Np, dY.p, tmp.p, dal.p, da1.p, s));
     // K^-1 = W^T W: with the ride-along, W^T is what the factorisation left in dKi -- no transpose; the result goes to dT, free by now
     const double *Kinv = fused ? dT.p : dKi.p;
-    if (fused) KERNEL_TRY(launch_wtw(dW.p, dKi.p, dT.p, Np, s, 1, 1));
+    KERNEL_TRY(launch_nlml_scalars(dL.p, Np, N, dY.p, dal.p, dout.p + ngrad, s));        // (y . alpha, sum log L_ii): L has been read for the last time
+    if (fused && Np >= kSyrk3From) {
+        // from 2560 rows the product runs on the packed-operand kernel (128 x 128 tiles, A fragments straight from L2), its long K ranges in pieces;
+        // the packed copy of W^T goes where L was
+        if (ws.plan_Np != Np) {
+            std::vector<int> tasks, sums;
+            int nslots = 0;
+            syrk3_plan(Np, 1024, tasks, sums, &nslots);
+            IBO_TRY(ws.dtasks.ensure(tasks.size())); IBO_TRY(ws.dsums.ensure(sums.size() + 4)); IBO_TRY(ws.dpiece.ensure((size_t)(nslots + 1) * 16384));
+            HIP_TRY(hipMemcpy(ws.dtasks.p, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice));
+            if (!sums.empty()) HIP_TRY(hipMemcpy(ws.dsums.p, sums.data(), sizeof(int) * sums.size(), hipMemcpyHostToDevice));
+            ws.plan_Np = Np; ws.ntasks = (int)tasks.size() / 4; ws.nsums = (int)sums.size() / 4;
+        }
+        KERNEL_TRY(launch_syrk3(dKi.p, dL.p, dT.p, Np, ws.dtasks.p, ws.ntasks, ws.dsums.p, ws.nsums, ws.dpiece.p, s));
+    } else if (fused) KERNEL_TRY(launch_wtw(dW.p, dKi.p, dT.p, Np, s, 1, 1));
     else KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s, 1));
     KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, Kinv, Np, dal.p, dpart.p, dout.p, s));
-    KERNEL_TRY(launch_nlml_scalars(dL.p, Np, N, dY.p, dal.p, dout.p + ngrad, s));        // (y . alpha, sum log L_ii) behind the gradient
     std::vector<double> res(ngrad + 2);
     int h = 0;
     HIP_TRY(hipMemcpy(res.data(), dout.p, sizeof(double) * (ngrad + 2), hipMemcpyDeviceToHost));

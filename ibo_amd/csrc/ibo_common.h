@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <vector>
 
 #define IBO_DMAX 64            // largest input dimensionality handled on device (rows of X are padded to DP = 4, 8, 16, 32 or 64)
 #define IBO_DDOT 32            // ... and the largest for which the dot-form kernels (sweep2.hip, small2.hip: exponent GEMM of up to
@@ -265,6 +266,10 @@ int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batc
 int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int batch, size_t lstride, const double *Pk,
                         size_t pstride, hipStream_t s);
 // the same kernel on any region that starts on the diagonal (rows >= c0, columns [c0, c0 + width)) and any range [kbeg, kend) of packed columns
+// C = P P^T (lower 128-tiles) of an upper triangular P on the packed-operand kernel, long K ranges in pieces (update3.hip)
+void syrk3_plan(int Npad, int piece, std::vector<int> &tasks, std::vector<int> &sums, int *nslots);
+int launch_syrk3(const double *P, double *Pk, double *C, int Npad, const int *tasks_dev, int ntasks, const int *sums_dev, int nsums, double *part,
+                 hipStream_t s);
 int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
                               const double *Pk, size_t pstride, hipStream_t s);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)

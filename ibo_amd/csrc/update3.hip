@@ -27,6 +27,8 @@
 // nor multiplied nor stored: the y row the likelihood appends costs one 16-row block, not a 128-row tile.
 #include "ibo_common.h"
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 
 #define U3_NW 8
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -112,7 +114,8 @@ __device__ __forceinline__ void u3_row_block(double *L, int Npad, int c0, int nc
 // the whole trailing matrix, the last panel's K = 256 columns.
 __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, int Npad, int c0, int ncb, int nlive_rb,
                                                                   const double *Pk, size_t lstride, size_t pstride,
-                                                                  int tpm, int ntc, int batch, int chunk, int rowtile, int kb8, int K)
+                                                                  int tpm, int ntc, int batch, int chunk, int rowtile, int kb8, int K,
+                                                                  const int4 *__restrict__ tasks, double *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) double lds_b[2][U3_KS / 8 * 8 * 128];      // [stage][k8-step][column-block][lane][2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,8 +123,15 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
     // sequence entry of this workgroup (see the header): matrix m, tile t
     // (chunk = 0, fewer than 8 matrices: plain order -- neighbouring tiles on different XCDs find each other's strips in the
     // memory-side cache; whole-matrix chunks per XCD would leave most L2s without a matrix)
-    const int q = chunk ? (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if ((chunk && (int)(blockIdx.x >> 3) >= chunk) || q >= batch * tpm) return;
+    // tasks (the SYRK use, launch_syrk3: C = P P^T of an upper triangular P): entry blockIdx.x is tile tasks[].x's piece of the K range
+    // [kb8, kb8 + K / 8) k8-steps read from tasks[].y's fields; accumulators start from zero, the result is stored as it is -- into C, or
+    // into slot `pslot` of `part` (128 x 128 doubles each) when the tile's K range is dealt in pieces
+    int q = chunk ? (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int pslot = 0;
+    if (tasks) {
+        const int4 tk = tasks[blockIdx.x];          // tile, first k8-step, columns, slot (0: C itself)
+        q = tk.x; kb8 = tk.y; K = tk.z; pslot = tk.w;
+    } else if ((chunk && (int)(blockIdx.x >> 3) >= chunk) || q >= batch * tpm) return;
     const int m = q / tpm, t = q - m * tpm;
     L += (size_t)m * lstride; Pk += (size_t)m * pstride;
     if (rowtile && t >= tpm - rowtile) {                 // the matrix's last entries: the lone live row-block below the full tiles,
@@ -178,13 +188,18 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
     // accumulators <- MINUS the tile.  Element r of block (i, cb): row 16 (gA + i) + (lane>>4) + 4 r, column c0 + 16 (cb0 + cb) + (lane&15)
     d4_t acc[2][4];
     double *Cw = L + (size_t)(16 * gA + (lane >> 4)) * Npad + c0 + 16 * cb0 + (lane & 15);
+    size_t ldc = Npad;
+    if (pslot) {            // a piece's own 128 x 128 slot
+        Cw = part + (size_t)(pslot - 1) * 16384 + (size_t)(32 * wr + (lane >> 4)) * 128 + 64 * wc + (lane & 15);
+        ldc = 128;
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int cb = 0; cb < 4; cb++) {
-            const bool in = i < ni && cb0 + cb < ncb;
+            const bool in = i < ni && cb0 + cb < ncb && !tasks;
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[i][cb][r] = in ? -Cw[(size_t)(16 * i + 4 * r) * Npad + 16 * cb] : 0.0;
+            for (int r = 0; r < 4; r++) acc[i][cb][r] = in ? -Cw[(size_t)(16 * i + 4 * r) * ldc + 16 * cb] : 0.0;
         }
 
     u3_v4 A[4][2];
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
         for (int cb = 0; cb < 4; cb++) {
             if (i < ni && cb0 + cb < ncb) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) Cw[(size_t)(16 * i + 4 * r) * Npad + 16 * cb] = -acc[i][cb][r];
+                for (int r = 0; r < 4; r++) Cw[(size_t)(16 * i + 4 * r) * ldc + 16 * cb] = tasks ? acc[i][cb][r] : -acc[i][cb][r];
             }
         }
 }
@@ -287,7 +302,7 @@ int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, 
     const long long total = (long long)tpm * batch;
     const int chunk = batch >= 8 ? (int)((total + 7) / 8) : 0;
     hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)(chunk ? 8 * chunk : total)), dim3(U3_NW * 64), 0, s, L, Npad, c0, ncb, nlive_rb, Pk,
-                       lstride, pstride, tpm, ntc, batch, chunk, rowtile, kbeg / 8, kend - kbeg);
+                       lstride, pstride, tpm, ntc, batch, chunk, rowtile, kbeg / 8, kend - kbeg, (const int4 *)nullptr, (double *)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -310,4 +325,78 @@ int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t
     int rc = launch_chol_pack3(Lpanel, Npad, r0, 64 * p0, 64 * (pend - p0), batch, lstride, ws, wstride, s);
     if (rc) return rc;
     return launch_chol_update3_range(L, Npad, r0, Npad - r0, 64 * p0, 64 * pend, Npad, batch, lstride, ws, wstride, s);
+}
+
+
+// ---- C = P P^T for an UPPER triangular P (K^-1 = W^T W with P = W^T as the ride-along leaves it: ibo_nlml_grad), lower 128 x 128 tiles of C.
+// Tile row I starts its K range at its own first row (everything left of it is zero), so tile (0, 0) is N deep and the last tiles 64: dealt whole,
+// the first row's tiles ARE the launch (561 tiles at N = 4096 are one round of the chip).  Here K ranges beyond `piece` columns go out in pieces
+// (pieces of a tile sum in a fixed order afterwards: syrk3_sum_kernel), longest pieces first.
+// P's fragments: as chol_pack3_kernel, with exact zeros where the block column lies left of the row's diagonal block (the ride-along never wrote
+// there); only columns from the row's 128-row tile on are ever read.
+__global__ __launch_bounds__(256) void syrk3_pack_kernel(const double *__restrict__ P, int Npad, double *__restrict__ Pk)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int nk8 = Npad >> 3;
+    if (e >= (size_t)Npad * Npad) return;
+    const int h = (int)(e & 1), lane = (int)((e >> 1) & 63);
+    const size_t gj = e >> 7;
+    const int j = (int)(gj % nk8), g = (int)(gj / nk8);
+    const int row = 16 * g + (lane & 15), col = 8 * j + 4 * h + (lane >> 4);
+    if (col < (row & ~127)) return;
+    Pk[e] = (col >> 6) >= (row >> 6) ? P[(size_t)row * Npad + col] : 0.0;
+}
+// C tile += its later pieces, in piece order (sums[]: tile index, first slot, number of slots)
+__global__ __launch_bounds__(256) void syrk3_sum_kernel(double *__restrict__ C, int Npad, const double *__restrict__ part, const int4 *__restrict__ sums)
+{
+    const int4 sm = sums[blockIdx.x];            // x: tile row I, y: tile column J, z: first slot, w: slots
+    const int I = sm.x, J = sm.y;
+    for (int e = blockIdx.y * 2048 + threadIdx.x; e < (int)(blockIdx.y + 1) * 2048; e += 256) {       // (eight workgroups per tile)
+        const int r = e >> 7, c = e & 127;
+        const int row = 128 * I + r, col = 128 * J + c;
+        if (row >= Npad || col >= Npad || (I == J && (c >> 6) > (r >> 6))) continue;      // (a diagonal tile's upper 64-block is never formed)
+        double v = C[(size_t)row * Npad + col];
+        for (int k = 0; k < sm.w; k++) v += part[(size_t)(sm.z + k) * 16384 + e];
+        C[(size_t)row * Npad + col] = v;
+    }
+}
+
+// host side of the task list for one Npad (kept by the caller's workspace): tasks (int4 per workgroup), sums (int4 per tile dealt in pieces)
+void syrk3_plan(int Npad, int piece, std::vector<int> &tasks, std::vector<int> &sums, int *nslots)
+{
+    const int nt = (Npad + 127) / 128;
+    struct T { int len, t, kb8, pslot; };
+    std::vector<T> all;
+    int slot = 0, t = 0;
+    for (int I = 0; I < nt; I++)
+        for (int J = 0; J <= I; J++, t++) {
+            const int k0 = 128 * I, len = Npad - k0;                 // (a multiple of 64)
+            const int np = len > piece + piece / 4 ? (len + piece - 1) / piece : 1;
+            const int per = ((len / np + 63) / 64) * 64;
+            int first = -1, cnt = 0;
+            for (int p = 0, k = k0; k < Npad; p++, k += per) {
+                const int l = k + per <= Npad ? per : Npad - k;
+                int ps = 0;
+                if (p > 0) { ps = ++slot; if (first < 0) first = slot - 1; cnt++; }
+                all.push_back(T{l, t, k / 8, ps});
+            }
+            if (cnt) { sums.push_back(I); sums.push_back(J); sums.push_back(first); sums.push_back(cnt); }
+        }
+    std::stable_sort(all.begin(), all.end(), [](const T &a, const T &b) { return a.len > b.len; });
+    for (const T &a : all) { tasks.push_back(a.t); tasks.push_back(a.kb8); tasks.push_back(a.len); tasks.push_back(a.pslot); }
+    *nslots = slot;
+}
+
+// P: Npad x Npad row-major upper triangular (blocks left of the diagonal blocks never read); Pk: Npad^2 doubles of scratch; C: the product's lower tiles;
+// tasks_dev / sums_dev / part: syrk3_plan's lists on the device and nslots x 16384 doubles
+int launch_syrk3(const double *P, double *Pk, double *C, int Npad, const int *tasks_dev, int ntasks, const int *sums_dev, int nsums, double *part,
+                 hipStream_t s)
+{
+    const size_t total = (size_t)Npad * Npad;
+    hipLaunchKernelGGL(syrk3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, Npad, Pk);
+    const int nt = (Npad + 127) / 128;
+    hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)ntasks), dim3(U3_NW * 64), 0, s, C, Npad, 0, Npad / 16, Npad / 16, (const double *)Pk,
+                       (size_t)0, (size_t)0, nt * (nt + 1) / 2, nt, 1, 0, 0, 0, 0, (const int4 *)tasks_dev, part);
+    if (nsums) hipLaunchKernelGGL(syrk3_sum_kernel, dim3((unsigned)nsums, 8), dim3(256), 0, s, C, Npad, (const double *)part, (const int4 *)sums_dev);
+    return (int)hipGetLastError();
 }

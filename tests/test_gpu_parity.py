@@ -1332,6 +1332,24 @@ def test_single_level_fit_at_every_launch_shape(ibo):
             GaussianProcess(GaussianKernel_ard([.3, .4, .5]), Xd, Y, noise=0.0)
 
 
+def test_nlml_gradient_from_2560_rows_on_the_packed_operand_product(ibo):
+    """from 2560 rows ibo_nlml_grad forms K^-1 = W^T W on chol_update3_kernel (csrc/update3.hip launch_syrk3: W^T packed into fragment order,
+    128 x 128 tiles, K ranges beyond ~1280 columns in pieces that are summed in a fixed order): value and gradient against the oracle
+    (ego/gaussianprocess/trainhyper.py:47-95) where the last tile row is 64 rows (2600 -> 2624) and where it is whole (2688), an evaluation
+    repeated bit for bit, and the sizes below the switch unchanged by it"""
+    import oracle.oracle as orc
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+    theta = [.5, .7, .9, 1.1]
+    for N in (2600, 2688):
+        X, Y = synth(N + 7, N, 4)
+        v, g = marginalLikelihood(GaussianKernel_ard(theta), X, Y, 4, True, noise=1e-2)
+        ov, od = orc.marginal_likelihood(orc.Kern("ard", theta), X, Y, 4, True, 1e-2)
+        assert abs(v - ov) <= 1e-9 * abs(ov) and np.abs(np.asarray(g) - np.asarray(od)).max() <= 1e-8 * np.abs(od).max(), (N, g, od)
+        v2, g2 = marginalLikelihood(GaussianKernel_ard(theta), X, Y, 4, True, noise=1e-2)
+        assert v2 == v and np.array_equal(np.asarray(g2), np.asarray(g))
+
+
 def test_nlml_grid_does_not_depend_on_what_shares_its_launches(ibo):
     """the batched NLML grid: the same values whatever the batch size, alone or together; a theta whose matrix is not positive definite
     leaves nothing behind"""

@@ -34,7 +34,7 @@ SPEC = {
     "fit4096": (("chol_pipe", "chol_step"), 8, "fit (tools/time_fit.py: the constructor's fit + 7)"),
     "fit2048": (("chol_pipe", "chol_step"), 8, "fit"),           # chol_pipe8_kernel since round 4 (chol_pipe_kernel / chol_step*_kernel before)
     "fit1024": (("chol_pipe", "chol_step"), 8, "fit"),
-    "learn4096": (("chol_pipe", "chol_step", "wtw_kernel", "nlml_grad"), 8, "NLML + gradient evaluation (tools/learn_only.py 4096 16 8): factorisation, W^T W, contraction"),
+    "learn4096": (("chol_pipe", "chol_step", "wtw_kernel", "chol_update3", "syrk3", "nlml_grad"), 8, "NLML + gradient evaluation (tools/learn_only.py 4096 16 8): factorisation, W^T W, contraction"),
     "learn1024": (("chol_pipe", "chol_step", "wtw_kernel", "nlml_grad"), 8, "NLML + gradient evaluation (tools/learn_only.py 1024 16 8)"),
 }
 for name in ("c3", "c5", "fit4096", "fit2048", "fit1024", "learn4096", "learn1024", "gallery", "c4"):
