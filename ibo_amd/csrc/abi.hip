@@ -1570,7 +1570,7 @@ extern "C" int ibo_direct_max(ibo_gp_t *g, int D, const double *lb, const double
 struct NlmlWorkspace {
     DevBuf<double> dX, dY, dout, dL, d64, dP;       // dP: packed store of the trailing updates (update3.hip)
     DevBuf<KParams> dkp;                            // the theta-points' kernel parameters (one covariance launch per sub-batch)
-    DevBuf<int> dinfo;
+    DevBuf<int> dinfo, dflags;                      // dflags: four hand-over words per matrix (chol_panel_fused_kernel)
     const double *padded = nullptr;                 // dL as it was when its matrices got their identity pad,
     int pad_Np = 0, pad_N = 0, pad_B = 0;           // and for which geometry
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};     // sub-batches of a grid run side by side (created on first use, kept)
@@ -1589,7 +1589,7 @@ extern "C" int ibo_trim(int device)
     IBO_TRY(use_device(device));
     std::lock_guard<std::mutex> lk(g_dev_mu[device & 15]);
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
-    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release(); ws.dkp.release();
+    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release(); ws.dflags.release(); ws.dkp.release();
     ws.padded = nullptr;
     for (int g = 0; g < 4; g++) if (ws.streams[g]) { (void)hipStreamDestroy(ws.streams[g]); ws.streams[g] = nullptr; }
     GradWorkspace &gw = g_grad_ws[device & 15];
@@ -1636,6 +1636,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     const bool left = g_chol_left != 0;
     const size_t pws = nn;
     IBO_TRY(ws.dP.ensure(pws * B));
+    IBO_TRY(ws.dflags.ensure((size_t)4 * B));
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
     // identity pad once: the factorisation leaves the pad rows/columns as it found them, so the workspace of an
@@ -1662,7 +1663,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
             if (!ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
             hipStream_t sg = ws.streams[g];
             const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
-            grp[g] = CholGroup{dL.p + nn * k0, d64.p + (size_t)(Np / 64) * 4096 * k0, ws.dP.p + pws * k0, dinfo.p + t0 + k0, ng, sg};
+            grp[g] = CholGroup{dL.p + nn * k0, d64.p + (size_t)(Np / 64) * 4096 * k0, ws.dP.p + pws * k0, dinfo.p + t0 + k0, ng, sg, ws.dflags.p + 4 * k0};
             KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg));
             KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
         }

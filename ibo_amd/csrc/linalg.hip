@@ -870,10 +870,247 @@ void chol_panel_diag_kernel(double *L, int Npad, int p0, int P, double *__restri
     }
 }
 
+// ---- the panel's diagonal block AND the rows below it in ONE launch (round 5; the batched left-looking order).  As two launches the chain of the
+// diagonal block (~90 us, one workgroup per matrix) runs alone on the chip before the row kernel may start.  Here workgroups [0, batch) take the diagonal
+// blocks -- lowest indices: dispatched, hence resident, before any other -- and publish, column by column, that inv(L_jj) and the in-panel row blocks
+// L_{j2,jj} are in memory: those blocks are stored and fetched with the sc1 cache policy (past the XCDs' non-coherent L2 lines), the publisher waits
+// for its stores' acknowledgements and raises one flag word per matrix and column (fences instead -- L2 write-back and invalidation by a thousand
+// workgroups -- made the launch five times slower); the row workgroups (two 64-row blocks each, the geometry and the
+// arithmetic of chol_panel_rows8r_kernel per block: identical bits) load their own tiles, then wait for column jj's flag before they fetch its
+// operands, so they work on column jj while the diagonal workgroup factors column jj + 1.  A wait is bounded: on a timeout the workgroup reports
+// through the info word and leaves (a wrong factor flagged not-positive-definite instead of a hung GPU).
+typedef unsigned pf_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned pf_u4 __attribute__((ext_vector_type(4)));
+#define PF_SC1 16       // buffer instruction cache policy: past the non-coherent L2 lines, to where every XCD sees it
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pf_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+}
+// pr8_fetch of the 64 x 64 block at byte offset `base` (row stride ld8 bytes) through the coherent path
+__device__ __forceinline__ void pf_fetch(const __amdgpu_buffer_rsrc_t r, unsigned base, unsigned ld8, d2_t (&v)[4])
+{
+    const unsigned t = threadIdx.x, voff = (t >> 5) * ld8 + (t & 31) * 16u;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const pf_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, base + (unsigned)(16 * u) * ld8, PF_SC1);
+        v[u].x = __hiloint2double((int)w.y, (int)w.x); v[u].y = __hiloint2double((int)w.w, (int)w.z);
+    }
+}
+__device__ __forceinline__ void pf_store(const __amdgpu_buffer_rsrc_t r, unsigned off, double x)
+{
+    pf_u2 w;
+    w.x = (unsigned)__double2loint(x); w.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, off, 0, PF_SC1);
+}
+__device__ __forceinline__ bool panel_wait(const int *flag, int want, int *info)
+{
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        int good = 1;
+        const long long t0 = wall_clock64();                    // (100 MHz)
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 200000000LL) { good = 0; atomicCAS(info, 0, 0x7ffffff0); break; }     // 2 s (the publisher needs ~20 us): something is wrong
+        }
+        ok = good;
+    }
+    __syncthreads();                                   // (the operands are then fetched through the coherent path: no cache invalidation)
+    return ok != 0;
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void chol_panel_fused_kernel(double *L, int Npad, int p0, int pend, double *__restrict__ diag64, int *info, size_t lstride, size_t dstride,
+                             double *__restrict__ Pk, size_t pstride, int rm_from, int batch, int nrows, int *flags)
+{
+    __shared__ double lds[3 * 64 * SD];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr8 = wv >> 1, wc8 = wv & 1;
+    const int P = pend - p0, want = p0 + 1;
+    if ((int)blockIdx.x < batch) {
+        // ---------------- a diagonal block (chol_panel_diag_kernel's body, publishing after each column's row blocks)
+        const int z = blockIdx.x;
+        double *S = lds, *V = lds + 64 * SD, *T = lds + 2 * 64 * SD;
+        L += z * lstride; diag64 += z * dstride; info += z; flags += 4 * z;
+        auto blk = [&](int r, int c) { return L + (size_t)(p0 + r) * 64 * Npad + (size_t)(p0 + c) * 64; };
+        const __amdgpu_buffer_rsrc_t rL = pf_rsrc(L, (size_t)Npad * Npad * sizeof(double)), rD = pf_rsrc(diag64, (size_t)(Npad / 64) * 32768);
+        const unsigned ld8 = (unsigned)Npad * 8u;
+        auto boff = [&](int r, int c) { return (unsigned)((p0 + r) * 64) * ld8 + (unsigned)(p0 + c) * 512u; };
+        d2_t va[4], vb[4];
+        for (int j = 0; j < P; j++) {
+            const int jb = p0 + j;
+            double *Djj = blk(j, j);
+            {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = Djj[(size_t)(8 * u + wv) * Npad + lane];
+                if (j + 1 < P) pr8_fetch(blk(j + 1, j), Npad, va);
+#pragma unroll
+                for (int u = 0; u < 8; u++) { S[(8 * u + wv) * SD + lane] = v[u]; V[(8 * u + wv) * SD + lane] = 0.0; }
+                if (t < 256) T[(t >> 4) * CHAIN_TD + (t & 15)] = ((t >> 4) == (t & 15)) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            diag64_factor_invert<CHAIN_TD>(S, V, T, jb * 64, info);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int r = 8 * u + wv, c = lane;
+                Djj[(size_t)r * Npad + c] = (c <= r) ? S[r * SD + c] : 0.0;
+                pf_store(rD, (unsigned)jb * 32768u + (unsigned)(r * 64 + c) * 8u, V[r * SD + c]);      // (the inverse: what the row workgroups read)
+            }
+            __syncthreads();
+            for (int r = j + 1; r < P; r++) {
+                pr8_stash(S, va);
+                __syncthreads();
+                if (r + 1 < P) pr8_fetch(blk(r + 1, j), Npad, va);
+                d4_t x[2] = {};
+                if (wc8) pr8_mma_nt_tri_body<1, 2>(S, V, x, wr8, lane);
+                else pr8_mma_nt_tri_body<0, 3>(S, V, x, wr8, lane);
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) pf_store(rL, boff(r, j) + (unsigned)PR8_ROW(q) * ld8 + (unsigned)PR8_COL_TRI(n) * 8u, x[n][q]);
+                __syncthreads();
+            }
+            // column j's inverse and row blocks are on their way past the L2: when every wave's stores are acknowledged, publish
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(flags + j, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool have = false;
+            for (int c = j + 1; c < P; c++)
+                for (int r = c; r < P; r++) {
+                    if (!have) { pf_fetch(rL, boff(r, j), ld8, va); pf_fetch(rL, boff(c, j), ld8, vb); }
+                    double *C = blk(r, c);
+                    d4_t acc[2];
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) acc[n][q] = C[(size_t)PR8_ROW(q) * Npad + PR8_COL(n)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) va[u] = -va[u];
+                    pr8_stash(S, va);
+                    pr8_stash(V, vb);
+                    __syncthreads();
+                    {
+                        int r2 = r + 1, c2 = c;
+                        if (r2 >= P) { c2 = c + 1; r2 = c2; }
+                        have = c2 < P;
+                        if (have) { pf_fetch(rL, boff(r2, j), ld8, va); pf_fetch(rL, boff(c2, j), ld8, vb); }
+                    }
+                    pr8_mma_nt(S, V, acc, wr8, wc8, lane);
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) C[(size_t)PR8_ROW(q) * Npad + PR8_COL(n)] = acc[n][q];
+                    __syncthreads();
+                }
+        }
+        return;
+    }
+    // ---------------- two row blocks below the panel
+    const int nrw = (nrows + 1) / 2, rb = (int)blockIdx.x - batch, z = rb / nrw, pair = rb - z * nrw;
+    double *Xc0 = lds, *Xc1 = lds + 64 * SD, *Bs = lds + 2 * 64 * SD;
+    L += z * lstride; diag64 += z * dstride; info += z; flags += 4 * z;
+    if (Pk) Pk += z * pstride;
+    const int i0 = pend + 2 * pair;
+    const bool two = 2 * pair + 1 < nrows;                    // (workgroup-uniform: the second block exists)
+    const __amdgpu_buffer_rsrc_t rL = pf_rsrc(L, (size_t)Npad * Npad * sizeof(double)), rD = pf_rsrc(diag64, (size_t)(Npad / 64) * 32768);
+    const unsigned ld8 = (unsigned)Npad * 8u;
+    auto fetch_b = [&](int jj, int j2, d2_t (&vb)[4]) {
+        if (j2 > jj) pf_fetch(rL, (unsigned)((p0 + j2) * 64) * ld8 + (unsigned)(p0 + jj) * 512u, ld8, vb);
+        else pf_fetch(rD, (unsigned)(p0 + jj) * 32768u, 512u, vb);
+    };
+    auto pack_col = [&](int s, int jj, const double *Xm) {
+        const int g = wv >> 1, nk8 = Npad >> 3;
+        double *dst = Pk + (((size_t)((i0 + s) * 4 + g) * nk8 + (size_t)(p0 + jj) * 8 + 4 * (wv & 1)) * 64 + lane) * 2;
+        const double *src = Xm + (16 * g + (lane & 15)) * SD + 32 * (wv & 1) + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            d2_t v;
+            v.x = -src[8 * j]; v.y = -src[8 * j + 4];
+            *(d2_t *)(dst + (size_t)j * 128) = v;
+        }
+    };
+    d2_t vb[4];
+    d4_t acc[2][4][2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const double *Ai = L + (size_t)(i0 + s) * 64 * Npad + (size_t)p0 * 64;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (c < P && (s == 0 || two)) {
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[s][c][n][r] = Ai[(size_t)PR8_ROW(r) * Npad + c * 64 + PR8_COL(n)];
+            }
+    }
+    if (!panel_wait(flags + 0, want, info)) return;
+    fetch_b(0, 0, vb);
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        if (jj >= P) break;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            if (s == 0 || two) {
+                double *Xc = s ? Xc1 : Xc0;
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Xc[PR8_ROW(r) * SD + PR8_COL(n)] = acc[s][jj][n][r];
+            }
+        pr8_stash(Bs, vb);
+        __syncthreads();
+        if (jj + 1 < P) fetch_b(jj, jj + 1, vb);
+        d4_t x[2][2] = {};
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            if (s == 0 || two) {
+                double *Xc = s ? Xc1 : Xc0;
+                if (wc8) pr8_mma_nt_tri_stream<1, 2>(Xc, Bs, x[s], wr8, lane);
+                else pr8_mma_nt_tri_stream<0, 3>(Xc, Bs, x[s], wr8, lane);
+                if (!Pk || i0 + s >= rm_from) {
+                    double *Ai = L + (size_t)(i0 + s) * 64 * Npad + (size_t)p0 * 64;
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Ai[(size_t)PR8_ROW(r) * Npad + jj * 64 + PR8_COL_TRI(n)] = x[s][n][r];
+                }
+            }
+        __syncthreads();
+        if (jj + 1 < P || Pk) {
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                if (s == 0 || two) {
+                    double *Xc = s ? Xc1 : Xc0;
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Xc[PR8_ROW(r) * SD + PR8_COL_TRI(n)] = -x[s][n][r];
+                }
+        }
+#pragma unroll
+        for (int j2 = 1; j2 < 4; j2++) {
+            if (j2 <= jj || j2 >= P) continue;
+            pr8_stash(Bs, vb);
+            __syncthreads();
+            if (j2 + 1 < P) fetch_b(jj, j2 + 1, vb);
+            else {
+                if (!panel_wait(flags + jj + 1, want, info)) return;      // (the next column's inverse)
+                fetch_b(jj + 1, jj + 1, vb);
+            }
+            if (Pk && j2 == jj + 1) { pack_col(0, jj, Xc0); if (two) pack_col(1, jj, Xc1); }
+            pr8_mma_nt(Xc0, Bs, acc[0][j2], wr8, wc8, lane);
+            if (two) pr8_mma_nt(Xc1, Bs, acc[1][j2], wr8, wc8, lane);
+            __syncthreads();
+        }
+        if (Pk && jj + 1 == P) {
+            __syncthreads();
+            pack_col(0, jj, Xc0); if (two) pack_col(1, jj, Xc1);
+        }
+    }
+}
+
 // the block columns [p0, pend) of a panel whose columns are up to date: diagonal blocks, row blocks, K = 64 updates inside the panel.
 // Returns true when the rows below the panel went to the packed store Pk (left-looking order) on the way.
 static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, int *info_dev, int batch, size_t lstride, hipStream_t s,
-                         double *Pk = nullptr, size_t pstride = 0, int rm_from = 0)
+                         double *Pk = nullptr, size_t pstride = 0, int rm_from = 0, int *flags = nullptr)
 {
     const int nb = Npad / 64;
     const size_t dstride = (size_t)nb * 4096;
@@ -881,6 +1118,13 @@ static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
     // chol_panel_diag_kernel -- and the rows below it take the whole panel in one more (chol_panel_rows8r_kernel): the same arithmetic
     // in the same order as the per-column sequence, which runs where the rows are few (its short launches finish sooner).
     const bool rows_fused = pend - p0 <= 4 && (size_t)(nb - pend) * batch >= 256;
+    if (rows_fused && pend < nb && flags) {
+        // (flags: four ints per matrix, zero at the start of the factorisation)
+        const int nrows = nb - pend, nrw = (nrows + 1) / 2;
+        hipLaunchKernelGGL(chol_panel_fused_kernel, dim3((unsigned)(batch + batch * nrw)), dim3(512), 0, s, L, Npad, p0, pend, diag64, info_dev, lstride,
+                           dstride, Pk, pstride, rm_from, batch, nrows, flags);
+        return Pk != nullptr;
+    }
     if (rows_fused)
         hipLaunchKernelGGL(chol_panel_diag_kernel, dim3(1, 1, batch), dim3(512), 0, s, L, Npad, p0, pend - p0, diag64, info_dev, lstride, dstride);
     else
@@ -937,7 +1181,10 @@ int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad,
     const int nb = Npad / 64;
     const int P = panel;
     if (nfactor <= 0 || nfactor > nb) nfactor = nb;
-    for (int g = 0; g < ngroups; g++) HIPCHK(hipMemsetAsync(groups[g].info, 0, sizeof(int) * groups[g].batch, groups[g].stream));
+    for (int g = 0; g < ngroups; g++) {
+        HIPCHK(hipMemsetAsync(groups[g].info, 0, sizeof(int) * groups[g].batch, groups[g].stream));
+        if (groups[g].flags) HIPCHK(hipMemsetAsync(groups[g].flags, 0, sizeof(int) * 4 * groups[g].batch, groups[g].stream));
+    }
     // THE TAIL.  Left-looking, the last panels have few tiles (17 .. 5 per matrix over the last 1024 columns) and a long K: the
     // chip runs half empty (46 .. 81 % of the update kernel's rate on panels 12 .. 15 of 16).  From block column `tail` on the
     // order changes: ONE update brings all remaining columns up to date with everything before `tail` (many tiles, long K), and
@@ -961,7 +1208,8 @@ int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad,
             }
             // the rows below the panel reach the packed store straight from chol_panel_rows8r_kernel's LDS where that kernel runs
             // (and then only the block rows >= rm_from are also stored row-major), through chol_pack3_kernel otherwise
-            const bool packed = chol_inpanel(G.L, Npad, p0, pend, G.diag64, G.info, G.batch, lstride, G.stream, pend < nfactor ? G.Pk : nullptr, pstride, rm_from);
+            const bool packed = chol_inpanel(G.L, Npad, p0, pend, G.diag64, G.info, G.batch, lstride, G.stream, pend < nfactor ? G.Pk : nullptr, pstride, rm_from,
+                                             G.flags);
             if (pend < nfactor && !packed) {
                 int rc = launch_chol_pack3(G.L, Npad, 64 * pend, 64 * p0, 64 * (pend - p0), G.batch, lstride, G.Pk, pstride, G.stream);
                 if (rc) return rc;
