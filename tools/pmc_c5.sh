@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "update" in k or "rows" in k or "panel_diag" in k or "cov_grid" in k:
+        if "update" in k or "rows" in k or "panel_" in k or "cov_grid" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in acc.items():
     tot = {n: sum(v) for n, v in c.items()}
