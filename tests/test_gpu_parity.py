@@ -1396,18 +1396,22 @@ def test_left_looking_grid_equals_the_right_looking_one(ibo, oracle):
     update in one long-K launch, from one packed copy of the factor, pad rows untouched, the y row's lonely last block column
     left out); same sums in the same order as the right-looking two-level order: identical values -- for sizes on, just
     below and just above multiples of 64 / 128 / 256, batches that are not multiples of 8, a theta that is not positive
-    definite in the middle of a batch -- and the oracle's"""
+    definite in the middle of a batch, batches large enough for the fused panel launches -- and the oracle's"""
     from ibo_amd import _lib
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard, MaternKernel5
     from ibo_amd.gaussianprocess.trainhyper import nlml_grid
     rs = np.random.RandomState(31)
     for N, D, nth, noise in ((256, 3, 5, .01), (255, 3, 9, .01), (257, 2, 3, .01), (320, 4, 8, .01), (511, 5, 16, .01), (512, 5, 17, .01),
-                             (700, 3, 4, .01), (1024, 4, 11, 1e-3), (1100, 6, 3, 1e-3), (2048, 8, 8, 1e-3)):
+                             (700, 3, 4, .01), (1024, 4, 11, 1e-3), (1100, 6, 3, 1e-3), (2048, 8, 8, 1e-3),
+                             # enough row blocks x matrices for the ONE-launch panels (chol_panel_fused_kernel: diagonal workgroups and row
+                             # workgroups handing over through flags): an even and an odd number of row blocks below a panel
+                             (1500, 5, 32, .01), (1599, 4, 32, .01), (2300, 3, 24, .01)):
         X, Y = synth(N + D, N, D)
         th = np.exp(rs.uniform(np.log(.2), np.log(2), size=(nth, D)))
-        if nth >= 5:
+        bad = nth >= 5 and N <= 1100                     # (beyond, the tiny noise below leaves no theta of the draw positive definite)
+        if bad:
             th[2] = 3e3                                  # numerically singular with the tiny noise below: NaN in that slot
-        nz = 1e-14 if nth >= 5 else noise
+        nz = 1e-14 if bad else noise
         out = []
         for left in (1, 0, 1):
             _lib.check(_lib.lib.ibo_set_option(b"chol_left", left))
@@ -1416,8 +1420,10 @@ def test_left_looking_grid_equals_the_right_looking_one(ibo, oracle):
             finally:
                 _lib.check(_lib.lib.ibo_set_option(b"chol_left", 1))
         assert np.array_equal(out[0], out[1], equal_nan=True) and np.array_equal(out[0], out[2], equal_nan=True), (N, D, nth)
-        if nth >= 5:
+        if bad:
             assert np.isnan(out[0][2]) and np.isfinite(out[0]).sum() >= nth // 2, out[0]
+        else:
+            assert np.all(np.isfinite(out[0])), (N, D, nth)
         if N <= 512 and nth < 5:
             for t in range(nth):
                 close(out[0][t], oracle.nlml_c(oracle.Kern("ard", th[t]), X, Y, noise=nz), rtol=1e-9)
