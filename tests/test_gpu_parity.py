@@ -1439,6 +1439,30 @@ def test_left_looking_grid_equals_the_right_looking_one(ibo, oracle):
             _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 0))
 
 
+def test_fused_panel_launches_with_a_failed_matrix_in_the_batch(ibo):
+    """chol_panel_fused_kernel's row workgroups wait on flags the diagonal workgroups raise: a matrix whose chain breaks down (NaN pivots) raises
+    them all the same -- its slot is NaN, nobody waits for ever, and the other 31 values are those of the right-looking order and of a batch
+    without the failed matrix"""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid
+    X, Y = synth(1505, 1500, 5)
+    th = np.exp(np.random.RandomState(77).uniform(np.log(.05), np.log(.12), size=(32, 5)))      # nearly diagonal matrices: fine with next to no noise
+    good = nlml_grid(GaussianKernel_ard, th, X, Y, noise=1e-14)[0]
+    assert np.all(np.isfinite(good))
+    th2 = th.copy(); th2[5] = 3e3                       # numerically singular
+    out = []
+    for left in (1, 0):
+        _lib.check(_lib.lib.ibo_set_option(b"chol_left", left))
+        try:
+            out.append(nlml_grid(GaussianKernel_ard, th2, X, Y, noise=1e-14)[0])
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"chol_left", 1))
+    assert np.isnan(out[0][5]) and np.array_equal(out[0], out[1], equal_nan=True)
+    keep = np.arange(32) != 5
+    assert np.array_equal(np.asarray(out[0])[keep], np.asarray(good)[keep])
+
+
 def test_randomised_parity_sweep(ibo, oracle):
     """a seeded slice of tools/fuzz_gpu.py: random (N, D, kernel family, noise, M) -- fit, posterior mean/variance and
     libego-flavoured EI of every candidate against the oracle, all within the 1e-6 bar; arg-max = first maximiser"""
