@@ -1652,32 +1652,55 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     IBO_TRY(ws.dkp.ensure(n_theta));
     HIP_TRY(hipMemcpy(ws.dkp.p, kps.data(), sizeof(KParams) * n_theta, hipMemcpyHostToDevice));
     HIP_TRY(hipStreamSynchronize(s));               // the identity pad is in place before the sub-batches' streams start
+    // Whatever way this function is left, nothing of it stays in flight on the sub-batch streams: they are non-blocking, so the next
+    // call's blocking copies into dX / dY / dkp would not wait for them (an error return inside the batch loop used to leave them running).
+    struct StreamDrain {
+        NlmlWorkspace &w;
+        ~StreamDrain() { for (int g = 0; g < 4; g++) if (w.streams[g]) (void)hipStreamSynchronize(w.streams[g]); }
+    } drain{ws};
+    std::vector<int> info(n_theta);
     for (int t0 = 0; t0 < n_theta; t0 += B) {
         const int nb = n_theta - t0 < B ? n_theta - t0 : B;
-        // sub-batches of at least 8 matrices, each on its own stream: one's in-panel chain (64 workgroups at a time, latency)
-        // and launch tails run beside the other's long-K updates
-        int G = left ? g_nlml_groups.load() : 1;
-        while (G > 1 && nb / G < 8) G--;
-        CholGroup grp[4];
-        for (int g = 0; g < G; g++) {
-            if (!ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
-            hipStream_t sg = ws.streams[g];
-            const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
-            grp[g] = CholGroup{dL.p + nn * k0, d64.p + (size_t)(Np / 64) * 4096 * k0, ws.dP.p + pws * k0, dinfo.p + t0 + k0, ng, sg, ws.dflags.p + 4 * k0};
-            KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg));
-            KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
+        // One batch.  with_flags: the panels' diagonal blocks and the rows below them in one launch whose row workgroups wait on flags the
+        // diagonal workgroups raise (chol_panel_fused_kernel).  Such a wait is bounded; if one ever runs out (the launch's forward progress
+        // rests on the dispatch order of its workgroups) the workgroup leaves the code kPanelWaitTimeout in the matrix's info word -- which
+        // says nothing about the matrix: the batch is then run again through the two-launch form of the panels (no waits, the same bits).
+        auto run_batch = [&](bool with_flags) -> int {
+            // sub-batches of at least 8 matrices, each on its own stream: one's in-panel chain (64 workgroups at a time, latency)
+            // and launch tails run beside the other's long-K updates
+            int G = left ? g_nlml_groups.load() : 1;
+            while (G > 1 && nb / G < 8) G--;
+            CholGroup grp[4];
+            for (int g = 0; g < G; g++) {
+                if (!ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
+                hipStream_t sg = ws.streams[g];
+                const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
+                grp[g] = CholGroup{dL.p + nn * k0, d64.p + (size_t)(Np / 64) * 4096 * k0, ws.dP.p + pws * k0, dinfo.p + t0 + k0, ng, sg,
+                                   with_flags ? ws.dflags.p + 4 * k0 : nullptr};
+                KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg));
+                KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
+            }
+            // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
+            if (left) KERNEL_TRY(launch_cholesky_batched_left(grp, G, Np, nn, 4, pws, N + 1, N % 64 == 0 ? Np / 64 - 1 : Np / 64, N / 64));
+            else KERNEL_TRY(launch_cholesky_batched(grp[0].L, Np, grp[0].diag64, grp[0].info, grp[0].batch, nn, 4, grp[0].stream, grp[0].Pk, pws));      // (G = 1)
+            for (int g = 0; g < G; g++) KERNEL_TRY(launch_nlml_reduce(grp[g].L, Np, N, dout.p + 2 * (size_t)(grp[g].info - dinfo.p), grp[g].stream, grp[g].batch, nn));
+            for (int g = 0; g < G; g++) HIP_TRY(hipStreamSynchronize(ws.streams[g]));      // the next batch reuses the matrix slots
+            HIP_TRY(hipMemcpy(info.data() + t0, dinfo.p + t0, sizeof(int) * nb, hipMemcpyDeviceToHost));
+            return IBO_OK;
+        };
+        IBO_TRY(run_batch(true));
+        bool timed_out = false;
+        for (int k = 0; k < nb; k++) timed_out |= info[t0 + k] == kPanelWaitTimeout;
+        if (timed_out) {
+            // (the matrices were overwritten by the failed attempt: run_batch forms them again; the identity pad is untouched by a factorisation)
+            IBO_TRY(run_batch(false));
+            for (int k = 0; k < nb; k++)
+                if (info[t0 + k] == kPanelWaitTimeout) return fail(IBO_ERR_HIP, "a panel launch reported a wait that ran out on the path that has no waits");
         }
-        // (N a multiple of 64: the y row sits alone in the last block column, whose factor nobody reads -- it is left out)
-        if (left) KERNEL_TRY(launch_cholesky_batched_left(grp, G, Np, nn, 4, pws, N + 1, N % 64 == 0 ? Np / 64 - 1 : Np / 64, N / 64));
-        else KERNEL_TRY(launch_cholesky_batched(grp[0].L, Np, grp[0].diag64, grp[0].info, grp[0].batch, nn, 4, grp[0].stream, grp[0].Pk, pws));      // (G = 1)
-        for (int g = 0; g < G; g++) KERNEL_TRY(launch_nlml_reduce(grp[g].L, Np, N, dout.p + 2 * (size_t)(grp[g].info - dinfo.p), grp[g].stream, grp[g].batch, nn));
-        for (int g = 0; g < G; g++) HIP_TRY(hipStreamSynchronize(ws.streams[g]));      // the next batch reuses the matrix slots 
     }
     HIP_TRY(hipStreamSynchronize(s));
     std::vector<double> out(2 * (size_t)n_theta);
-    std::vector<int> info(n_theta);
     HIP_TRY(hipMemcpy(out.data(), dout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(info.data(), dinfo.p, sizeof(int) * n_theta, hipMemcpyDeviceToHost));
     const double half_log_2pi_n = 0.5 * N * log(2.0 * M_PI);
     for (int t = 0; t < n_theta; t++)
         nlml_host[t] = info[t] ? NAN : 0.5 * out[2 * t] + out[2 * t + 1] + half_log_2pi_n;

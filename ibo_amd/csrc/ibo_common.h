@@ -258,6 +258,9 @@ int launch_cholesky_batched(double *L, int Npad, double *diag64, int *info_dev, 
 int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t lstride, double *ws, size_t wstride,
                         hipStream_t s, const double *Lpanel = nullptr);
 // left-looking outer order from one packed copy of the finished block columns (update3.hip); bit-identical to the above
+// what a row workgroup of chol_panel_fused_kernel leaves in its matrix's info word when a flag wait runs out (not a pivot: the caller
+// runs the batch again through the launches that have no waits)
+static const int kPanelWaitTimeout = 0x7ffffff0;
 struct CholGroup { double *L, *diag64, *Pk; int *info; int batch; hipStream_t stream; int *flags; };   // flags: 4 ints per matrix (the fused panel kernel's hand-overs) or null      // a sub-batch of matrices (lstride / pstride apart) on its stream
 int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad, size_t lstride, int panel, size_t pstride, int nlive,
                                  int nfactor = 0, int rm_from = 0);

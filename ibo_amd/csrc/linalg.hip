@@ -910,7 +910,7 @@ __device__ __forceinline__ bool panel_wait(const int *flag, int want, int *info)
         const long long t0 = wall_clock64();                    // (100 MHz)
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 200000000LL) { good = 0; atomicCAS(info, 0, 0x7ffffff0); break; }     // 2 s (the publisher needs ~20 us): something is wrong
+            if (wall_clock64() - t0 > 200000000LL) { good = 0; atomicCAS(info, 0, kPanelWaitTimeout); break; }     // 2 s (the publisher needs ~20 us): something is wrong
         }
         ok = good;
     }
@@ -1118,7 +1118,9 @@ static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
     // chol_panel_diag_kernel -- and the rows below it take the whole panel in one more (chol_panel_rows8r_kernel): the same arithmetic
     // in the same order as the per-column sequence, which runs where the rows are few (its short launches finish sooner).
     const bool rows_fused = pend - p0 <= 4 && (size_t)(nb - pend) * batch >= 256;
-    if (rows_fused && pend < nb && flags) {
+    // (the fused launch reaches its blocks through buffer descriptors with 32-bit offsets: one matrix must lie inside 2^31 bytes -- 16 320 rows;
+    // beyond, the two launches below, whose addresses are 64-bit)
+    if (rows_fused && pend < nb && flags && (size_t)Npad * Npad * sizeof(double) <= 0x7fffffffu) {
         // (flags: four ints per matrix, zero at the start of the factorisation)
         const int nrows = nb - pend, nrw = (nrows + 1) / 2;
         hipLaunchKernelGGL(chol_panel_fused_kernel, dim3((unsigned)(batch + batch * nrw)), dim3(512), 0, s, L, Npad, p0, pend, diag64, info_dev, lstride,

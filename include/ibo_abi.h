@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define IBO_ABI_VERSION 6   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info; 6: + ibo_sweep_state_levels */
+#define IBO_ABI_VERSION 7   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info; 6: + ibo_sweep_state_levels;
+                             * 7: no new symbol -- ibo_set_option knows the keys listed below and nothing else: the experiment switches of rounds 2-4
+                             * (nlml_groups, cov_fast, chol_fused, small_local, zero_copy, gallery_lazy, pipe_fit, .. -- about 35 keys) were removed in
+                             * round 5 and now return IBO_ERR_ARG "unknown option", as does a NULL key; ibo_nlml_grid's covariance pass is the fast one */
 
 /* status codes */
 #define IBO_OK              0

@@ -307,7 +307,7 @@ def g7_prefs():
     out = {}
     names = []
     tf = Hartman6()
-    for P in (8, 16, 32):
+    for P in (8, 16, 32, 64):
         rs = np.random.RandomState(40 + P)
         pts = rs.rand(2 * P, 6)
         prefs = []

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), "libibo_hip.so does not export %s" % s
         assert s in _lib.EXPORTED, "%s is declared in ibo_abi.h but not bound in ibo_amd/_lib.py" % s
-    assert _lib.lib.ibo_abi_version() == 6
+    assert _lib.lib.ibo_abi_version() == 7
 
 
 def test_the_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):

@@ -289,8 +289,9 @@ def test_c3_whole_four_million_candidate_array_on_one_gpu(ibo, oracle):
 
 def test_c5_all_sixty_four_thetas_in_one_batch(ibo, oracle):
     """BASELINE config 5's batch as bench.py runs it: 64 theta-points at N = 4096, D = 16 in ONE ibo_nlml_grid call (two
-    sub-batches of 32 on two streams, left-looking).  Three of the values against the oracle's marginal likelihood (NumPy
-    LAPACK on the oracle's K, trainhyper.py:47-75) at 1e-9; all 64 bit-identical to one matrix at a time (nlml_batch = 1)."""
+    sub-batches of 32 on two streams, left-looking).  Eight of the values against the oracle's marginal likelihood (NumPy
+    LAPACK on the oracle's K, trainhyper.py:47-75) at 1e-9 -- the first, the last of each sub-batch and five inside them, among them
+    the grid's arg-min; all 64 bit-identical to one matrix at a time (nlml_batch = 1)."""
     from ibo_amd import _lib
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
     from ibo_amd.gaussianprocess.trainhyper import nlml_grid
@@ -299,7 +300,7 @@ def test_c5_all_sixty_four_thetas_in_one_batch(ibo, oracle):
     thetas = np.exp(np.random.RandomState(105).uniform(np.log(.1), np.log(3), size=(512, D)))[:T]
     vals, am = nlml_grid(GaussianKernel_ard, thetas, X, Y, noise=1e-3)
     assert vals.shape == (T,) and np.all(np.isfinite(vals)) and am == int(np.argmin(vals))
-    for t in (0, 31, 63):                               # first, the last of the first sub-batch, the last of the second
+    for t in sorted({0, 31, 63, 7, 19, 32, 45, 58, am}):   # first, the last of the first sub-batch, the last of the second; five more; the winner
         ref = oracle.marginal_likelihood(oracle.Kern("ard", thetas[t]), X, Y, D, compute_gradient=False, noise=1e-3)
         close(vals[t], ref, rtol=1e-9)
     _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 1))

@@ -5,7 +5,7 @@
 O=${1:-gpurun_out/c5_timeline}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O/t -- python3 tools/c5_only.py nlml_batch=0 > $O/log.txt 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python3 tools/c5_only.py nlml_batch=0 > $O/log.txt 2>&1
 python3 - $O <<'PY' > $O/timeline.txt
 import csv, glob, sys, collections
 O = sys.argv[1]
@@ -14,6 +14,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last grid: from the last cov_grid_kernel pair on
 cg = [i for i, r in enumerate(rows) if 'cov_grid' in r['Kernel_Name']]
+if not cg: sys.exit('no cov_grid launch in the trace (did the run fail? see log.txt)')
 first = cg[-2] if len(cg) >= 2 else cg[-1]
 seq = rows[first:]
 t0 = int(seq[0]['Start_Timestamp']); t1 = max(int(r['End_Timestamp']) for r in seq)

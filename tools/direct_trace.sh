@@ -2,7 +2,7 @@
 # kernel trace of maximizeEI (GPU box): the dependent chain of one batch -- kernel durations and the gaps between them
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/direct_trace; mkdir -p gpurun_out/direct_trace
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/direct_trace/t -- python3 tools/time_direct.py > gpurun_out/direct_trace/log.txt 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/direct_trace/t -- python3 tools/time_direct.py > gpurun_out/direct_trace/log.txt 2>&1
 python3 - <<'PY' > gpurun_out/direct_trace/summary.txt
 import csv, glob, collections
 import numpy as np

@@ -3,7 +3,7 @@
 N=${1:-4096}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/fit_timeline; mkdir -p gpurun_out/fit_timeline
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fit_timeline/t -- python3 tools/time_fit.py "$@" $N > gpurun_out/fit_timeline/log.txt 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fit_timeline/t -- python3 tools/time_fit.py "$@" $N > gpurun_out/fit_timeline/log.txt 2>&1
 python3 - <<'PY' > gpurun_out/fit_timeline/timeline.txt
 import csv, glob
 f = glob.glob('gpurun_out/fit_timeline/t/*/*_kernel_trace.csv')[0]

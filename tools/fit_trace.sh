@@ -4,7 +4,7 @@
 N=${1:-4096}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/fit_trace; mkdir -p gpurun_out/fit_trace
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fit_trace/t -- python3 tools/time_fit.py $N > gpurun_out/fit_trace/log.txt 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fit_trace/t -- python3 tools/time_fit.py $N > gpurun_out/fit_trace/log.txt 2>&1
 python3 - <<'PY' > gpurun_out/fit_trace/summary.txt
 import csv, glob, collections
 f = glob.glob('gpurun_out/fit_trace/t/*/*_kernel_trace.csv')[0]

@@ -3,7 +3,7 @@
 N=${1:-4096}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pipe_cols; mkdir -p gpurun_out/pipe_cols
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pipe_cols/t -- python3 tools/time_fit.py $N "$@" > gpurun_out/pipe_cols/log.txt 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pipe_cols/t -- python3 tools/time_fit.py $N "$@" > gpurun_out/pipe_cols/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/pipe_cols/t/*/*_kernel_trace.csv')[0]

@@ -5,7 +5,7 @@ OUT=gpurun_out/pmc_c5
 rm -rf $OUT; mkdir -p $OUT
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pass | cut -d" " -f1)
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python3 tools/c5_only.py > $OUT/pmc_$tag.log 2>&1
+  timeout -k 5 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python3 tools/c5_only.py > $OUT/pmc_$tag.log 2>&1
 done
 python3 - <<PY > $OUT/summary.txt
 import csv, glob, collections
