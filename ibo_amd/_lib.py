@@ -57,6 +57,7 @@ _sig("ibo_last_error", c_char_p)
 _sig("ibo_device_count", c_int, POINTER(c_int))
 _sig("ibo_device_name", c_int, c_int, c_char_p, c_size_t)
 _sig("ibo_selftest_mfma", c_int, c_int, _DP)
+_sig("ibo_gpu_time_ms", c_int, c_int, _DP)
 _sig("ibo_set_option", c_int, c_char_p, c_int)
 _sig("ibo_trim", c_int, c_int)
 _sig("ibo_dev_alloc", c_int, c_int, c_size_t, POINTER(c_void_p))
@@ -108,6 +109,8 @@ _sig("ibo_comm_destroy", c_int, c_void_p)
 _sig("ibo_comm_count", c_int, c_void_p, POINTER(c_int))
 _sig("ibo_comm_argmax", c_int, c_void_p, c_double, c_int64, _DP, c_int, _DP, POINTER(c_int64), _DP, POINTER(c_int))
 _sig("ibo_comm_allreduce_sum", c_int, c_void_p, _DP, c_int64)
+_sig("ibo_acq_sweep_exchange", c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_double, c_int, c_double, c_double,
+     c_int, _DP, c_double, c_int64, _DP, POINTER(c_int64), _DP, POINTER(c_int64), _DP, POINTER(c_int))
 _sig("ibo_comm_barrier", c_int, c_void_p)
 # legacy libego symbols (kept so the .so is a drop-in under the reference's own ctypes code)
 _sig("acqmaxGP", _DP, c_int, _DP, _DP, _DP, _DP, _DP, c_int, c_int, c_int, _DP, c_int, _DP, _DP, c_double, _DP, _DP,
@@ -115,13 +118,13 @@ _sig("acqmaxGP", _DP, c_int, _DP, _DP, _DP, _DP, _DP, c_int, c_int, c_int, _DP, 
 _sig("direct", _DP, OBJECTIVE, c_int, _DP, _DP, c_int, c_int, c_int)
 _sig("logCDFs", c_double, c_int, POINTER(c_int), _DP)
 
-EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device_name", "ibo_selftest_mfma",
+EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device_name", "ibo_selftest_mfma", "ibo_gpu_time_ms",
             "ibo_set_option", "ibo_trim", "ibo_dev_alloc", "ibo_dev_free", "ibo_memcpy_h2d", "ibo_memcpy_d2h",
             "ibo_device_synchronize", "ibo_dev_generation", "ibo_gp_create", "ibo_gp_destroy", "ibo_gp_fit", "ibo_gp_fit_with_matrix",
             "ibo_gp_extend", "ibo_gp_reserve", "ibo_pref_begin", "ibo_pref_rinv_mul", "ibo_pref_newton_step", "ibo_pref_finish", "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
             "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_spd_solve", "ibo_spd_inverse", "ibo_posterior_batch",
             "ibo_acq_sweep", "ibo_acq_batch", "ibo_acq_sweep_incremental", "ibo_sweep_state_info", "ibo_sweep_state_levels", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_host", "ibo_nlml_grid", "ibo_nlml_grad",
-            "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_count", "ibo_comm_argmax", "ibo_comm_allreduce_sum", "ibo_comm_barrier",
+            "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_count", "ibo_comm_argmax", "ibo_comm_allreduce_sum", "ibo_acq_sweep_exchange", "ibo_comm_barrier",
             "acqmaxGP", "direct", "logCDFs"]
 
 
@@ -146,6 +149,13 @@ def device_count():
     n = c_int(0)
     check(lib.ibo_device_count(ctypes.byref(n)))
     return n.value
+
+
+def gpu_time_ms(device=None):
+    """device time the library has measured with HIP events in this process so far (ibo_gpu_time_ms), ms"""
+    v = ctypes.c_double(0.0)
+    check(lib.ibo_gpu_time_ms(default_device() if device is None else int(device), ctypes.byref(v)))
+    return v.value
 
 
 def trim(device=None):

@@ -172,7 +172,7 @@ def maximizeEI(model, bounds, useCDIRECT=True, xi=0.01, maxiter=50, maxtime=30, 
 
 
 def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None, native=True, ymax=None,
-          exclude=None, exclude_radius=0.5, index_base=0, outputs=(), NA=None, incremental=False):
+          exclude=None, exclude_radius=0.5, index_base=0, outputs=(), NA=None, incremental=False, exchange=None):
     """Evaluate an acquisition over a whole candidate array and return its arg-max.
 
     candidates   (M, D) ndarray (uploaded) or a _lib.DeviceArray already in HBM
@@ -185,6 +185,9 @@ def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None,
                  (fastUCBGallery's rounds).  Honoured for a caller-owned DeviceArray only (an ndarray is uploaded to a
                  temporary and swept in full); the state is keyed on the array's generation (_lib.DeviceArray.generation),
                  so a freed-and-reallocated or re-uploaded array is swept in full again
+    exchange     an ibo_amd.multigpu.RcclArgmax: the sharded step in one device-side call (ibo_acq_sweep_exchange) -- this rank's
+                 arg-max goes from the sweep's output words into the all-reduce buffer without visiting the host; the result then
+                 also carries global_val, global_idx, global_x, global_rank (identical on every rank).  No `outputs` with it.
     Returns dict(best_val, best_idx, kernel_ms, [mu], [s2], [acq]); first maximiser wins ties.
     """
     if isinstance(candidates, _lib.DeviceArray):
@@ -209,20 +212,34 @@ def sweep(model, candidates, acq='ei', xi=0.01, delta=0.1, scale=0.2, parm=None,
     bv = ctypes.c_double(); bi = ctypes.c_int64()
     if native:
         _lib.check(_lib.lib.ibo_gp_set_kstar_sf2(h, sf2_native))
+    glob = None
     try:
+        if exchange is not None:
+            if outputs:
+                raise ValueError("per-candidate outputs are not available together with exchange=")
+            gv = ctypes.c_double(); gi = ctypes.c_int64(); gr = ctypes.c_int(); gx = np.zeros(cand.shape[1])
+            _lib.check(_lib.lib.ibo_acq_sweep_exchange(
+                h, exchange.h, 1 if incremental else 0, M, cand.ptr, code, float(parm), _lib.ERF_LIBM if native else _lib.ERF_NR,
+                _lib.CLAMP_NATIVE if native else _lib.CLAMP_PY, float('nan') if ymax is None else float(ymax),
+                0 if ex is None else len(ex), None if ex is None else _lib.dp(ex), float(exclude_radius), int(index_base),
+                ctypes.byref(bv), ctypes.byref(bi), ctypes.byref(gv), ctypes.byref(gi), _lib.dp(gx), ctypes.byref(gr)))
+            glob = dict(global_val=gv.value, global_idx=gi.value, global_x=gx, global_rank=gr.value)
         entry = _lib.lib.ibo_acq_sweep_incremental if incremental else _lib.lib.ibo_acq_sweep
-        _lib.check(entry(
-            h, M, cand.ptr, code, float(parm), _lib.ERF_LIBM if native else _lib.ERF_NR,
-            _lib.CLAMP_NATIVE if native else _lib.CLAMP_PY, float('nan') if ymax is None else float(ymax),
-            0 if ex is None else len(ex), None if ex is None else _lib.dp(ex), float(exclude_radius),
-            int(index_base), outs["mu"].ptr if "mu" in outs else None, outs["s2"].ptr if "s2" in outs else None,
-            outs["acq"].ptr if "acq" in outs else None, ctypes.byref(bv), ctypes.byref(bi)))
+        if exchange is None:
+            _lib.check(entry(
+                h, M, cand.ptr, code, float(parm), _lib.ERF_LIBM if native else _lib.ERF_NR,
+                _lib.CLAMP_NATIVE if native else _lib.CLAMP_PY, float('nan') if ymax is None else float(ymax),
+                0 if ex is None else len(ex), None if ex is None else _lib.dp(ex), float(exclude_radius),
+                int(index_base), outs["mu"].ptr if "mu" in outs else None, outs["s2"].ptr if "s2" in outs else None,
+                outs["acq"].ptr if "acq" in outs else None, ctypes.byref(bv), ctypes.byref(bi)))
     finally:
         if native:
             _lib.check(_lib.lib.ibo_gp_set_kstar_sf2(h, sf2_py))
     ms = ctypes.c_float(); name = ctypes.c_char_p()
     _lib.check(_lib.lib.ibo_last_sweep_kernel_ms(h, ctypes.byref(ms), ctypes.byref(name)))
     res = dict(best_val=bv.value, best_idx=bi.value, kernel_ms=ms.value, kernel=name.value.decode())
+    if glob is not None:
+        res.update(glob)
     for k, v in outs.items():
         res[k] = v.to_host()
     return res

@@ -245,17 +245,109 @@ __global__ __launch_bounds__(256) void cov_grid_kernel(const KParams *__restrict
     }
 }
 
+// The same pass with the exponent on the MFMA unit (round 6; north_star: "MFMA only for the dense K(X,X) / K(X,X*) GEMM-shaped blocks";
+// maths: ego/gaussianprocess/kernel.py:46-53,147-149, trainhyper.py:55).  As in the candidate sweep (sweep2_kernels.h), -z/2 of a pair is
+//     y_ij = a_i + a_j + x~_i . x~_j,   a_k = -|x~_k|^2 / 2,   x~ = x sqrt(w)  (the theta-point's scaling),
+// i.e. the product [x~_i | a_i | 1] [x~_j | 1 | a_j]^T: ceil((D + 2) / 4) fp64 MFMAs per 16 x 16 entries where the difference form spends
+// 2 D VALU instructions per entry (52 with its exp at D = 16: the kernel was bound by them, 1.45 ms per 64-theta grid against 0.9 ms for
+// its 4.3 GB of stores).  Same tiles and numbering as cov_grid_kernel (64 rows x 128 columns, four waves: wave w takes rows 16 w .. of all
+// eight column blocks, so a row's 1 KiB still leaves the workgroup together); the augmented rows are built in LDS with an odd stride
+// (conflict-free fragment reads); exp_fast / sqrt_fast as before.  |y|'s absolute error is ~|x~|^2 2^-52, hence the caller's guard
+// (|x~|^2 <= 1e5 for every row and every theta-point of the call: launch_cov_matrix_batched's `dot_ok`), beyond which the difference form runs.
+// The 64 x 64 diagonal blocks are written whole, as before; inside them K_ij and K_ji may differ in the last bit (the two a's enter the
+// sum in the other order) -- the factorisation reads the lower triangle only.
+template <int KA4>
+__global__ __launch_bounds__(256) void cov_grid_mfma_kernel(const KParams *__restrict__ kps, int n, const double *__restrict__ X, int ldp,
+                                                            double noise, double *__restrict__ K, int ldk, size_t kstride)
+{
+    constexpr int KA = 4 * KA4, LD = KA + 1;
+    __shared__ double As[64 * LD];                   // [x~ | a | 1 | 0 ..]
+    __shared__ double Bs[128 * LD];                  // [x~ | 1 | a | 0 ..]
+    const KParams &kp = kps[blockIdx.z];
+    K += blockIdx.z * kstride;
+    const int t = threadIdx.x, lane = t & 63, D = kp.D;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int q = blockIdx.x;
+    int a = (int)((sqrt(1.0 + 4.0 * (double)q) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) <= q) a++;
+    while (a * (a + 1) > q) a--;
+    const int rem = q - a * (a + 1);
+    const int I = 2 * a + rem / (a + 1), J = rem % (a + 1);
+    const int i0 = 64 * I, j0 = 128 * J;
+    if (i0 >= n) return;
+    for (int e = t; e < 64 * KA; e += 256) {
+        const int r = e / KA, d = e - r * KA;
+        As[r * LD + d] = (d < D && i0 + r < n) ? X[(size_t)(i0 + r) * ldp + d] * kp.sw[d] : 0.0;
+    }
+    for (int e = t; e < 128 * KA; e += 256) {
+        const int r = e / KA, d = e - r * KA;
+        Bs[r * LD + d] = (d < D && j0 + r < n) ? X[(size_t)(j0 + r) * ldp + d] * kp.sw[d] : 0.0;
+    }
+    __syncthreads();
+    if (t < 192) {                                   // the rows' -|x~|^2 / 2 and the constant 1, each where its operand wants it
+        double *row = t < 64 ? As + t * LD : Bs + (t - 64) * LD;
+        double n2 = 0.0;
+        for (int d = 0; d < D; d++) n2 = fma(row[d], row[d], n2);
+        row[D + (t < 64 ? 0 : 1)] = -0.5 * n2;
+        row[D + (t < 64 ? 1 : 0)] = 1.0;
+    }
+    __syncthreads();
+    const int fam = kp.family;
+    const double log_sf2 = log(kp.sf2), sf2 = kp.sf2;
+    double af[KA4];
+    {
+        const double *ap = As + (16 * wave + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < KA4; s++) af[s] = ap[4 * s];
+    }
+    const int ib = i0 + 16 * wave;                   // this wave's first row
+#pragma unroll 2
+    for (int cb = 0; cb < 8; cb++) {
+        const int jb = j0 + 16 * cb;
+        if (jb >= n || (jb >> 6) > (ib >> 6)) continue;          // beyond the data, or a 64 x 64 block right of the diagonal one (wave-uniform)
+        const double *bp = Bs + (16 * cb + (lane & 15)) * LD + (lane >> 4);
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KA4; s++) y = mfma_f64(af[s], bp[4 * s], y);
+        const int j = jb + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = ib + (lane >> 4) + 4 * r;
+            double v;
+            if (fam == FAM_SE) v = exp_fast(y[r] + log_sf2);
+            else {
+                const double z = fmax(-2.0 * y[r], 0.0);
+                const double rr = sqrt_fast((fam == FAM_M3 ? 3.0 : 5.0) * z);
+                const double poly = fam == FAM_M3 ? 1.0 + rr : fma(rr, fma(rr, 1.0 / 3.0, 1.0), 1.0);
+                v = sf2 * poly * exp_fast(-rr);
+            }
+            if (i == j) v = sf2 + noise;             // k(x, x) + noise, exactly
+            if (i < n && j < n) K[(size_t)i * ldk + j] = v;
+        }
+    }
+}
+
 // `batch` covariance matrices K(A1, A1) + noise I (the blocks on and below the diagonal), parameters kps_dev[z] (device), outputs kstride
-// doubles apart (ldp = the dimension: the points are handed over unpadded)
+// doubles apart (ldp = the dimension: the points are handed over unpadded).  dot_ok: every scaled point of every parameter set lies within
+// |x~|^2 <= 1e5 (the caller's bound) -- the exponent then comes from the MFMA unit, else from coordinate differences.
 int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const double *A1, int ldp, int diag_rule, double noise,
-                              double *K, int ldk, size_t kstride, hipStream_t s)
+                              double *K, int ldk, size_t kstride, hipStream_t s, int dot_ok)
 {
     if (diag_rule != 1) return (int)hipErrorInvalidValue;      // (IBO_DIAG_KERNEL_PLUS_NOISE: the likelihood's rule is the only one a grid has)
     const int nI = (n1 + 63) / 64;                   // tiles: sum over rows I of I / 2 + 1
     long ntile = 0;
     for (int I = 0; I < nI; I++) ntile += I / 2 + 1;
-    if (ldp <= 32) hipLaunchKernelGGL(cov_grid_kernel<33>, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
-    else hipLaunchKernelGGL(cov_grid_kernel<65>, dim3((unsigned)ntile, 1, batch), dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
+    const dim3 grid((unsigned)ntile, 1, batch);
+    if (dot_ok && ldp <= IBO_DDOT) {
+#define COV_MFMA(KA4) hipLaunchKernelGGL(cov_grid_mfma_kernel<KA4>, grid, dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride)
+        switch ((ldp + 2 + 3) / 4) {
+        case 1: COV_MFMA(1); break; case 2: COV_MFMA(2); break; case 3: COV_MFMA(3); break; case 4: COV_MFMA(4); break;
+        case 5: COV_MFMA(5); break; case 6: COV_MFMA(6); break; case 7: COV_MFMA(7); break; case 8: COV_MFMA(8); break;
+        default: COV_MFMA(9); break;
+        }
+#undef COV_MFMA
+    } else if (ldp <= 32) hipLaunchKernelGGL(cov_grid_kernel<33>, grid, dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
+    else hipLaunchKernelGGL(cov_grid_kernel<65>, grid, dim3(256), 0, s, kps_dev, n1, A1, ldp, noise, K, ldk, kstride);
     return (int)hipGetLastError();
 }
 

@@ -247,7 +247,7 @@ int launch_cov_matrix(const KParams &kp, int n1, const double *A1, int n2, const
 int launch_cov_fit(const KParams &kp, int n, const double *X, int ldp, int diag_rule, double noise, double *K2, int np2, double *Eye,
                    int *zero_word, hipStream_t s);          // the fit's own pass: working copy (lower blocks, identity pad), ride-along identity, info word
 int launch_cov_matrix_batched(const KParams *kps_dev, int batch, int n1, const double *A1, int ldp, int diag_rule, double noise,
-                              double *K, int ldk, size_t kstride, hipStream_t s);
+                              double *K, int ldk, size_t kstride, hipStream_t s, int dot_ok = 0);
 // factor the Npad x Npad matrix in L (lower part, ld = Npad) in place; diag64 receives the
 // inverses of the 64x64 diagonal blocks; info (device int) gets the 1-based failing pivot or 0
 // ws (optional): Npad * Npad doubles per matrix (wstride apart), the packed store of the packed-operand trailing update

@@ -60,6 +60,7 @@ def fill_slot(world_size, rank, val, idx, payload):
 
 class RcclArgmax(object):
     """slot protocol over RCCL/xGMI through libibo_hip (one communicator per process)"""
+    device_exchange = True        # sharded_sweep may hand the whole step to ibo_acq_sweep_exchange
 
     def __init__(self, world_size, rank, unique_id, device=None):
         self.world_size, self.rank = world_size, rank
@@ -279,6 +280,11 @@ def sharded_sweep(model, local_candidates, start, comm, **sweep_kw):
     Returns dict(best_val, best_idx (global), best_x, best_rank, kernel_ms)."""
     from .acquisition import sweep
     sweep_kw.pop('index_base', None)
+    if getattr(comm, "device_exchange", False) and isinstance(local_candidates, _lib.DeviceArray) and not sweep_kw.get("outputs"):
+        # RCCL: sweep and exchange in one device-side call -- the local arg-max never visits the host on its way into the all-reduce
+        r = sweep(model, local_candidates, index_base=start, exchange=comm, **sweep_kw)
+        return dict(best_val=r["global_val"], best_idx=r["global_idx"], best_x=r["global_x"], best_rank=r["global_rank"],
+                    kernel_ms=r["kernel_ms"], local=r)
     r = sweep(model, local_candidates, index_base=start, **sweep_kw)
     D = local_candidates.shape[1]
     if r["best_idx"] >= 0:

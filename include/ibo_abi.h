@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define IBO_ABI_VERSION 7   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info; 6: + ibo_sweep_state_levels;
-                             * 7: no new symbol -- ibo_set_option knows the keys listed below and nothing else: the experiment switches of rounds 2-4
+                             * 7: + ibo_gpu_time_ms, ibo_acq_sweep_exchange; option "arena_mb" -- ibo_set_option knows the keys listed below and nothing else: the experiment switches of rounds 2-4
                              * (nlml_groups, cov_fast, chol_fused, small_local, zero_copy, gallery_lazy, pipe_fit, .. -- about 35 keys) were removed in
                              * round 5 and now return IBO_ERR_ARG "unknown option", as does a NULL key; ibo_nlml_grid's covariance pass is the fast one */
 
@@ -84,10 +84,17 @@ int         ibo_device_name(int device, char *buf, size_t buflen);
 /* self-test of the fp64 MFMA fragment layout on the device (returns IBO_OK or
  * IBO_ERR_HIP with a message); cheap, used by smoke() */
 int         ibo_selftest_mfma(int device, double *max_abs_err);
-/* The ten option keys (everything else is decided by the data: sizes, dimensions, what the caller asks for).
+/* milliseconds of device time this process has measured with HIP events on `device` so far: fits and block extensions, candidate
+ * sweeps (the dominant kernel's span, as ibo_last_sweep_kernel_ms), likelihood grids (a batch's longest sub-batch span) and
+ * gradients.  DIRECT's small batches and the copies are not event-timed and not in it.  bench.py reports it as gpu_kernel_s_total
+ * so that a line can be related to an outside observer's busy-GPU samples. */
+int         ibo_gpu_time_ms(int device, double *ms);
+/* The eleven option keys (everything else is decided by the data: sizes, dimensions, what the caller asks for).
  * Functional:  "legacy_exact" 1/0 -- acqmaxGP in libego's operation order (default) or on the MFMA sweep kernels (see acqmaxGP);
  *   "nlml_batch" B -- matrices per batched factorisation in ibo_nlml_grid (0: as many as 12 GB hold; the values do not depend on it);
  *   "pool_limit_mb" n -- the per-device free list of recycled buffers (ibo_trim);
+ *   "arena_mb" n -- MiB per slab of the buffer arena (1024; 0: none): device buffers of up to half a slab are sub-allocated from slabs
+ *   taken from the device once, the first when the library first allocates there, so a new model finds warm memory (ibo_trim keeps the first);
  *   "fused2_min_nb" nb -- block columns (of 64 rows) from which a single matrix is factored in the two-level order (104; the order fixes the
  *   last bits of L and W -- one rule for ibo_gp_fit, the preference GP and ibo_nlml_grad).
  * Comparators kept for the tests (a second route to the same numbers):  "sweep_path" 0 auto (small2.hip's three kernels up to 4096
@@ -397,6 +404,19 @@ int ibo_comm_count(ibo_comm_t *comm, int *nranks);
 int ibo_comm_argmax(ibo_comm_t *comm, double val, int64_t idx,
                     const double *payload, int npayload,
                     double *best_val, int64_t *best_idx, double *best_payload, int *best_rank);
+/*
+ * The sharded sweep's step in ONE call: ibo_acq_sweep (incremental != 0: ibo_acq_sweep_incremental) over this rank's block of the
+ * candidate array (rows index_base ..), then the exchange above with the winner's D coordinates as payload -- the sweep's (value,
+ * index) never visit the host on the way: a kernel writes them and the coordinates into the rank's slot of the all-reduce buffer,
+ * ncclAllReduce runs on the sweep's stream, one copy into pinned memory brings back every rank's slot, one synchronisation.
+ * local_val / local_idx: this rank's own maximum (index -1 and -inf without an admissible candidate); best_* as ibo_comm_argmax,
+ * best_x: D doubles.  Replaces, per round, the candidate loop of ego/acquisition/gallery.py:93-134 cut over the ranks.
+ */
+int ibo_acq_sweep_exchange(ibo_gp_t *gp, ibo_comm_t *comm, int incremental, int64_t M, const double *cand_dev,
+                           int acq, double parm, int erf_mode, double clamp_lo, double ymax,
+                           int n_excl, const double *excl_host, double excl_radius, int64_t index_base,
+                           double *local_val, int64_t *local_idx,
+                           double *best_val, int64_t *best_idx, double *best_x, int *best_rank);
 /* in-place ncclAllReduce(sum) of a host buffer: gathers the sharded NLML grid (each rank fills
  * its own theta slots of a zero buffer) */
 int ibo_comm_allreduce_sum(ibo_comm_t *comm, double *host_buf, int64_t n);

@@ -1030,6 +1030,28 @@ def test_rccl_argmax_world_of_one(ibo):
     g1 = np.array(fastUCBGallery(GP, b, 4, candidates=cand))
     g2 = np.array(sharded_gallery(GP, b, 4, cand, 0, comm))
     np.testing.assert_array_equal(g1, g2)
+    # the one-call step (ibo_acq_sweep_exchange: the local arg-max goes from the sweep's output words into the all-reduce buffer on
+    # the device) against sweep-then-exchange through host values: every field equal, with exclusion balls, on a kept state
+    # (incremental), with an index base beyond 32 bits, and when every candidate is excluded (no admissible winner anywhere)
+    from ibo_amd import DeviceArray
+    from ibo_amd.multigpu import sharded_sweep
+    dc = DeviceArray.from_host(cand)
+    for kw in (dict(acq='ei', xi=.01, native=True), dict(acq='ei', xi=.4, native=False, exclude=cand[:3], exclude_radius=.3),
+               dict(acq='ucb', native=True, incremental=True), dict(acq='ei', xi=.4, native=False, exclude=np.full((1, 3), .5), exclude_radius=5.)):
+        fused = sharded_sweep(GP, dc, (1 << 40) + 7, comm, **kw)
+        comm.device_exchange = False
+        try:
+            plain = sharded_sweep(GP, dc, (1 << 40) + 7, comm, **kw)
+        finally:
+            del comm.device_exchange
+        assert fused["best_idx"] == plain["best_idx"] and fused["best_rank"] == plain["best_rank"], (kw, fused, plain)
+        if plain["best_idx"] >= 0:
+            assert fused["best_val"] == plain["best_val"] and fused["local"]["best_val"] == plain["local"]["best_val"]
+            np.testing.assert_array_equal(fused["best_x"], plain["best_x"])
+            np.testing.assert_array_equal(fused["best_x"], cand[fused["best_idx"] - (1 << 40) - 7])
+            assert fused["local"]["best_idx"] == plain["local"]["best_idx"]
+        else:
+            assert fused["local"]["best_idx"] == -1
     thetas = np.random.RandomState(53).rand(5, 3) + .2
     v1, a1 = nlml_grid(GaussianKernel_ard, thetas, X, Y)
     v2, a2 = sharded_nlml_grid(GaussianKernel_ard, thetas, X, Y, comm)
@@ -1389,6 +1411,45 @@ def test_nlml_grid_does_not_depend_on_what_shares_its_launches(ibo):
     finally:
         _lib.check(_lib.lib.ibo_set_option(b"nlml_batch", 0))
     assert np.all(np.isfinite(va)) and np.array_equal(va, vb)
+
+
+def test_grid_covariance_on_the_mfma_unit_against_the_oracle_and_the_difference_form(ibo, oracle):
+    """ibo_nlml_grid's covariance pass forms -z/2 = a_i + a_j + x~_i . x~_j as a product on the MFMA unit (csrc/assemble.hip
+    cov_grid_mfma_kernel; ego/gaussianprocess/kernel.py:46-53,147-149, trainhyper.py:55) where every scaled point stays inside the dot
+    form's guard, by coordinate differences elsewhere (ibo_set_option("dot_form", 0) forces those).  NLML values of both routes against
+    the oracle at 1e-9 and against each other at 1e-10: ragged sizes (a last tile of one row; rows that are not a multiple of 16, 64 or
+    128), 1 .. 30 dimensions (one to eight k4-steps of the exponent product), every covariance family; a theta-point with length scales so
+    short that the guard trips sends the whole call to the difference form (same values as forced)."""
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.gaussianprocess.trainhyper import nlml_grid, nlml_values
+
+    def both(kernels, X, Y, noise):
+        v = nlml_values(kernels, X, Y, noise)
+        _lib.check(_lib.lib.ibo_set_option(b"dot_form", 0))
+        try:
+            d = nlml_values(kernels, X, Y, noise)
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"dot_form", -1))
+        return np.asarray(v), np.asarray(d)
+    for N, D in ((65, 1), (193, 2), (500, 3), (1000, 6), (1345, 16), (777, 30)):
+        X, Y = synth(40 + N, N, D)
+        th = np.exp(np.random.RandomState(N).uniform(np.log(.3), np.log(2), size=(5, D))) * np.sqrt(D)
+        v, d = both([K.GaussianKernel_ard(t) for t in th], X, Y, 1e-2)
+        assert np.all(np.isfinite(v)) and np.abs(v - d).max() <= 1e-10 * np.abs(d).max(), (N, D, v, d)
+        ref = oracle.marginal_likelihood(oracle.Kern("ard", th[2]), X, Y, D, compute_gradient=False, noise=1e-2)
+        close(v[2], ref, rtol=1e-9); close(d[2], ref, rtol=1e-9)
+    X, Y = synth(41, 600, 4)
+    for kern, ok in ((K.MaternKernel3([.8, 1.1]), oracle.Kern("m3", [.8, 1.1])), (K.MaternKernel5([.9, 1.2]), oracle.Kern("m5", [.9, 1.2])),
+                     (K.SVGaussianKernel_iso([.7, 1.3]), oracle.Kern("sviso", [.7, 1.3])), (K.GaussianKernel_iso([.6]), oracle.Kern("iso", [.6]))):
+        v, d = both([kern], X, Y, 1e-2)
+        ref = oracle.marginal_likelihood(ok, X, Y, len(kern.hyperparams), compute_gradient=False, noise=1e-2)
+        close(v[0], ref, rtol=1e-9); close(d[0], ref, rtol=1e-9)
+        assert abs(v[0] - d[0]) <= 1e-10 * abs(d[0]), (type(kern).__name__, v, d)
+    # |x~|^2 beyond 1e5 for one theta-point of the call (length scale 1e-3 on coordinates up to 1): the guard keeps the difference form
+    th = np.array([[.5, .6, .7, .8], [1e-3, .6, .7, .8]])
+    v, d = both([K.GaussianKernel_ard(t) for t in th], X, Y, 1e-2)
+    assert np.array_equal(v, d)
 
 
 def test_left_looking_grid_equals_the_right_looking_one(ibo, oracle):
