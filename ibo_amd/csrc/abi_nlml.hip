@@ -126,7 +126,21 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
             while (G > 1 && nb / G < 8) G--;
             CholGroup grp[4];
             for (int g = 0; g < G; g++) {
-                if (!ws.streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ws.streams[g], hipStreamNonBlocking));
+                if (!ws.streams[g]) {
+                    // a sub-batch's stream must run BESIDE the others': a new stream may share a hardware queue with one of them
+                    // (assemble.hip: streams_run_side_by_side) -- then another is made, the rejected ones given back afterwards
+                    hipStream_t rejected[6];
+                    int nrej = 0;
+                    for (;;) {
+                        hipStream_t cand = nullptr;
+                        HIP_TRY(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+                        bool ok = true;
+                        for (int g2 = 0; g2 < g && ok; g2++) KERNEL_TRY(streams_run_side_by_side(ws.streams[g2], cand, &ok));
+                        if (ok || nrej == 6) { ws.streams[g] = cand; break; }
+                        rejected[nrej++] = cand;
+                    }
+                    for (int r = 0; r < nrej; r++) (void)hipStreamDestroy(rejected[r]);
+                }
                 if (!ws.t0[g]) { HIP_TRY(hipEventCreate(&ws.t0[g])); HIP_TRY(hipEventCreate(&ws.t1[g])); }
                 hipStream_t sg = ws.streams[g];
                 HIP_TRY(hipEventRecord(ws.t0[g], sg));

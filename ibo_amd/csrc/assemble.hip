@@ -1049,3 +1049,36 @@ int launch_mfma_selftest(double *out_err, hipStream_t s)
     hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, s, out_err);
     return (int)hipGetLastError();
 }
+
+// ---- do two streams run side by side?  HIP maps its streams onto a handful of hardware queues (four unless GPU_MAX_HW_QUEUES says
+// otherwise) and a stream created when all are taken shares one -- possibly with the very stream it is meant to run beside: the
+// likelihood grid's two sub-batch streams then take turns (measured: 29.7 instead of 27.5 ms per 64-theta grid, depending on nothing
+// but how many streams the process had created before).  No API names a stream's queue, so the pair is probed: a wave that sleeps
+// ~40 us on each stream, the span from the first's start to the second's end: one sleep when they overlap, two when they share a queue.
+__global__ void stream_probe_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();                   // (100 MHz)
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int streams_run_side_by_side(hipStream_t a, hipStream_t b, bool *yes)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 2 && e == hipSuccess; rep++) {      // (the first launch of a kernel pays its load)
+        e = hipEventRecord(e0, a);
+        hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(64), 0, a, 4000LL);
+        hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(64), 0, b, 4000LL);
+        if (e == hipSuccess) e = hipEventRecord(e1, b);
+        if (e == hipSuccess) e = hipStreamSynchronize(a);
+        if (e == hipSuccess) e = hipStreamSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    *yes = best < 0.065f;                                  // 40 us side by side, 80 one after the other
+    return (int)e;
+}

@@ -317,3 +317,4 @@ int launch_pref_build(const double *base, int N, int Npad, double diag, int nnz,
                       double *out, hipStream_t s);
 int launch_pref_sum(const double *R, const double *Cinv, int N, int Npad, double *A, hipStream_t s);
 int launch_mfma_selftest(double *out_err, hipStream_t s);
+int streams_run_side_by_side(hipStream_t a, hipStream_t b, bool *yes);      // a timing probe: do the two streams sit on different hardware queues?
