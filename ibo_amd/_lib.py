@@ -99,6 +99,7 @@ _sig("ibo_sweep_state_info", c_int, c_void_p, POINTER(c_int64), POINTER(c_int64)
 _sig("ibo_sweep_state_levels", c_int, c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int64))
 _sig("ibo_direct_max", c_int, c_void_p, c_int, _DP, _DP, c_int, c_double, c_int, c_double, c_int, c_int, c_int,
      c_int, _DP, _DP, POINTER(c_int64))
+_sig("ibo_direct_server_info", c_int, c_void_p, POINTER(c_int), POINTER(c_char_p))
 _sig("ibo_direct_host", c_int, OBJECTIVE, c_int, _DP, _DP, c_int, c_int, c_int, c_int, _DP, _DP, POINTER(c_int64))
 _sig("ibo_nlml_grid", c_int, c_int, c_int, c_int, c_int, _DP, _DP, c_int, _DP, c_int, _DP, c_double, _DP)
 _sig("ibo_nlml_grad", c_int, c_int, c_int, c_int, c_int, _DP, _DP, _DP, c_int, c_double, c_double, c_int,
@@ -123,7 +124,7 @@ EXPORTED = ["ibo_abi_version", "ibo_last_error", "ibo_device_count", "ibo_device
             "ibo_device_synchronize", "ibo_dev_generation", "ibo_gp_create", "ibo_gp_destroy", "ibo_gp_fit", "ibo_gp_fit_with_matrix",
             "ibo_gp_extend", "ibo_gp_reserve", "ibo_pref_begin", "ibo_pref_rinv_mul", "ibo_pref_newton_step", "ibo_pref_finish", "ibo_gp_set_y", "ibo_gp_set_kstar_sf2", "ibo_gp_set_prior", "ibo_gp_get_R", "ibo_gp_get_L",
             "ibo_gp_get_W", "ibo_gp_info", "ibo_gp_last_fit_ms", "ibo_cov_matrix", "ibo_spd_solve", "ibo_spd_inverse", "ibo_posterior_batch",
-            "ibo_acq_sweep", "ibo_acq_batch", "ibo_acq_sweep_incremental", "ibo_sweep_state_info", "ibo_sweep_state_levels", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_host", "ibo_nlml_grid", "ibo_nlml_grad",
+            "ibo_acq_sweep", "ibo_acq_batch", "ibo_acq_sweep_incremental", "ibo_sweep_state_info", "ibo_sweep_state_levels", "ibo_last_sweep_kernel_ms", "ibo_direct_max", "ibo_direct_server_info", "ibo_direct_host", "ibo_nlml_grid", "ibo_nlml_grad",
             "ibo_comm_get_unique_id", "ibo_comm_init", "ibo_comm_destroy", "ibo_comm_count", "ibo_comm_argmax", "ibo_comm_allreduce_sum", "ibo_acq_sweep_exchange", "ibo_comm_barrier",
             "acqmaxGP", "direct", "logCDFs"]
 

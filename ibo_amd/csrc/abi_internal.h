@@ -41,6 +41,7 @@ int ibo_fail(int code, const char *fmt, ...);
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
 // ---- option switches (abi_core.hip: ibo_set_option)
+extern std::atomic<int> g_direct_resident, g_direct_idle_ms;      // ibo_set_option("direct_resident", 0/1), ("direct_idle_ms", n)
 extern std::atomic<int> g_host_pipeline, g_fused2_min_nb, g_gallery_prune, g_nlml_batch, g_chol_left, g_dot_override, g_legacy_exact, g_force_path, g_nlml_groups;
 extern std::mutex g_dev_mu[16];             // serialises the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad / ibo_trim
 extern std::atomic<size_t> g_pool_limit;
@@ -125,6 +126,8 @@ struct ibo_gp {
     bool signal_pending = false;
     const double *alpha_tail_Y = nullptr, *alpha_tail_1 = nullptr; int alpha_tail_Np = 0;   // where the alpha vectors' zero tails are
     DevBuf<unsigned> done_count;
+    DevBuf<unsigned> srv_ctl;       // the resident evaluation server's control words (small2.hip: ServerCtl)
+    int srv_batches = 0; const char *srv_why = "";      // the last ibo_direct_max on this handle: batches the server evaluated; why it did not (all of them)
     // preference GP (ibo_pref_*): R^-1, the matrix being factored and its factors, vectors, sparse terms
     struct PrefWork {
         DevBuf<double> Rinv, A, Lh, E, Et, d64, vec, tmp, val;

@@ -449,6 +449,140 @@ extern "C" int ibo_acq_batch(ibo_gp_t *g, int64_t M, const double *Q_host, int a
 }
 
 // ------------------------------------------------------------------------ DIRECT on the GPU objective
+// The resident evaluation server's host side (small2.hip: direct_server_kernel): started for the lifetime of one direct_on_gp call where
+// the model and the acquisition admit it, fed through a mailbox in the handle's pinned staging, and -- whenever it is not there (not
+// started, not resident in time, left on a deadline, a batch larger than its mailbox) -- replaced by the launches of eval_host_points:
+// the same values bit for bit, so the search cannot tell.  Every host-side wait is bounded.
+static double mono_us()
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
+}
+struct DirectServer {
+    ibo_gp *g = nullptr;
+    bool active = false;
+    int Mmax = 0, D = 0;
+    unsigned long long seq = 0;
+    volatile unsigned long long *bx = nullptr;      // the mailbox's words: [0] seq, [1] M, [2] done, [3] state
+    double *cand = nullptr, *vals = nullptr;
+    int batches = 0;
+    const char *why = "";
+    unsigned long long *stamps = nullptr;
+    int stall_after = -1;
+    double t_post[64], t_seen[64];                  // host clock (us) when batch b was posted / seen finished (diagnostics)
+
+    int start(ibo_gp *gp, int acq, double parm, int erf_mode, double clamp_lo)
+    {
+        g = gp; D = g->D;
+        if (!g_direct_resident.load()) { why = "switched off"; return IBO_OK; }
+        if (g_force_path != 0 || !sweep2_fits(g->Npad)) { why = "model outside the small-batch kernels"; return IBO_OK; }
+        SweepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.kp = g->kp; a.N = g->N; a.Npad = g->Npad; a.DP = g->DP; a.M = 1;
+        a.Xs = g->Xs.p; a.ak = g->ak.p; a.XA = g->XA.p; a.log_sf2 = log(g->kp.sf2);
+        a.dot_form = (g_dot_override >= 0 && g->D <= IBO_DDOT) ? g_dot_override.load() : g->dot_form;
+        a.Xp = g->Xp.p; a.W = g->W.p; a.Wp = g->Wp.p; a.alphaY = g->alphaY.p; a.alpha1 = g->alpha1.p;
+        a.prior.nb = g->nb; a.prior.theta = g->ptheta; a.prior.means = g->pmeans.p; a.prior.beta = g->pbeta.p;
+        a.prior.lowerb = g->plowerb.p; a.prior.width = g->pwidth.p;
+        a.noise = g->noise; a.clamp_lo = clamp_lo; a.ymax = g->maxY; a.parm = parm; a.acq = acq; a.erf_mode = erf_mode;
+        if (!direct_server_takes(a)) { why = "dimension or form outside the server's instantiations"; return IBO_OK; }
+        Mmax = 2048;
+        const size_t box_doubles = IBO_SRV_BOX_CAND + (size_t)Mmax * D + Mmax;
+        IBO_TRY(ensure_pinned(g, box_doubles));
+        IBO_TRY(exp_table(g->device, &a.exp_tab));
+        IBO_TRY(g->small_ws.ensure(small_sweep_workspace(g->Npad, Mmax)));
+        const bool stamping = getenv("IBO_SRV_STAMPS") != nullptr;
+        if (const char *sa = getenv("IBO_SRV_STALL_AFTER")) stall_after = atoi(sa);
+        IBO_TRY(g->srv_ctl.ensure(IBO_SRV_CTL_BYTES / sizeof(unsigned) + (stamping ? 64 * 2 * 8 * 2 : 0)));
+        bx = (volatile unsigned long long *)g->pin;
+        cand = g->pin + IBO_SRV_BOX_CAND; vals = cand + (size_t)Mmax * D;
+        bx[0] = 0; bx[1] = 0; bx[2] = 0; bx[3] = 0;
+        a.cand = cand; a.out_acq = vals;
+        hipStream_t st = g->stream;
+        HIP_TRY(hipMemsetAsync(g->srv_ctl.p, 0, IBO_SRV_CTL_BYTES + (stamping ? 64 * 2 * 8 * 8 : 0), st));
+        stamps = stamping ? (unsigned long long *)(g->srv_ctl.p + IBO_SRV_CTL_BYTES / sizeof(unsigned)) : nullptr;
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->device));
+        if (ncu < 8) { why = "device too small"; return IBO_OK; }
+        KERNEL_TRY(launch_direct_server(a, g->srv_ctl.p, g->pin, g->small_ws.p, Mmax, ncu, g_direct_idle_ms.load(), st, stamps));
+        // resident?  (bounded: ~2 ms on the device side, 20 ms here -- the kernel may sit behind other work in the queue)
+        const double t0 = mono_us();
+        while (bx[3] == 0 && mono_us() - t0 < 20000.0) {}
+        if (bx[3] != IBO_SRV_READY) {
+            why = bx[3] == IBO_SRV_NOT_RESIDENT ? "not every workgroup became resident" : "no answer from the device";
+            __atomic_store_n((unsigned long long *)&bx[0], IBO_SRV_EXIT, __ATOMIC_RELEASE);
+            HIP_TRY(hipStreamSynchronize(st));
+            return IBO_OK;
+        }
+        active = true; seq = 0;
+        return IBO_OK;
+    }
+    // 0: done by the server; 1: not taken (the caller runs the batch by launches); else an error code
+    int eval(const double *pts, int n, double *out)
+    {
+        if (!active) return 1;
+        if (n > Mmax) { IBO_TRY(stop()); why = "a batch beyond the mailbox"; return 1; }
+        if (stall_after >= 0 && batches == stall_after) {
+            // (diagnostics, env IBO_SRV_STALL_AFTER=k: the host stops feeding after k batches for longer than the kernel's idle deadline --
+            // what a dead caller looks like from the device; tests/test_gpu_parity.py checks that the kernel has left and the call still ends right)
+            struct timespec ts = {0, (long)(g_direct_idle_ms.load() + 15) * 1000000L};
+            nanosleep(&ts, nullptr);
+        }
+        memcpy(cand, pts, sizeof(double) * (size_t)n * D);
+        bx[1] = (unsigned long long)n;
+        ++seq;
+        __atomic_store_n((unsigned long long *)&bx[0], seq, __ATOMIC_RELEASE);
+        const double t0 = mono_us();
+        if (stamps && seq <= 64) t_post[seq - 1] = t0;
+        for (int spin = 0;; spin++) {
+            if (bx[2] == seq) break;
+            if ((spin & 255) == 255 && (bx[3] != IBO_SRV_READY || mono_us() - t0 > 100000.0)) {
+                // the kernel left (its own deadline, an abort) or does not answer: wait it out -- it is bounded -- and go on by launches
+                active = false;
+                why = bx[3] != IBO_SRV_READY ? "the server left on a deadline" : "no answer to a batch within 100 ms";
+                __atomic_store_n((unsigned long long *)&bx[0], IBO_SRV_EXIT, __ATOMIC_RELEASE);
+                HIP_TRY(hipStreamSynchronize(g->stream));
+                if (bx[2] == seq) break;                 // (it did answer in the end)
+                return 1;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (stamps && seq <= 64) t_seen[seq - 1] = mono_us();
+        memcpy(out, vals, sizeof(double) * n);
+        batches++;
+        return 0;
+    }
+    int stop()
+    {
+        if (!active) return IBO_OK;
+        active = false;
+        __atomic_store_n((unsigned long long *)&bx[0], IBO_SRV_EXIT, __ATOMIC_RELEASE);
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (stamps) {
+            std::vector<unsigned long long> h(64 * 2 * 8);
+            HIP_TRY(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+            const int nb = batches < 64 ? batches : 64;
+            double acc[2][6] = {}, hostrt = 0.0, relay = 0.0;
+            for (int b = 1; b < nb; b++) {                // (batch 0 carries the start-up)
+                for (int w = 0; w < 2; w++)
+                    for (int k = 1; k < 6; k++) {
+                        const unsigned long long t0 = h[(b * 2 + w) * 8], tk = h[(b * 2 + w) * 8 + k];
+                        if (tk) acc[w][k] += (double)(tk - t0) * 0.01;
+                    }
+                hostrt += t_seen[b] - t_post[b];
+                relay += (double)(h[(b * 2 + 0) * 8] - h[(b * 2 + 0) * 8 + 6]) * 0.01;
+            }
+            const int n = nb > 1 ? nb - 1 : 1;
+            fprintf(stderr, "[libibo_hip] server stamps over %d batches (us after a workgroup saw the batch; wg 0 | last wg): phase-1 %.2f | %.2f  handover-1 %.2f | %.2f  "
+                            "phase-2 %.2f | %.2f  handover-2 %.2f | %.2f  finish %.2f | %.2f;  mailbox seen -> relayed and seen by wg 0's own loop %.2f;  host post -> done seen %.2f\n", n,
+                    acc[0][1] / n, acc[1][1] / n, acc[0][2] / n, acc[1][2] / n, acc[0][3] / n, acc[1][3] / n, acc[0][4] / n, acc[1][4] / n, acc[0][5] / n, acc[1][5] / n,
+                    relay / n, hostrt / n);
+        }
+        return IBO_OK;
+    }
+};
+
 int direct_on_gp(ibo_gp *g, int D, const double *lb, const double *ub, int acq, double parm, int erf_mode,
                         double clamp_lo, int maxiter, int maxtime, int maxsample, int compat,
                         double *opt, double *optx, int64_t *nsamples)
@@ -456,10 +590,13 @@ int direct_on_gp(ibo_gp *g, int D, const double *lb, const double *ub, int acq, 
     if (D != g->D) return fail(IBO_ERR_ARG, "bounds have %d dimensions, model has %d", D, g->D);
     const bool dbg = getenv("IBO_DEBUG") != nullptr;
     double t_eval = 0.0; int n_batches = 0; int64_t n_pts = 0;
+    DirectServer srv;
+    IBO_TRY(srv.start(g, acq, parm, erf_mode, clamp_lo));
     ibo::batch_eval_t ev = [&](const double *pts, int n, double *vals) -> int {
         struct timespec a0, a1;
         if (dbg) clock_gettime(CLOCK_MONOTONIC, &a0);
-        int rc = eval_host_points(g, n, pts, acq, parm, erf_mode, clamp_lo, nullptr, nullptr, vals);
+        int rc = srv.eval(pts, n, vals);
+        if (rc == 1) rc = eval_host_points(g, n, pts, acq, parm, erf_mode, clamp_lo, nullptr, nullptr, vals);
         if (dbg) { clock_gettime(CLOCK_MONOTONIC, &a1); t_eval += (a1.tv_sec - a0.tv_sec) * 1e3 + (a1.tv_nsec - a0.tv_nsec) * 1e-6; n_batches++; n_pts += n; }
         if (rc) return rc;
         for (int i = 0; i < n; i++) vals[i] = -vals[i];     // DIRECT minimises the negated acquisition
@@ -472,13 +609,26 @@ int direct_on_gp(ibo_gp *g, int D, const double *lb, const double *ub, int acq, 
     clock_gettime(CLOCK_MONOTONIC, &w0);
     ibo::DirectResult r = ibo::direct_minimize(ev, D, lb, ub, o);
     clock_gettime(CLOCK_MONOTONIC, &w1);
-    if (dbg) fprintf(stderr, "[libibo_hip] DIRECT: %d iterations, %lld samples, %d batches (%lld points): %.2f ms total, %.2f ms in GPU evaluation\n",
-                     r.iterations, (long long)r.nsamples, n_batches, (long long)n_pts,
+    const int src = srv.stop();
+    g->srv_batches = srv.batches; g->srv_why = srv.why;
+    if (dbg) fprintf(stderr, "[libibo_hip] DIRECT: %d iterations, %lld samples, %d batches (%lld points; %d by the resident server%s%s): %.2f ms total, %.2f ms in GPU evaluation\n",
+                     r.iterations, (long long)r.nsamples, n_batches, (long long)n_pts, srv.batches, srv.why[0] ? "; " : "", srv.why,
                      (w1.tv_sec - w0.tv_sec) * 1e3 + (w1.tv_nsec - w0.tv_nsec) * 1e-6, t_eval);
     if (r.status) return r.status;
+    if (src) return src;
     if (opt) *opt = -r.fmin;
     if (optx) for (int i = 0; i < D; i++) optx[i] = r.xmin[i];
     if (nsamples) *nsamples = r.nsamples;
+    return IBO_OK;
+}
+
+// what the resident evaluation server did in the last ibo_direct_max on this handle: the batches it evaluated, and -- when some
+// or all went through launches instead -- why ("" otherwise)
+extern "C" int ibo_direct_server_info(ibo_gp_t *g, int *batches, const char **why)
+{
+    if (!g) return fail(IBO_ERR_ARG, "gp is NULL");
+    if (batches) *batches = g->srv_batches;
+    if (why) *why = g->srv_why;
     return IBO_OK;
 }
 

@@ -237,7 +237,14 @@ bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);
 // small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
 int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
-size_t small_sweep_workspace(int Npad, int64_t M);      // its LDS budget holds both alpha vectors (N <= ~5000)
+size_t small_sweep_workspace(int Npad, int64_t M);
+// the resident evaluation server of ibo_direct_max (small2.hip): mailbox layout in doubles -- [0] seq, [1] M, [2] done, [3] state, [8 ..) candidates
+#define IBO_SRV_BOX_CAND 8
+#define IBO_SRV_EXIT 0xffffffffull
+enum { IBO_SRV_READY = 1, IBO_SRV_NOT_RESIDENT = 2, IBO_SRV_LEFT_ON_DEADLINE = 3, IBO_SRV_LEFT = 4 };
+#define IBO_SRV_CTL_BYTES 64
+bool direct_server_takes(const SweepArgs &a);
+int launch_direct_server(const SweepArgs &a, void *ctl, double *box, double *ws, int Mmax, int G, double idle_ms, hipStream_t s, unsigned long long *stamps = nullptr);      // its LDS budget holds both alpha vectors (N <= ~5000)
 int launch_pack_xa(const double *Xs, const double *ak, int N, int Npad, int DP, int D, double *XA, hipStream_t s);
 int launch_argmax_final(const SweepArgs &a, int64_t ntiles, hipStream_t s);
 

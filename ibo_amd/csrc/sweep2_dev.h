@@ -45,16 +45,19 @@ __device__ __forceinline__ double s2_exp(double y, const double *tab)
 
 // acquisition epilogue of one candidate; coordinates are read from global memory where needed (prior,
 // exclusion balls) so that no per-lane coordinate array exists (dynamic indexing would put it in scratch)
-__device__ __forceinline__ double s2_finish(const SweepArgs &a, const double *x, double q, double muY, double mu1,
+// SYS: the candidate's coordinates lie in host memory that a resident kernel sees change (server.hip): system-scope loads
+template <bool SYS = false>
+__device__ __forceinline__ double s2_finish(const SweepArgs &a, const double *xp, double q, double muY, double mu1,
                                             int64_t li, bool valid, bool &excluded)
 {
     const int D = a.kp.D;
+    auto X = [&](int j) { return SYS ? __hip_atomic_load(xp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : xp[j]; };
     double m = 0.0;
     if (a.prior.nb > 0) {
         for (int i = 0; i < a.prior.nb; i++) {
             double d = 0.0;
             for (int j = 0; j < D; j++) {
-                double t = (x[j] - a.prior.lowerb[j]) / a.prior.width[j] - a.prior.means[(size_t)i * D + j];
+                double t = (X(j) - a.prior.lowerb[j]) / a.prior.width[j] - a.prior.means[(size_t)i * D + j];
                 d += t * t;
             }
             m += a.prior.beta[i] * exp(-a.prior.theta * d);
@@ -68,13 +71,19 @@ __device__ __forceinline__ double s2_finish(const SweepArgs &a, const double *x,
     excluded = false;
     for (int e = 0; e < a.n_excl; e++) {
         double d2 = 0.0;
-        for (int j = 0; j < D; j++) { double t = x[j] - a.excl[(size_t)e * D + j]; d2 += t * t; }
+        for (int j = 0; j < D; j++) { double t = X(j) - a.excl[(size_t)e * D + j]; d2 += t * t; }
         if (!(sqrt(d2) > a.excl_radius)) excluded = true;
     }
     if (valid) {
-        if (a.out_mu) a.out_mu[li] = mu;
-        if (a.out_s2) a.out_s2[li] = s2;
-        if (a.out_acq) a.out_acq[li] = val;
+        if (SYS) {                                      // (a resident kernel has no launch boundary to flush its results to host memory)
+            if (a.out_mu) __hip_atomic_store(a.out_mu + li, mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.out_s2) __hip_atomic_store(a.out_s2 + li, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.out_acq) __hip_atomic_store(a.out_acq + li, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            if (a.out_mu) a.out_mu[li] = mu;
+            if (a.out_s2) a.out_s2[li] = s2;
+            if (a.out_acq) a.out_acq[li] = val;
+        }
     }
     return val;
 }
@@ -95,16 +104,18 @@ __device__ __forceinline__ double s2_kstar(double y, double sf2, const double *t
 // length scales from the origin (hence > 450 from every observation: |x~| <= 316 where the dot form is in use) has k* = 0
 // exactly; it is pulled in to that radius, where k* is still 0, so that the exponent stays within what s2_exp's integer
 // arithmetic covers (|y| < 7e5).  Called by the whole workgroup; ends with a barrier.
-template <int FAM, int TCAND, int KA, int NT>
-__device__ __forceinline__ void s2_stage_candidates(const SweepArgs &a, int64_t tile0, double *lds_c, const double *cand = nullptr)
+template <int FAM, int TCAND, int KA, int NT, bool SYS = false>
+__device__ __forceinline__ void s2_stage_candidates(const SweepArgs &a, int64_t tile0, double *lds_c, const double *cand = nullptr, int64_t Mo = -1)
 {
     const int tid = threadIdx.x, D = a.kp.D;
+    const int64_t Mtot = Mo >= 0 ? Mo : a.M;          // (a resident kernel's batches differ in size: the caller says)
     if (!cand) cand = a.cand;
     for (int e = tid; e < TCAND * KA; e += NT) {
         const int c = e / KA, col = e - c * KA;
         int64_t gi = tile0 + c;
-        if (gi > a.M - 1) gi = a.M - 1;
-        lds_c[c * (KA + 1) + col] = (col < D) ? cand[gi * D + col] * a.kp.sw[col] : (col == D ? 1.0 : 0.0);
+        if (gi > Mtot - 1) gi = Mtot - 1;
+        lds_c[c * (KA + 1) + col] = (col < D) ? (SYS ? __hip_atomic_load(cand + gi * D + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : cand[gi * D + col]) * a.kp.sw[col]
+                                              : (col == D ? 1.0 : 0.0);
     }
     __syncthreads();
     if (tid < TCAND) {

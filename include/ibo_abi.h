@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define IBO_ABI_VERSION 7   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info; 6: + ibo_sweep_state_levels;
-                             * 7: + ibo_gpu_time_ms, ibo_acq_sweep_exchange; option "arena_mb" -- ibo_set_option knows the keys listed below and nothing else: the experiment switches of rounds 2-4
+                             * 7: + ibo_gpu_time_ms, ibo_acq_sweep_exchange, ibo_direct_server_info; options "direct_resident", "direct_idle_ms", "arena_mb" -- ibo_set_option knows the keys listed below and nothing else: the experiment switches of rounds 2-4
                              * (nlml_groups, cov_fast, chol_fused, small_local, zero_copy, gallery_lazy, pipe_fit, .. -- about 35 keys) were removed in
                              * round 5 and now return IBO_ERR_ARG "unknown option", as does a NULL key; ibo_nlml_grid's covariance pass is the fast one */
 
@@ -89,12 +89,13 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * gradients.  DIRECT's small batches and the copies are not event-timed and not in it.  bench.py reports it as gpu_kernel_s_total
  * so that a line can be related to an outside observer's busy-GPU samples. */
 int         ibo_gpu_time_ms(int device, double *ms);
-/* The eleven option keys (everything else is decided by the data: sizes, dimensions, what the caller asks for).
+/* The thirteen option keys (everything else is decided by the data: sizes, dimensions, what the caller asks for).
  * Functional:  "legacy_exact" 1/0 -- acqmaxGP in libego's operation order (default) or on the MFMA sweep kernels (see acqmaxGP);
  *   "nlml_batch" B -- matrices per batched factorisation in ibo_nlml_grid (0: as many as 12 GB hold; the values do not depend on it);
  *   "pool_limit_mb" n -- the per-device free list of recycled buffers (ibo_trim);
  *   "arena_mb" n -- MiB per slab of the buffer arena (1024; 0: none): device buffers of up to half a slab are sub-allocated from slabs
  *   taken from the device once, the first when the library first allocates there, so a new model finds warm memory (ibo_trim keeps the first);
+ *   "direct_resident" 0/1, "direct_idle_ms" n -- ibo_direct_max's resident evaluation server (see ibo_direct_max; off);
  *   "fused2_min_nb" nb -- block columns (of 64 rows) from which a single matrix is factored in the two-level order (104; the order fixes the
  *   last bits of L and W -- one rule for ibo_gp_fit, the preference GP and ibo_nlml_grad).
  * Comparators kept for the tests (a second route to the same numbers):  "sweep_path" 0 auto (small2.hip's three kernels up to 4096
@@ -345,6 +346,13 @@ int ibo_direct_max(ibo_gp_t *gp, int D, const double *lb, const double *ub,
                    int acq, double parm, int erf_mode, double clamp_lo,
                    int maxiter, int maxtime, int maxsample, int compat,
                    double *opt, double *optx, int64_t *nsamples);
+/* ibo_set_option("direct_resident", 1): for the lifetime of one ibo_direct_max call a kernel stays resident on the chip (one workgroup per CU)
+ * and takes DIRECT's batches from a mailbox in pinned host memory instead of three launches per batch -- the same items on the same operands,
+ * the same values bit for bit.  Every wait is bounded on both sides ("direct_idle_ms", 20: the kernel leaves when its mailbox stays silent
+ * that long; not all workgroups resident within ~2 ms: it never starts; the host finishes the call by launches whenever the server is not there),
+ * so there is no hung-GPU mode.  OFF by default: measured slower than the launches (2.26 against 1.48 ms per maximizeEI at N = 1024;
+ * profiles/r06_direct_server_breakdown.txt).  ibo_direct_server_info: batches the server evaluated in the last call on this handle, and why not all. */
+int ibo_direct_server_info(ibo_gp_t *gp, int *batches, const char **why);
 
 /* DIRECT minimisation of a HOST callback with the reference's semantics
  * (cpp/direct.cpp:329; what ego.utils.optimize.cdirect wraps), plus the sample

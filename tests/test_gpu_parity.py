@@ -1007,6 +1007,79 @@ def test_direct_sample_counts_match_oracle(ibo, oracle):
     assert ns > 17 and x[0] == .5
 
 
+def _server_info(GP):
+    from ibo_amd import _lib
+    import ctypes
+    n = ctypes.c_int(); why = ctypes.c_char_p()
+    _lib.check(_lib.lib.ibo_direct_server_info(GP._handle(), ctypes.byref(n), ctypes.byref(why)))
+    return n.value, (why.value or b"").decode()
+
+
+def test_resident_evaluation_server_of_direct_max(ibo, oracle):
+    """ibo_set_option("direct_resident", 1): DIRECT's batches go to a kernel that stays on the chip for the call (csrc/small2.hip
+    direct_server_kernel; the objective of cpp/direct.cpp:372-498 behind ego/acquisition/__init__.py:174-197) instead of three launches
+    each.  Same (opt, optx) BIT FOR BIT as the launches -- small model (one hand-over), larger ones (two), Matern, a mean prior, PI and UCB,
+    eight and sixteen dimensions -- and against the oracle's maximiser; the server really took the batches; a model it does not take
+    (17 dimensions) goes by launches without a word.  BOUNDED WAITS: with the host silent after three batches for longer than the
+    kernel's idle deadline (IBO_SRV_STALL_AFTER, what a dead caller looks like from the device) the kernel has left, the call finishes by
+    launches, and the result is still the same."""
+    import os
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.gaussianprocess.prior import RBFNMeanPrior
+    from ibo_amd.acquisition import maximizeEI, maximizePI, maximizeUCB
+
+    def both(f, GP, *a, **kw):
+        out = []
+        for mode in (1, 0):
+            _lib.check(_lib.lib.ibo_set_option(b"direct_resident", mode))
+            try:
+                out.append(f(GP, *a, **kw))
+                out.append(_server_info(GP))
+            finally:
+                _lib.check(_lib.lib.ibo_set_option(b"direct_resident", 0))
+        (r1, i1, r0, i0) = out
+        assert r1[0] == r0[0] and np.array_equal(np.asarray(r1[1]), np.asarray(r0[1])), (r1, r0)
+        assert i0[0] == 0
+        return r1, i1
+    cases = [(60, 2, K.GaussianKernel_ard([.3, .3])), (500, 3, K.GaussianKernel_ard([.3] * 3)), (1024, 4, K.GaussianKernel_ard([.3] * 4)),
+             (1500, 8, K.MaternKernel5([.5, 1.0])), (700, 6, K.MaternKernel3([.6, 1.0])), (900, 16, K.GaussianKernel_ard([.9] * 16))]
+    for N, D, kern in cases:
+        X, Y = synth(70 + N, N, D)
+        GP = GaussianProcess(kern, X, Y, noise=.1)
+        b = [[0., 1.]] * D
+        r, info = both(maximizeEI, GP, b, maxiter=25)
+        assert info[0] >= 20 and info[1] == "", (N, D, info)
+    X, Y = synth(71, 300, 4)
+    ogp = oracle.GP(oracle.Kern("ard", [.3] * 4), X, Y, noise=.1)
+    GP = GaussianProcess(K.GaussianKernel_ard([.3] * 4), X, Y, noise=.1)
+    r, info = both(maximizeEI, GP, [[0., 1.]] * 4, maxiter=20)
+    o, ox, _ = oracle.acqmax_native(ogp, [[0., 1.]] * 4, oracle.ACQ_EI, .01, maxiter=20)
+    close(r[0], o, atol=1e-12); close(r[1], ox, rtol=1e-9, atol=1e-12)
+    both(maximizePI, GP, [[0., 1.]] * 4, maxiter=15); both(maximizeUCB, GP, [[0., 1.]] * 4, maxiter=15)
+    # a mean prior (its basis functions read the candidates again in the finish)
+    pr = RBFNMeanPrior(); pr.means = np.random.RandomState(5).rand(6, 4); pr.beta = np.random.RandomState(6).randn(6); pr.theta = 2.0
+    pr.lowerb = np.zeros(4); pr.width = np.ones(4)
+    GPp = GaussianProcess(K.GaussianKernel_ard([.3] * 4), X, Y, noise=.1, prior=pr)
+    r, info = both(maximizeEI, GPp, [[0., 1.]] * 4, maxiter=15)
+    assert info[0] > 0
+    # outside the server's instantiations: by launches, silently
+    X17, Y17 = synth(72, 200, 19)
+    GP17 = GaussianProcess(K.GaussianKernel_ard([1.2] * 19), X17, Y17, noise=.1)
+    r, info = both(maximizeEI, GP17, [[0., 1.]] * 19, maxiter=6)
+    assert info[0] == 0 and info[1] != ""
+    # the host falls silent in mid-call: the kernel leaves on its deadline, the call ends by launches with the same result
+    _lib.check(_lib.lib.ibo_set_option(b"direct_idle_ms", 5))
+    os.environ["IBO_SRV_STALL_AFTER"] = "3"
+    try:
+        r, info = both(maximizeEI, GP, [[0., 1.]] * 4, maxiter=20)
+    finally:
+        del os.environ["IBO_SRV_STALL_AFTER"]
+        _lib.check(_lib.lib.ibo_set_option(b"direct_idle_ms", 20))
+    assert info[0] == 3 and "deadline" in info[1], info
+
+
 def test_rccl_argmax_world_of_one(ibo):
     """the RCCL exchange itself (csrc/comm.hip) on the one GPU this box has"""
     from ibo_amd.multigpu import RcclArgmax
