@@ -30,6 +30,7 @@ std::atomic<int> g_chol_left{1};      // ibo_set_option("chol_left", 0/1): ibo_n
 std::atomic<int> g_dot_override{-1};  // ibo_set_option("dot_form", -1/0/1): -1 auto, 0/1 force the difference / dot form of k* (tests)
 std::atomic<int> g_legacy_exact{1};   // ibo_set_option("legacy_exact", 0/1): acqmaxGP evaluates libego's formulas in libego's operation order (legacy.hip)
 std::atomic<int> g_force_path{0};     // ibo_set_option("sweep_path"): 0 auto, 1 gemv, 2 mfma, 3 panel-split (IBO_SWEEP_IMPL env / tests)
+std::atomic<int> g_super_min_nb{kSuperFrom};   // ibo_set_option("super_min_nb", nb): single-matrix fits from nb block columns on run in super-panels (linalg.hip: launch_cholesky_super)
 std::atomic<int> g_direct_resident{0};  // ibo_set_option("direct_resident", 0/1): ibo_direct_max evaluates its batches on a resident kernel (small2.hip) instead of launches -- off: measured slower, DESIGN 4.4
 std::atomic<int> g_direct_idle_ms{20};  // ibo_set_option("direct_idle_ms", n): that kernel leaves when its mailbox stays silent this long
 std::atomic<int> g_nlml_groups{2};    // IBO_NLML_GROUPS=1..4 (env): a batch of theta-points runs as that many sub-batches, each on its own stream(s); values do not depend on it
@@ -304,6 +305,7 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (!strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
     if (!strcmp(key, "chol_left")) { g_chol_left = value; return IBO_OK; }
     if (!strcmp(key, "fused2_min_nb")) { if (value < 1) return fail(IBO_ERR_ARG, "fused2_min_nb < 1"); g_fused2_min_nb = value; return IBO_OK; }
+    if (!strcmp(key, "super_min_nb")) { if (value < 2 * kSuperPanel) return fail(IBO_ERR_ARG, "super_min_nb < %d", 2 * kSuperPanel); g_super_min_nb = value; return IBO_OK; }
     if (!strcmp(key, "direct_resident")) { g_direct_resident = value != 0; return IBO_OK; }
     if (!strcmp(key, "direct_idle_ms")) { if (value < 1 || value > 1000) return fail(IBO_ERR_ARG, "direct_idle_ms outside 1..1000"); g_direct_idle_ms = value; return IBO_OK; }
     if (!strcmp(key, "arena_mb")) { if (value < 0) return fail(IBO_ERR_ARG, "arena_mb < 0"); g_arena_mb = value; return IBO_OK; }
@@ -447,7 +449,7 @@ extern "C" int ibo_gp_destroy(ibo_gp_t *g)
     g->tmp.release(); g->cand.release(); g->outs.release(); g->excl.release(); g->qpart.release();
     g->mupart.release(); g->partv.release(); g->res_v.release(); g->parti.release(); g->res_i.release(); g->state.release(); g->small_ws.release();
     g->tile_done.release(); g->tile_ub.release(); g->part_words.release(); g->tile_rows.release(); g->tile_sel.release();
-    g->done_count.release(); g->srv_ctl.release();
+    g->done_count.release(); g->srv_ctl.release(); g->tall.release(); g->Pk2.release();
     g->pw.Rinv.release(); g->pw.A.release(); g->pw.Lh.release(); g->pw.E.release(); g->pw.Et.release(); g->pw.d64.release();
     g->pw.vec.release(); g->pw.tmp.release(); g->pw.val.release(); g->pw.lin.release(); g->pw.info.release();
     g->info.release(); g->pmeans.release(); g->pbeta.release(); g->plowerb.release(); g->pwidth.release();

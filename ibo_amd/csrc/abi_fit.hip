@@ -122,13 +122,20 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
     HIP_TRY(hipEventRecord(g->fit0, s));
     // R, and in the same pass the identity-padded copy the factorisation works on
     const bool fused = single_level_order(Np);                   // (else the two-level order; both out of place: the matrix in T, the factor into L)
-    double *work = g->T.p;                                       // T is free until launch_trinv uses it as scratch
+    // from g_super_min_nb block columns on the single-level order runs in super-panels: the matrix and the ride-along's identity are the two
+    // halves of ONE tall buffer (launch_cholesky_super), T and W are outputs only
+    const bool super = super_order(Np);
+    if (super) {
+        IBO_TRY(g->tall.ensure(2 * (size_t)Np * Np)); IBO_TRY(g->Pk2.ensure(2 * (size_t)Np * Np));
+    }
+    double *work = super ? g->tall.p : g->T.p;                   // T is free until launch_trinv uses it as scratch
+    double *eye = super ? g->tall.p + (size_t)Np * Np : g->W.p;
     // (with the working copy the same pass writes the identity the ride-along starts from and clears the info word)
     const bool one_pass = fused && !A_host;
     // (GP.R itself is not written here: 33 MB of stores at N = 2048 that only ibo_gp_get_R and ibo_pref_finish read -- ensure_R;
     // stage_data marked it stale)
     if (!A_host)
-        KERNEL_TRY(launch_cov_fit(kp, N, g->Xp.p, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, work, Np, one_pass ? g->W.p : nullptr, g->info.p, s));
+        KERNEL_TRY(launch_cov_fit(kp, N, g->Xp.p, g->DP, IBO_DIAG_UNIT_PLUS_NOISE, noise, work, Np, one_pass ? eye : nullptr, g->info.p, s));
     else {
         HIP_TRY(hipMemsetAsync(g->info.p, 0, sizeof(int), s));
         KERNEL_TRY(launch_pad_copy(g->A.p, N, N, work, Np, 1.0, s));
@@ -137,8 +144,9 @@ static int fit_factor(ibo_gp *g, const KParams &kp, int N, double noise, bool ha
         // the plain right-looking order: one launch per block column, out of place, with W = L^-1 riding along (E = I in W's buffer
         // turns into (L^-1)^T in Wp's, which is transposed into W and packed into T's buffer -- free by then -- in one pass; T and
         // Wp then trade places)
-        if (!one_pass) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, g->W.p, Np, 1.0, s));       // identity
-        KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s, g->W.p, g->Wp.p, true));
+        if (!one_pass) KERNEL_TRY(launch_pad_copy(g->Xp.p, 0, 1, eye, Np, 1.0, s));       // identity
+        if (super) KERNEL_TRY(launch_cholesky_super(g->tall.p, g->L.p, Np, g->diag64.p, g->info.p, s, g->Wp.p, g->Pk2.p, true));
+        else KERNEL_TRY(launch_cholesky_fused(g->T.p, g->L.p, Np, g->diag64.p, g->info.p, s, g->W.p, g->Wp.p, true));
         KERNEL_TRY(launch_transpose_pack(g->Wp.p, N, Np, g->W.p, g->T.p, s));
         std::swap(g->T, g->Wp);
     } else {

@@ -41,6 +41,7 @@ int ibo_fail(int code, const char *fmt, ...);
 #define IBO_TRY(expr) do { int s_ = (expr); if (s_ != IBO_OK) return s_; } while (0)
 
 // ---- option switches (abi_core.hip: ibo_set_option)
+extern std::atomic<int> g_super_min_nb;        // ibo_set_option("super_min_nb", nb): block columns from which a fit runs in super-panels
 extern std::atomic<int> g_direct_resident, g_direct_idle_ms;      // ibo_set_option("direct_resident", 0/1), ("direct_idle_ms", n)
 extern std::atomic<int> g_host_pipeline, g_fused2_min_nb, g_gallery_prune, g_nlml_batch, g_chol_left, g_dot_override, g_legacy_exact, g_force_path, g_nlml_groups;
 extern std::mutex g_dev_mu[16];             // serialises the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad / ibo_trim
@@ -126,6 +127,8 @@ struct ibo_gp {
     bool signal_pending = false;
     const double *alpha_tail_Y = nullptr, *alpha_tail_1 = nullptr; int alpha_tail_Np = 0;   // where the alpha vectors' zero tails are
     DevBuf<unsigned> done_count;
+    // fits from g_super_min_nb block columns on (launch_cholesky_super): [A ; E] in one tall buffer, the packed store of [L ; E^T-in-progress]
+    DevBuf<double> tall, Pk2;
     DevBuf<unsigned> srv_ctl;       // the resident evaluation server's control words (small2.hip: ServerCtl)
     int srv_batches = 0; const char *srv_why = "";      // the last ibo_direct_max on this handle: batches the server evaluated; why it did not (all of them)
     // preference GP (ibo_pref_*): R^-1, the matrix being factored and its factors, vectors, sparse terms
@@ -148,6 +151,8 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // single-level order wins up to there (N = 4096: 2.49 -> 2.07 ms; 6400 rows: 6.20 against 6.50; 7040: 8.18 against 7.70).  ONE predicate for
 // ibo_gp_fit, the preference GP's factorisations and ibo_nlml_grad: the order fixes the last bits of L and W.
 static inline bool single_level_order(int Np) { return Np / 64 < g_fused2_min_nb; }
+
+static inline bool super_order(int Np) { return single_level_order(Np) && Np / 64 >= g_super_min_nb; }
 
 // ---- helpers one unit lends another
 int ibo_comm_exchange_dev(ibo_comm_t *c, hipStream_t s, const double *res_v, const int64_t *res_i, const double *cand_dev, int D, int64_t index_base,

@@ -15,7 +15,7 @@ struct NlmlWorkspace {
 static NlmlWorkspace g_nlml_ws[16];
 static const int kSyrk3From = 2560;          // rows from which ibo_nlml_grad forms K^-1 = W^T W on the packed-operand kernel (launch_syrk3)
 struct GradWorkspace {
-    DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout, dpiece;
+    DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout, dpiece, tall, Pk2;     // tall, Pk2: the super-panel order's (launch_cholesky_super)
     DevBuf<int> dinfo, dtasks, dsums;
     int plan_Np = 0, ntasks = 0, nsums = 0;         // launch_syrk3's lists on the device, for this Npad
     hipEvent_t t0 = nullptr, t1 = nullptr;          // the evaluation's span on the device (ibo_gpu_time_ms)
@@ -36,7 +36,7 @@ extern "C" int ibo_trim(int device)
     GradWorkspace &gw = g_grad_ws[device & 15];
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
     gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
-    gw.dpiece.release(); gw.dtasks.release(); gw.dsums.release(); gw.plan_Np = 0;
+    gw.dpiece.release(); gw.dtasks.release(); gw.dsums.release(); gw.plan_Np = 0; gw.tall.release(); gw.Pk2.release();
     pool_trim(device);
     return IBO_OK;
 }
@@ -228,7 +228,12 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     const bool fused = single_level_order(Np);
     if (!ws.t0) { HIP_TRY(hipEventCreate(&ws.t0)); HIP_TRY(hipEventCreate(&ws.t1)); }
     HIP_TRY(hipEventRecord(ws.t0, s));
-    if (fused) {
+    if (fused && super_order(Np)) {
+        // (the fit's rule: from g_super_min_nb block columns on in super-panels -- the matrix and the ride-along's identity in one tall buffer; same bits)
+        IBO_TRY(ws.tall.ensure(2 * nn)); IBO_TRY(ws.Pk2.ensure(2 * nn));
+        KERNEL_TRY(launch_cov_fit(kp, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, ws.tall.p, Np, ws.tall.p + nn, dinfo.p, s));
+        KERNEL_TRY(launch_cholesky_super(ws.tall.p, dL.p, Np, d64.p, dinfo.p, s, dKi.p, ws.Pk2.p, true));
+    } else if (fused) {
         KERNEL_TRY(launch_cov_fit(kp, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dT.p, Np, dW.p, dinfo.p, s));
         KERNEL_TRY(launch_cholesky_fused(dT.p, dL.p, Np, d64.p, dinfo.p, s, dW.p, dKi.p, true));
     } else {

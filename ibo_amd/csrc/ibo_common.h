@@ -273,6 +273,7 @@ int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad,
                                  int nfactor = 0, int rm_from = 0);
 int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batch, size_t lstride, double *Pk, size_t pstride,
                       hipStream_t s);
+int launch_chol_pack3e(const double *E, int Npad, int rend, int c0, int K, double *PkE, hipStream_t s);
 int launch_chol_update3(double *L, int Npad, int c0, int width, int nlive, int batch, size_t lstride, const double *Pk,
                         size_t pstride, hipStream_t s);
 // the same kernel on any region that starts on the diagonal (rows >= c0, columns [c0, c0 + width)) and any range [kbeg, kend) of packed columns
@@ -289,6 +290,14 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
 // the two-level order (panels of P block columns) out of place, one fused launch per block column inside a panel
 int launch_cholesky_fused2(double *work, double *out, int Npad, double *diag64, int *info_dev, int P, hipStream_t s,
                            bool info_is_zero = false, double *ws = nullptr);
+// the single-level order in SUPER-PANELS (linalg.hip): the pipelined launches keep their trailing tiles inside a super-panel of 16 block
+// columns; the columns beyond take a finished super-panel's steps as ONE deep update from packed operands (update3.hip).  tall: [A ; E] in
+// one buffer (2 Npad x Npad: the matrix being reduced, then the ride-along's identity); Pk: 2 Npad^2 doubles (the packed store of
+// [out ; Eout]).  Same bits as launch_cholesky_fused.
+static const int kSuperFrom = 64;       // block columns (4096 rows) from which it is the faster one (3840 rows: 1.85 against 1.77 ms; 4096: 2.04 / 2.10; 5000: 3.18 / 3.48)
+static const int kSuperPanel = 16;
+int launch_cholesky_super(double *tall, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s, double *Eout, double *Pk,
+                          bool info_is_zero = false);
 int launch_transpose_lower(const double *Et, double *W, int Npad, hipStream_t s);
 // W = Et^T (lower, rows >= N zero) and its MFMA-fragment-order copy Wp (another buffer than Et) in one pass
 int launch_transpose_pack(const double *Et, int N, int Npad, double *W, double *Wp, hipStream_t s);

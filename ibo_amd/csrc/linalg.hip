@@ -1583,6 +1583,70 @@ int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, i
     return (int)hipGetLastError();
 }
 
+// ---- The single-level order in SUPER-PANELS (round 6; fits from kSuperFrom block columns on, with the ride-along).
+// Plain right-looking, every trailing tile makes a round trip through the fabric per two steps: at N = 4096 the tiles, not the chain, are
+// what a block column costs (8.8 us of CU time per pair tile, fabric-side traffic 13.7 x the algorithmic bytes).  Here the
+// pipelined launches (chol_pipe8_kernel<1>, unchanged) keep their tiles inside a super-panel of kSuperPanel block columns -- the rows are
+// all there, matrix and E alike --, and after a super-panel the columns beyond it take its sixteen steps in ONE deep pass (K = 1024) from
+// packed operands on chol_update3_kernel: [A ; E] is one tall matrix (2 Npad rows), its packed store [out ; Eout] likewise, so E's tiles are
+// simply the tall matrix's rows beyond Npad -- rows of E from which nothing can come yet (>= 64 c1) are not live, and Eout's never-written
+// blocks left of a row's diagonal are packed as zeros.  A column still receives its steps in ascending order, each super-panel's as one
+// ascending K loop with accumulators that start as -C (C = -acc): L and W are BIT-IDENTICAL to the step-by-step order (tested), so the
+// switch is a matter of speed only -- 2.04 against 2.10 ms at N = 4096, 3.18 / 3.48 at 5000, 4.83 / 5.56 at 6144; slower below 4096 rows.
+// Where the time goes at N = 4096 (profiles/r06_fit4096_super_timeline.txt): the 64 pipelined launches 1160 us (17-18 us each: the chain),
+// three deep updates 263 + 254 + 140 us (58 TFLOP/s where the chip is full: 492 tiles; 392 tiles leave half the CUs with one workgroup and
+// last as long; 228 are one round of one per CU), packing 48, covariance 39,
+// transpose + alpha 125.  Measured and not kept: the later super-panels' part of an update on a second stream beside the next chain (its
+// 64 KB workgroups hold the CUs the chain's 133 KB workgroups need: the next super-panel's first launch waits for them, 2.07 ms), panels
+// of 8 / 24 / 32 block columns (2.21 / 2.08 / 2.17 ms).
+static void pipe8_launch_in_panel(double *work, double *out, int Npad, int jb, int c0, int c1, int &split, double *diag64, int *info_dev, hipStream_t s,
+                                  double *Ework, double *Eout)
+{
+    const int nb = Npad / 64;
+    const int m = nb - jb - 1, nE = jb + 1;
+    const int nrow = m + nE + 1;
+    int nsingle = 0, q = 0, c_lo = 0, c_hi = 0;
+    if (jb & 1) {
+        if (jb + 1 < c1) nsingle = m + jb;                     // step jb - 1 on column jb + 1 (the next super-panel's first column takes it deep)
+        if (jb >= c0 + 3) { q = jb - 2; c_lo = split < c1 ? split : c1; c_hi = c1; }
+    } else if (jb >= c0 + 2) {
+        q = jb - 1;
+        long total = 0, run = 0;
+        for (int k = jb + 1; k < c1; k++) total += (nb - k) + (q + 1);
+        const long later = jb + 2 < c1 ? (nb - jb - 2) + (jb + 1) : 0;
+        split = jb + 1;
+        while (split < c1 && (split < jb + 3 || 2 * run < total + later)) { run += (nb - split) + (q + 1); split++; }
+        c_lo = jb + 1; c_hi = split;
+    } else split = c1;                                         // a super-panel's first launch: no pair is due yet
+    long npair = 0;
+    for (int k = c_lo; k < c_hi; k++) npair += (nb - k) + (q + 1);
+    hipLaunchKernelGGL(chol_pipe8_kernel<1>, dim3(nrow + nsingle + (int)npair), dim3(512), 0, s, work, out, Npad, jb, diag64, info_dev,
+                       nrow, Ework, Eout, nb, jb > c0 ? 1 : 0, nsingle, q, c_lo, c_hi);
+}
+
+int launch_cholesky_super(double *tall, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s, double *Eout, double *Pk,
+                          bool info_is_zero)
+{
+    const int S = kSuperPanel, nb = Npad / 64;
+    const size_t nn = (size_t)Npad * Npad;
+    double *work = tall, *Ework = tall + nn, *PkE = Pk + nn;
+    if (!info_is_zero) HIPCHK(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    for (int c0 = 0; c0 < nb; c0 += S) {
+        const int c1 = c0 + S < nb ? c0 + S : nb;
+        int split = c1;
+        for (int jb = c0; jb < c1; jb++) pipe8_launch_in_panel(work, out, Npad, jb, c0, c1, split, diag64, info_dev, s, Ework, Eout);
+        if (c1 >= nb) break;
+        // the finished columns in fragment order (the matrix's rows below the super-panel, E's rows 0 .. 64 c1), then every later column's update
+        int rc = launch_chol_pack3(out, Npad, 64 * c1, 64 * c0, 64 * (c1 - c0), 1, 0, Pk, 0, s);
+        if (rc) return rc;
+        rc = launch_chol_pack3e(Eout, Npad, 64 * c1, 64 * c0, 64 * (c1 - c0), PkE, s);
+        if (rc) return rc;
+        rc = launch_chol_update3_range(tall, Npad, 64 * c1, 64 * (nb - c1), 64 * c0, 64 * c1, Npad + 64 * c1, 1, 0, Pk, 0, s);
+        if (rc) return rc;
+    }
+    return (int)hipGetLastError();
+}
+
 // The same out-of-place scheme in the TWO-LEVEL order (panels of P block columns; one matrix of >= 104 blocks): inside a panel every
 // block column is one chol_step8_kernel launch over the tiles (i, k), jb < k < pend, k <= i < nb, instead of the diagonal / row-block /
 // update launches (21.4 -> 18.5 us per column at N = 4096); a panel's last column has nothing to update inside the panel and keeps its

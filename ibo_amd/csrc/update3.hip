@@ -59,6 +59,29 @@ __global__ __launch_bounds__(256) void chol_pack3_kernel(const double *__restric
     Pk[((((size_t)(row >> 4) * (Npad >> 3) + (col >> 3)) * 64 + lane) << 1) + h] = v;
 }
 
+// The ride-along's finished block columns [c0, c0 + K) of E^T-in-progress (Eout: row block i holds X_ij for j >= i and was never written left
+// of its diagonal block) into the second half of a tall packed store: rows [0, rend), exact zeros where the block column lies left of the row's
+// diagonal block -- a tall update's K range then needs no per-row start
+__global__ __launch_bounds__(256) void chol_pack3e_kernel(const double *__restrict__ E, int Npad, int rend, int c0, int K, double *__restrict__ PkE)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)rend * K;
+    if (e >= total) return;
+    const int h = (int)(e & 1), lane = (int)((e >> 1) & 63), nk8 = K >> 3;
+    const size_t gj = e >> 7;
+    const int j = (int)(gj % nk8), g = (int)(gj / nk8);
+    const int row = 16 * g + (lane & 15), col = c0 + 8 * j + 4 * h + (lane >> 4);
+    const double v = (col >> 6) >= (row >> 6) ? E[(size_t)row * Npad + col] : 0.0;
+    PkE[((((size_t)(row >> 4) * (Npad >> 3) + (col >> 3)) * 64 + lane) << 1) + h] = v;
+}
+int launch_chol_pack3e(const double *E, int Npad, int rend, int c0, int K, double *PkE, hipStream_t s)
+{
+    if (rend <= 0 || K <= 0) return 0;
+    const size_t total = (size_t)rend * K;
+    hipLaunchKernelGGL(chol_pack3e_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, E, Npad, rend, c0, K, PkE);
+    return (int)hipGetLastError();
+}
+
 // The single live row-block below the last full 128-row tile (the likelihood's y row: 1 live row, 15 of pad) against ALL of
 // the panel's column-blocks, one workgroup per matrix: wave w takes column-blocks 2 w and 2 w + 1 -- per k8-step one A and two
 // B fragments straight from the packed store (no LDS, no barrier), four MFMAs -- with the loads eight steps ahead (a wave
@@ -151,7 +174,9 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
     const int gB = (c0 + 128 * J) >> 4;                          // first of the tile's eight column-blocks, as row-blocks of the panel
     const int cb0 = 8 * J + 4 * wc;                              // this wave's first column-block inside the panel
     const int nk8s = Npad >> 3;                                  // k8-steps per row-block of the packed store
-    const size_t pbytes = (size_t)Npad * Npad * sizeof(double);
+    // (the packed store has Npad rows -- or, under the fit's ride-along, the 16 nlive_rb > Npad rows of the TALL matrix [A ; E], whose second
+    // half packs E's finished columns: launch_cholesky_super)
+    const size_t pbytes = (size_t)(16 * nlive_rb > Npad ? 16 * nlive_rb : Npad) * Npad * sizeof(double);
     const __amdgpu_buffer_rsrc_t rP = u3_rsrc(Pk, pbytes);
     const unsigned lane16 = lane * 16;
     // which of this wave's blocks exist: live rows only, the panel's columns only.  A wave with nothing to do runs the same

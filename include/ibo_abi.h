@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define IBO_ABI_VERSION 7   /* 2: + ibo_gp_extend, ibo_comm_count; 3: + ibo_pref_*; 4: + ibo_dev_generation; 5: + ibo_sweep_state_info; 6: + ibo_sweep_state_levels;
-                             * 7: + ibo_gpu_time_ms, ibo_acq_sweep_exchange, ibo_direct_server_info; options "direct_resident", "direct_idle_ms", "arena_mb" -- ibo_set_option knows the keys listed below and nothing else: the experiment switches of rounds 2-4
+                             * 7: + ibo_gpu_time_ms, ibo_acq_sweep_exchange, ibo_direct_server_info; options "super_min_nb", "direct_resident", "direct_idle_ms", "arena_mb" -- ibo_set_option knows the keys listed below and nothing else: the experiment switches of rounds 2-4
                              * (nlml_groups, cov_fast, chol_fused, small_local, zero_copy, gallery_lazy, pipe_fit, .. -- about 35 keys) were removed in
                              * round 5 and now return IBO_ERR_ARG "unknown option", as does a NULL key; ibo_nlml_grid's covariance pass is the fast one */
 
@@ -89,12 +89,14 @@ int         ibo_selftest_mfma(int device, double *max_abs_err);
  * gradients.  DIRECT's small batches and the copies are not event-timed and not in it.  bench.py reports it as gpu_kernel_s_total
  * so that a line can be related to an outside observer's busy-GPU samples. */
 int         ibo_gpu_time_ms(int device, double *ms);
-/* The thirteen option keys (everything else is decided by the data: sizes, dimensions, what the caller asks for).
+/* The fourteen option keys (everything else is decided by the data: sizes, dimensions, what the caller asks for).
  * Functional:  "legacy_exact" 1/0 -- acqmaxGP in libego's operation order (default) or on the MFMA sweep kernels (see acqmaxGP);
  *   "nlml_batch" B -- matrices per batched factorisation in ibo_nlml_grid (0: as many as 12 GB hold; the values do not depend on it);
  *   "pool_limit_mb" n -- the per-device free list of recycled buffers (ibo_trim);
  *   "arena_mb" n -- MiB per slab of the buffer arena (1024; 0: none): device buffers of up to half a slab are sub-allocated from slabs
  *   taken from the device once, the first when the library first allocates there, so a new model finds warm memory (ibo_trim keeps the first);
+ *   "super_min_nb" nb -- block columns from which a single-level factorisation runs in super-panels of 16 (64; linalg.hip launch_cholesky_super:
+ *   the columns beyond a super-panel take its steps as one deep update from packed operands -- the same bits, a matter of speed only);
  *   "direct_resident" 0/1, "direct_idle_ms" n -- ibo_direct_max's resident evaluation server (see ibo_direct_max; off);
  *   "fused2_min_nb" nb -- block columns (of 64 rows) from which a single matrix is factored in the two-level order (104; the order fixes the
  *   last bits of L and W -- one rule for ibo_gp_fit, the preference GP and ibo_nlml_grad).

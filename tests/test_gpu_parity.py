@@ -1379,6 +1379,54 @@ def test_two_level_order_agrees_with_the_single_level_order(ibo):
     assert np.abs(W[probe].dot(L) - np.eye(N)[probe]).max() < 1e-10 and np.all(np.triu(W, 1) == 0.0)
 
 
+def test_super_panel_order_has_the_bits_of_the_step_by_step_order(ibo):
+    """From 64 block columns (4096 rows) a single-level factorisation runs in super-panels of 16 block columns (csrc/linalg.hip
+    launch_cholesky_super: the pipelined launches keep their tiles inside a super-panel, the columns beyond take its sixteen steps as one deep
+    update from packed operands, E riding along as the lower half of one tall matrix; linalg.cholesky of ego/gaussianprocess/__init__.py:299,
+    the inverse of ego/acquisition/__init__.py:385-388).  ibo_set_option("super_min_nb") moves the switch: L and W of both orders are
+    BIT-IDENTICAL -- two, three and four super-panels, a last one of 2, 15 and 16 block columns -- and agree with NumPy; the NLML gradient, which
+    takes the same route, returns the same bits too; a matrix that is not positive definite is reported from the first and from a later
+    super-panel; one size in the default range (4100 rows)."""
+    from ibo_amd import _lib, NotPositiveDefinite
+    from ibo_amd.gaussianprocess import GaussianProcess
+    from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+
+    def fit(X, Y, N, nb):
+        _lib.check(_lib.lib.ibo_set_option(b"super_min_nb", nb))
+        try:
+            GP = GaussianProcess(GaussianKernel_ard([.45] * X.shape[1]), X, Y, noise=.05)
+            W = np.empty((N, N)); _lib.check(_lib.lib.ibo_gp_get_W(GP._handle(), _lib.dp(W)))
+            v, g = marginalLikelihood(GaussianKernel_ard([.45] * X.shape[1]), X, Y, X.shape[1], True, noise=.05)
+            return np.array(GP.L), W, np.array(GP.R), v, np.asarray(g)
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"super_min_nb", 64))
+    for N in (2113, 3000, 3072, 3905):                        # 34, 47, 48, 62 block columns
+        X, Y = synth(N + 3, N, 5)
+        L1, W1, R, v1, g1 = fit(X, Y, N, 1000)                # step by step
+        L2, W2, _, v2, g2 = fit(X, Y, N, 32)                  # in super-panels
+        assert np.array_equal(L1, L2) and np.array_equal(W1, W2), N
+        assert v1 == v2 and np.array_equal(g1, g2), N
+        Lr = np.linalg.cholesky(R)
+        assert np.abs(L2 - Lr).max() < 1e-11 and np.abs(np.triu(L2, 1)).max() == 0.0
+        probe = np.random.RandomState(N).randint(0, N, 200)
+        assert np.abs(W2[probe].dot(L2) - np.eye(N)[probe]).max() < 1e-10 and np.all(np.triu(W2, 1) == 0.0)
+    X, Y = synth(77, 2300, 4)
+    for dup in (40, 1500):                                     # the first and the second super-panel
+        Xd = X.copy(); Xd[dup + 5] = Xd[dup]
+        _lib.check(_lib.lib.ibo_set_option(b"super_min_nb", 32))
+        try:
+            with pytest.raises(NotPositiveDefinite):
+                GaussianProcess(GaussianKernel_ard([.4] * 4), Xd, Y, noise=0.0)
+        finally:
+            _lib.check(_lib.lib.ibo_set_option(b"super_min_nb", 64))
+    N = 4100                                                   # 65 block columns: super-panels by default
+    X, Y = synth(78, N, 6)
+    GP = GaussianProcess(GaussianKernel_ard([.5] * 6), X, Y, noise=.1)
+    L = np.array(GP.L)
+    assert np.abs(L - np.linalg.cholesky(np.array(GP.R))).max() < 1e-11
+
+
 def test_nlml_gradient_against_the_oracle_every_family(ibo):
     """dnlml (csrc/assemble.hip nlml_grad_fast_kernel: the pairs' coordinates shared over a thread's 4 x 4 pairs, one short loop per
     derivative, lower tiles counted twice) against the oracle's value and gradient (ego/gaussianprocess/trainhyper.py:47-95): SE-ARD in
