@@ -54,6 +54,9 @@ __device__ __forceinline__ double panel_rsq(double d)
 }
 __device__ __forceinline__ double panel_chain(double d, double y0)
 {
+    // (round 6, measured and removed: one Newton step s = y0 (1 + e / 2) instead of the third-order correction below -- four dependent instructions
+    // for five, the same |L - L_numpy| (7.5e-15): 0.272 against 0.272 ms at N = 1024, 0.572 / 0.570 at 2048.  The correction is not on the
+    // pivot's critical path: the previous pivot's pair updates issue beside it, and it is their 2 x (15 - J) DPP instructions that a pivot costs.)
     double s, e, p;
     asm volatile("v_mul_f64 %1, %3, -%4\n\t"                    // -d y0
                  "v_fma_f64 %1, %1, %3, 1.0\n\t"                // e = 1 - d y0^2
