@@ -512,7 +512,7 @@ def worker(args):
                     fits["N%d_D%d" % (n, d)] = {"device_ms": ms, "host_to_ready_ms": float(np.median(host_ms)),
                                                 "roofline": attach_pmc(roofline_mfma(f_fit(n, d), ms * 1e-3, flops_per_fit=f_fit(n, d),
                                                                                      algorithmic_bytes_per_fit=8 * n * d + 24 * n * n,
-                                                                                     kernels="cov_matrix + chol_pipe8 (pipelined block columns, two steps per pass over the trailing tiles, W riding along: up to 6592 rows; two-level order + trinv_* beyond) + transpose_pack + gemv"),
+                                                                                     kernels="cov_fit + chol_pipe8 (pipelined block columns, two steps per pass over the trailing tiles, W riding along; from 4096 rows in super-panels of 16 block columns with chol_pack3 + chol_update3 deep updates of the columns beyond; two-level order + trinv_* from 6656 rows) + transpose_pack + gemv"),
                                                                        "fit%d" % n)}
                     del g
                     # one more observation through addData: an in-place extension of L, W and the packed copies
@@ -570,7 +570,7 @@ def worker(args):
                     "n_not_pd": int(np.sum(~np.isfinite(o5[-1][0]))),
                     "roofline": attach_pmc(roofline_mfma(f_nlml(C5_N, C5_D), per, flops_per_theta=f_nlml(C5_N, C5_D),
                                                          algorithmic_bytes_per_theta=24 * C5_N * C5_N,
-                                                         kernels="batched cov_matrix + left-looking chol_update3 (dominant) + chol_panel_rows8 + in-panel chain + reduce"),
+                                                         kernels="cov_grid_mfma (exponent on the MFMA unit) + left-looking chol_update3 (dominant) + chol_panel_fused + tail + reduce"),
                                            "c5")}
             _lib.trim(local_rank)
             # hyper-parameter learning's inner loop (ego/gaussianprocess/trainhyper.py:77-95,130-136): one NLML value + gradient
@@ -592,7 +592,7 @@ def worker(args):
                     ng["N%d_D%d" % (n, d)] = {"ms": per, "first_call_ms": ms[0],
                                               "roofline": attach_pmc(roofline_mfma(fl, per * 1e-3, flops_per_evaluation=fl,
                                                                                    algorithmic_bytes_per_evaluation=8 * n * d + 4 * 8 * n * n,
-                                                                                   kernels="cov_fit + chol_pipe8 (W riding along) + transpose_pack + K^-1 = W^T W (wtw_kernel; from 2560 rows syrk3_pack + chol_update3 in pieces + syrk3_sum) + nlml_grad_fast + reductions"),
+                                                                                   kernels="cov_fit + chol_pipe8 (W riding along; super-panels + chol_update3 from 4096 rows) + transpose_pack + K^-1 = W^T W (wtw_kernel; from 2560 rows syrk3_pack + chol_update3 in pieces + syrk3_sum) + nlml_grad_fast + reductions"),
                                                                      "learn%d" % n)}
                 cfgs["nlml_grad"] = {"workload": "one marginalLikelihood(..., computeGradient=True) evaluation, SE-ARD, D = 16 length scales, host X, Y in, value + gradient out (wall, median of 5)",
                                      "results": ng}

@@ -24,21 +24,22 @@ def _spec_rows(kernels):
     return ktype, thetas, sf2
 
 
-def nlml_values(kernels, X, Y, noise=1e-3, device=None):
-    """NLML for a list of kernel objects of one class (a theta grid); NaN where K is not PD."""
+def nlml_values(kernels, X, Y, noise=1e-3, device=None, spec=None):
+    """NLML for a list of kernel objects of one class (a theta grid); NaN where K is not PD.
+    spec: (ktype, rows, sf2) as Kernel._ibo_spec_rows gives them, instead of the objects."""
     X = _lib.rows(X); Y = _lib.f64(Y)
     N, D = X.shape
-    ktype, thetas, sf2 = _spec_rows(kernels)
-    out = np.empty(len(kernels))
+    ktype, thetas, sf2 = _spec_rows(kernels) if spec is None else spec
+    out = np.empty(len(thetas))
     dev = _lib.default_device() if device is None else device
-    _lib.check(_lib.lib.ibo_nlml_grid(dev, ktype, N, D, _lib.dp(X), _lib.dp(Y), len(kernels), _lib.dp(thetas),
+    _lib.check(_lib.lib.ibo_nlml_grid(dev, ktype, N, D, _lib.dp(X), _lib.dp(Y), len(thetas), _lib.dp(thetas),
                                       thetas.shape[1], _lib.dp(sf2), float(noise), _lib.dp(out)))
     return out
 
 
 def nlml_grid(Kernel, thetas, X, Y, noise=1e-3, device=None):
     """NLML at every row of `thetas` (hyper-parameters, NOT logs); returns (values, argmin)."""
-    vals = nlml_values([Kernel(np.asarray(t, dtype=float)) for t in thetas], X, Y, noise, device)
+    vals = nlml_values(None, X, Y, noise, device, spec=Kernel._ibo_spec_rows(thetas))
     return vals, int(np.nanargmin(vals))
 
 

@@ -311,7 +311,7 @@ def sharded_nlml_grid(Kernel, thetas, X, Y, comm, noise=1e-3, device=None, local
     if b > a:
         if local_eval is None:
             from .gaussianprocess.trainhyper import nlml_values
-            vals = nlml_values([Kernel(t) for t in thetas[a:b]], X, Y, noise, device)
+            vals = nlml_values(None, X, Y, noise, device, spec=Kernel._ibo_spec_rows(thetas[a:b]))
         else:
             vals = np.asarray(local_eval(thetas[a:b]), dtype=float)
         ok = np.isfinite(vals)
