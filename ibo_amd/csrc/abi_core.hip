@@ -247,8 +247,15 @@ void pool_trim(int dev)
     std::vector<ArenaSlab> &A = g_arena[dev & 15];
     for (size_t i = A.size(); i-- > 1;)                // every slab but the first, if nothing lives in it
         if (A[i].used == 0) { (void)hipFree(A[i].base); A.erase(A.begin() + i); }
-    for (ExecSet &x : g_exec_pool[dev & 15]) exec_set_free(x);
-    g_exec_pool[dev & 15].clear();
+    // (two stream / event sets with small staging stay, as the arena's first slab does: they hold no device memory worth the name, and a
+    // model built right after a trim -- bench.py's preference GP -- paid 2.6 ms to make them again)
+    std::vector<ExecSet> &v = g_exec_pool[dev & 15];
+    size_t kept = 0;
+    for (size_t i = 0; i < v.size(); i++) {
+        if (kept < 2 && v[i].pin_cap <= ((size_t)1 << 16)) v[kept++] = v[i];
+        else exec_set_free(v[i]);
+    }
+    v.resize(kept);
 }
 
 // ------------------------------------------------------------------------ library

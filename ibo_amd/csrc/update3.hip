@@ -169,6 +169,13 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
         if (t < tri) { I = 0; int rem = t; while (rem > I) { rem -= I + 1; I++; } J = rem; }
         else { I = ntc + (t - tri) / ntc; J = (t - tri) % ntc; }
     }
+    // A tile of the TALL matrix's second half (rows >= Npad: the ride-along's E, launch_cholesky_super) has nothing but exact zeros left of its
+    // rows' diagonal block (chol_pack3e_kernel): its K range starts there -- a sixth of a super-panel's deep update is such products, and the
+    // shortened tiles are the last ones dealt
+    if (!tasks && c0 + 128 * I >= Npad) {
+        const int ks = ((c0 + 128 * I - Npad) >> 6) << 6, d = ks - 8 * kb8;
+        if (d > 0 && d < K) { kb8 += d >> 3; K -= d; }
+    }
     const int wr = wave >> 1, wc = wave & 1;
     const int gA = ((c0 + 128 * I) >> 4) + 2 * wr;               // first of this wave's two row-blocks (numbered from row 0)
     const int gB = (c0 + 128 * J) >> 4;                          // first of the tile's eight column-blocks, as row-blocks of the panel
