@@ -10,6 +10,12 @@ from ibo_amd.gaussianprocess import GaussianProcess
 from ibo_amd.gaussianprocess import kernel as K
 from ibo_amd.acquisition import sweep
 
+# FUZZ_OPTS="key=value,key=value": ibo_set_option switches for the whole run (e.g. super_min_nb=32,direct_resident=1: fits from 2048 rows in
+# super-panels, DIRECT's batches on the resident server -- the same oracle, the same bars)
+if os.environ.get("FUZZ_OPTS"):
+    from ibo_amd import _lib
+    for kv in os.environ["FUZZ_OPTS"].split(","):
+        k, v = kv.split("="); _lib.check(_lib.lib.ibo_set_option(k.encode(), int(v)))
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 special_N = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 511, 512, 513, 1023, 1025, 1471, 2047, 2049]
