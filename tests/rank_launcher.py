@@ -54,7 +54,7 @@ def run(job):
     for fo, fe in files:
         for f, key in ((fo, "out"), (fe, "err")):
             f.seek(0)
-            res[key].append(f.read().decode("utf-8", "replace")[-8000:])
+            res[key].append(f.read().decode("utf-8", "replace")[-200000:])      # (a bench line is ~10 KB)
             f.close()
     return res
 
