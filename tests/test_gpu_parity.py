@@ -1166,6 +1166,21 @@ def test_errors_are_loud(ibo):
     with pytest.raises(np.linalg.LinAlgError):
         GaussianProcess(GaussianKernel_ard([1.]), X, [1., 1., 2.], noise=-1.0)
     assert issubclass(NotPositiveDefinite, np.linalg.LinAlgError)
+    # the round-6 entry points and switches refuse what they cannot do, with a message
+    import ctypes
+    from ibo_amd import _lib, IBOError
+    GP = GaussianProcess(GaussianKernel_ard([1.]), np.array([[.1], [.4], [.8]]), [1., 2., 1.5])
+    v = ctypes.c_double(); i = ctypes.c_int64(); r = ctypes.c_int(); x = np.zeros(1)
+    rc = _lib.lib.ibo_acq_sweep_exchange(GP._handle(), None, 0, 1, None, 0, .01, 0, 1e-8, float('nan'), 0, None, .5, 0,
+                                         ctypes.byref(v), ctypes.byref(i), ctypes.byref(v), ctypes.byref(i), _lib.dp(x), ctypes.byref(r))
+    assert rc == 1 and _lib.lib.ibo_last_error()                  # IBO_ERR_ARG
+    for key, bad in ((b"super_min_nb", 3), (b"direct_idle_ms", 0), (b"arena_mb", -1), (b"no_such_option", 1)):
+        with pytest.raises(IBOError):
+            _lib.check(_lib.lib.ibo_set_option(key, bad))
+    ms = ctypes.c_double(-1.0)
+    _lib.check(_lib.lib.ibo_gpu_time_ms(0, ctypes.byref(ms)))
+    assert ms.value > 0.0                                   # (this process has fitted models: their device time is in it)
+    assert _lib.lib.ibo_gpu_time_ms(0, None) == 1 and _lib.lib.ibo_direct_server_info(None, None, None) == 1
 
 
 # --------------------------------------------------------------------------- full-size configurations
@@ -1539,7 +1554,7 @@ def test_grid_covariance_on_the_mfma_unit_against_the_oracle_and_the_difference_
     cov_grid_mfma_kernel; ego/gaussianprocess/kernel.py:46-53,147-149, trainhyper.py:55) where every scaled point stays inside the dot
     form's guard, by coordinate differences elsewhere (ibo_set_option("dot_form", 0) forces those).  NLML values of both routes against
     the oracle at 1e-9 and against each other at 1e-10: ragged sizes (a last tile of one row; rows that are not a multiple of 16, 64 or
-    128), 1 .. 30 dimensions (one to eight k4-steps of the exponent product), every covariance family; a theta-point with length scales so
+    128), 1 .. 32 dimensions (one to nine k4-steps of the exponent product), every covariance family; a theta-point with length scales so
     short that the guard trips sends the whole call to the difference form (same values as forced)."""
     from ibo_amd import _lib
     from ibo_amd.gaussianprocess import kernel as K
@@ -1553,7 +1568,7 @@ def test_grid_covariance_on_the_mfma_unit_against_the_oracle_and_the_difference_
         finally:
             _lib.check(_lib.lib.ibo_set_option(b"dot_form", -1))
         return np.asarray(v), np.asarray(d)
-    for N, D in ((65, 1), (193, 2), (500, 3), (1000, 6), (1345, 16), (777, 30)):
+    for N, D in ((65, 1), (193, 2), (500, 3), (1000, 6), (1345, 16), (777, 30), (300, 32)):
         X, Y = synth(40 + N, N, D)
         th = np.exp(np.random.RandomState(N).uniform(np.log(.3), np.log(2), size=(5, D))) * np.sqrt(D)
         v, d = both([K.GaussianKernel_ard(t) for t in th], X, Y, 1e-2)
