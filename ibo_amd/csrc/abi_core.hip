@@ -119,6 +119,41 @@ static void slab_give(ArenaSlab &sl, size_t off, size_t len)
     sl.used -= len;
 }
 static void exec_sets_prewarm(int dev);
+// one kernel of every translation unit (each defines its ibo_touch_*): their code objects are loaded now, not in the middle of the first
+// call that needs them
+void ibo_touch_small2(); void ibo_touch_sweep(); void ibo_touch_sweep2(); void ibo_touch_linalg(); void ibo_touch_assemble(); void ibo_touch_update3();
+void ibo_touch_legacy(); void ibo_touch_comm();
+void ibo_touch_s2fam_FAM_SE_0(); void ibo_touch_s2fam_FAM_SE_1(); void ibo_touch_s2fam_FAM_M3_0(); void ibo_touch_s2fam_FAM_M3_1();
+void ibo_touch_s2fam_FAM_M5_0(); void ibo_touch_s2fam_FAM_M5_1();
+static void load_code_objects()
+{
+    ibo_touch_small2(); ibo_touch_sweep(); ibo_touch_sweep2(); ibo_touch_linalg(); ibo_touch_assemble(); ibo_touch_update3();
+    ibo_touch_legacy(); ibo_touch_comm();
+    ibo_touch_s2fam_FAM_SE_0(); ibo_touch_s2fam_FAM_SE_1(); ibo_touch_s2fam_FAM_M3_0(); ibo_touch_s2fam_FAM_M3_1();
+    ibo_touch_s2fam_FAM_M5_0(); ibo_touch_s2fam_FAM_M5_1();
+    (void)hipGetLastError();
+}
+// (g_pool_mu held) one more slab; the first brings the start-up work with it
+static bool arena_add_slab(int dev, size_t slab_bytes)
+{
+    std::vector<ArenaSlab> &A = g_arena[dev & 15];
+    ArenaSlab sl;
+    if (hipMalloc((void **)&sl.base, slab_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (A.empty()) g_arena_off[dev & 15] = true;
+        return false;
+    }
+    sl.bytes = slab_bytes;
+    sl.holes.push_back(std::make_pair((size_t)0, slab_bytes));
+    const bool first = A.empty();
+    A.push_back(sl);
+    if (first) {
+        exec_sets_prewarm(dev); load_code_objects();
+        const double *tab = nullptr;
+        (void)exp_table(dev, &tab);                  // (the sweeps' table: its upload is the process's first pageable copy, 9 ms of runtime set-up)
+    }
+    return true;
+}
 // (g_pool_mu held)
 static void *arena_get(int dev, size_t bytes, size_t *got)
 {
@@ -132,20 +167,19 @@ static void *arena_get(int dev, size_t bytes, size_t *got)
     size_t beyond = 0;
     for (size_t i = 1; i < A.size(); i++) beyond += A[i].bytes;
     if (!A.empty() && beyond + slab_bytes > g_pool_limit) return nullptr;
-    ArenaSlab sl;
-    if (hipMalloc((void **)&sl.base, slab_bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        if (A.empty()) g_arena_off[dev & 15] = true;
-        return nullptr;
-    }
-    sl.bytes = slab_bytes;
-    sl.holes.push_back(std::make_pair((size_t)0, slab_bytes));
-    const bool first = A.empty();
-    A.push_back(sl);
-    if (first) exec_sets_prewarm(dev);
+    if (!arena_add_slab(dev, slab_bytes)) return nullptr;
     void *p = slab_take(A.back(), need);
     *got = need;
     return p;
+}
+// the library's start-up on a device, once: the arena's first slab, two stream / event / staging sets, every translation unit's code object.
+// Called when the first handle is created (so that it, too, finds a ready-made set) and, failing that, by the first allocation.
+void pool_warm(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    const size_t slab_bytes = (size_t)g_arena_mb.load() << 20;
+    if (slab_bytes == 0 || g_arena_off[dev & 15] || !g_arena[dev & 15].empty()) return;
+    (void)arena_add_slab(dev, slab_bytes);
 }
 
 void *pool_get(size_t bytes, size_t *got)
@@ -419,6 +453,7 @@ extern "C" int ibo_gp_create(int device, ibo_gp_t **out)
     ibo_gp *g = new ibo_gp();
     g->device = device;
     memset(&g->kp, 0, sizeof(g->kp));
+    pool_warm(device);                               // (the first handle of the process on this device: the library's start-up, see pool_warm)
     ExecSet x;
     if (exec_set_get(device, &x)) {
         g->stream = x.stream; g->ev0 = x.ev0; g->ev1 = x.ev1; g->fit0 = x.fit0; g->fit1 = x.fit1;

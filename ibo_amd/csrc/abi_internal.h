@@ -54,6 +54,7 @@ void gpu_time_add(int device, double ms);    // accumulates what ibo_gpu_time_ms
 void *pool_get(size_t bytes, size_t *got);
 void pool_put(void *p, size_t bytes);
 void pool_trim(int dev);
+void pool_warm(int dev);
 extern thread_local bool g_pool_quiet;       // the caller has synchronised the device already (ibo_gp_destroy: once for all its buffers)
 
 template <typename T>
@@ -155,6 +156,7 @@ static inline bool single_level_order(int Np) { return Np / 64 < g_fused2_min_nb
 static inline bool super_order(int Np) { return single_level_order(Np) && Np / 64 >= g_super_min_nb; }
 
 // ---- helpers one unit lends another
+int exp_table(int device, const double **out);                                                            // abi_sweep.hip: 2^(j/2048), one per device
 int ibo_comm_exchange_dev(ibo_comm_t *c, hipStream_t s, const double *res_v, const int64_t *res_i, const double *cand_dev, int D, int64_t index_base,
                           double *local_val, int64_t *local_idx, double *best_val, int64_t *best_idx, double *best_x, int *best_rank);   // comm.hip
 uint64_t alloc_generation(int device, const void *p, size_t bytes, size_t *offset);                       // abi_core.hip

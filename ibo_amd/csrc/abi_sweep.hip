@@ -5,7 +5,7 @@
 // 2^(j/2048), j < 2048: the table behind sweep2's exp (one per device, created on first use)
 static std::atomic<double *> g_exp_tab[16];
 static std::mutex g_exp_mu;                          // held only while a device's table is being created (never across a grid or a gradient)
-static int exp_table(int device, const double **out)
+int exp_table(int device, const double **out)
 {
     double *p = g_exp_tab[device & 15].load(std::memory_order_acquire);
     if (!p) {

@@ -1082,3 +1082,5 @@ int streams_run_side_by_side(hipStream_t a, hipStream_t b, bool *yes)
     *yes = best < 0.065f;                                  // 40 us side by side, 80 one after the other
     return (int)e;
 }
+
+void ibo_touch_assemble() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)pad_copy_kernel); }     // (see small2.hip: ibo_touch_small2)

@@ -309,3 +309,5 @@ double LegacyHost::negated(double prior_mu, double c_mean, double c_var) const
     const double phi = exp(-(u * u / 2.)) / root2pi;
     return -(gain * Phi + sd * phi);
 }
+
+void ibo_touch_legacy() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)legacy_transpose_kernel); }     // (see small2.hip: ibo_touch_small2)

@@ -1908,3 +1908,5 @@ int launch_wtw(const double *W, double *Wt, double *C, int Npad, hipStream_t s, 
     return (int)hipGetLastError();
 }
 
+
+void ibo_touch_linalg() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)chol_diag_kernel); }     // (see small2.hip: ibo_touch_small2)

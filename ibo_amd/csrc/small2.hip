@@ -703,3 +703,8 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
 #endif
     return launch_argmax_final(a, nfin, s);
 }
+
+// HIP loads a translation unit's code object when one of its kernels is first needed -- 0.5 .. 1.5 ms in the middle of whatever call that
+// is (the first gallery call of a process paid 2.8 ms for two of them).  The library asks for one kernel of every unit when it makes its
+// first allocation on a device (abi_core.hip: load_code_objects), beside the arena's first slab: start-up cost, paid once.
+void ibo_touch_small2() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)small_finish_kernel); }

@@ -465,3 +465,5 @@ int launch_sweep2(const SweepArgs &a, hipStream_t s, hipEvent_t e0, hipEvent_t e
     if (rc) return rc;
     return launch_argmax_final(a, nfin, s);
 }
+
+void ibo_touch_sweep2() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)acq_finish_kernel); }     // (see small2.hip: ibo_touch_small2)
