@@ -172,7 +172,7 @@ static void *arena_get(int dev, size_t bytes, size_t *got)
     *got = need;
     return p;
 }
-// the library's start-up on a device, once: the arena's first slab, two stream / event / staging sets, every translation unit's code object.
+// the library's start-up on a device, once: the arena's first slab, four stream / event / staging sets, every translation unit's code object.
 // Called when the first handle is created (so that it, too, finds a ready-made set) and, failing that, by the first allocation.
 void pool_warm(int dev)
 {
@@ -253,11 +253,13 @@ static void exec_set_put(int dev, ExecSet x)
     exec_set_free(x);
 }
 
-// two spare sets beside the arena's first slab (g_pool_mu held): the first handle and the model a gallery call makes from it
+// four ready-made sets beside the arena's first slab (g_pool_mu held).  Four, because what a new stream costs is the hardware queue the
+// runtime creates for it -- 9 ms each for the first four streams of a process (21 for the very first), next to nothing afterwards, when new
+// streams share the queues that exist: with two sets, the model a gallery call makes while two other models were alive paid those 9 ms
 static void exec_sets_prewarm(int dev)
 {
     std::vector<ExecSet> &v = g_exec_pool[dev & 15];
-    while (v.size() < 2) {
+    while (v.size() < 4) {
         ExecSet x;
         hipError_t e = hipStreamCreate(&x.stream);
         if (e == hipSuccess) e = hipEventCreate(&x.ev0);
@@ -281,12 +283,12 @@ void pool_trim(int dev)
     std::vector<ArenaSlab> &A = g_arena[dev & 15];
     for (size_t i = A.size(); i-- > 1;)                // every slab but the first, if nothing lives in it
         if (A[i].used == 0) { (void)hipFree(A[i].base); A.erase(A.begin() + i); }
-    // (two stream / event sets with small staging stay, as the arena's first slab does: they hold no device memory worth the name, and a
+    // (four stream / event sets with small staging stay, as the arena's first slab does: they hold no device memory worth the name, and a
     // model built right after a trim -- bench.py's preference GP -- paid 2.6 ms to make them again)
     std::vector<ExecSet> &v = g_exec_pool[dev & 15];
     size_t kept = 0;
     for (size_t i = 0; i < v.size(); i++) {
-        if (kept < 2 && v[i].pin_cap <= ((size_t)1 << 16)) v[kept++] = v[i];
+        if (kept < 4 && v[i].pin_cap <= ((size_t)1 << 16)) v[kept++] = v[i];
         else exec_set_free(v[i]);
     }
     v.resize(kept);

@@ -383,7 +383,7 @@ int ibo_nlml_grid(int device, int ktype, int N, int D,
  * matrices; the N x N buffers of the gradient) between calls, and the buffers of destroyed handles go to a
  * per-device free list (at most 2 GiB; ibo_set_option("pool_limit_mb", n) or env IBO_POOL_LIMIT_MB) for the next handle; buffers of up
  * to half a slab live in the arena (see "arena_mb").  This releases all of it EXCEPT the library's standing reservation on the device: the
- * arena's first slab and two stream / event / staging sets, which the next model would otherwise pay milliseconds to make again. */
+ * arena's first slab and four stream / event / staging sets, which the next model would otherwise pay milliseconds to make again. */
 int ibo_trim(int device);
 
 /*
