@@ -61,6 +61,7 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
+    size_t bytes = 0;              // what the pool handed out (a multiple of its grain, not of sizeof(T)): what goes back to it
     int ensure(size_t n)
     {
         if (n <= cap) return IBO_OK;
@@ -80,9 +81,10 @@ struct DevBuf {
         }
         p = (T *)q;
         cap = got / sizeof(T);
+        bytes = got;
         return IBO_OK;
     }
-    void release() { if (p) pool_put(p, cap * sizeof(T)); p = nullptr; cap = 0; }
+    void release() { if (p) pool_put(p, bytes); p = nullptr; cap = 0; bytes = 0; }
 };
 // function-local buffers: handed back on every exit path (the members of handles and of the static
 // workspaces are released explicitly -- a static object must not call into HIP at process exit)
