@@ -138,6 +138,13 @@ def check(rc):
     raise IBOError(rc, msg)
 
 
+# IBO_OPTIONS="key=value,key=value": ibo_set_option switches applied when the package is imported (a whole test or benchmark run under
+# another route without touching its code: IBO_OPTIONS=direct_resident=1,super_min_nb=32 python -m pytest tests -m gpu)
+for _kv in [kv for kv in os.environ.get("IBO_OPTIONS", "").split(",") if kv.strip()]:
+    _k, _, _v = _kv.partition("=")
+    check(lib.ibo_set_option(_k.strip().encode(), int(_v)))
+
+
 def f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
