@@ -139,6 +139,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
                         if (ok || nrej == 6) { ws.streams[g] = cand; break; }
                         rejected[nrej++] = cand;
                     }
+                    if (getenv("IBO_DEBUG")) fprintf(stderr, "[libibo_hip] sub-batch stream %d: %d candidate(s) shared a hardware queue with an earlier one%s\n", g, nrej, nrej == 6 ? " -- none found that does not" : "");
                     for (int r = 0; r < nrej; r++) (void)hipStreamDestroy(rejected[r]);
                 }
                 if (!ws.t0[g]) { HIP_TRY(hipEventCreate(&ws.t0[g])); HIP_TRY(hipEventCreate(&ws.t1[g])); }
