@@ -48,7 +48,15 @@ struct Pool {
     std::vector<double> cls_best;
     std::vector<int> pos;              // where rectangle j sits in members[cls[j]]
     size_t size() const { return y.size(); }
+    double last_dd = -1.0; int last_cls = -1;      // (the two children of a cut have the same d: every second look-up is the one before)
     int class_of(double dd)
+    {
+        if (dd == last_dd) return last_cls;
+        const int c = class_find(dd);
+        last_dd = dd; last_cls = c;
+        return c;
+    }
+    int class_find(double dd)
     {
         size_t lo = 0, hi = by_size.size();
         while (lo < hi) {
@@ -237,27 +245,28 @@ struct Search {
         }
         std::vector<double> &l = sc_l, &u = sc_u, &cl = sc_cl, &cu = sc_cu, &cc = sc_cc;
         l.assign(dv.lb.begin(), dv.lb.end()); u.assign(dv.ub.begin(), dv.ub.end()); cl.resize(D); cu.resize(D); cc.resize(D);
-        dv.kid_lb.clear(); dv.kid_ub.clear(); dv.kid_ctr.clear(); dv.kid_d.clear();
-        auto add_kid = [&](const std::vector<double> &kl, const std::vector<double> &ku) {
+        // a child is the rectangle as cut so far with ONE side replaced: written straight into the division's arrays (the sums below run over
+        // the dimensions in the same order with the same operands as a copy-then-modify would give them)
+        dv.kid_lb.resize(2 * m * D); dv.kid_ub.resize(2 * m * D); dv.kid_ctr.resize(2 * m * D); dv.kid_d.resize(2 * m);
+        auto add_kid = [&](size_t k, int side_dim, double lo_v, double hi_v) {
+            double *kl = &dv.kid_lb[k * D], *ku = &dv.kid_ub[k * D], *kc = &dv.kid_ctr[k * D];
             double dd = 0.0;
             for (int i = 0; i < D; i++) {
-                cc[i] = kl[i] + (ku[i] - kl[i]) / 2.;
-                dd += (kl[i] - cc[i]) * (kl[i] - cc[i]);
+                const double a = i == side_dim ? lo_v : l[i], b = i == side_dim ? hi_v : u[i];
+                kl[i] = a; ku[i] = b;
+                kc[i] = a + (b - a) / 2.;
+                dd += (a - kc[i]) * (a - kc[i]);
             }
-            dv.kid_lb.insert(dv.kid_lb.end(), kl.begin(), kl.end());
-            dv.kid_ub.insert(dv.kid_ub.end(), ku.begin(), ku.end());
-            dv.kid_ctr.insert(dv.kid_ctr.end(), cc.begin(), cc.end());
-            dv.kid_d.push_back(std::sqrt(dd));
+            dv.kid_d[k] = std::sqrt(dd);
         };
+        (void)cl; (void)cu; (void)cc;
         for (size_t q = 0; q < m; q++) {
             int dd = order[q];
             double w = u[dd] - l[dd];
             double s1 = l[dd] + w / 3.;
             double s2 = l[dd] + 2. * w / 3.;
-            cl = l; cu = u; cu[dd] = s1;
-            add_kid(cl, cu);
-            cl = l; cu = u; cl[dd] = s2;
-            add_kid(cl, cu);
+            add_kid(2 * q, dd, l[dd], s1);
+            add_kid(2 * q + 1, dd, s2, u[dd]);
             l[dd] = s1; u[dd] = s2;
         }
         double md = 0.0;
@@ -342,17 +351,25 @@ void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out
         double maxI1 = DBL_MIN, minI2 = DBL_MAX;
         {
             const __m128d vy = _mm_set1_pd(yj), vd = _mm_set1_pd(dj);
-            __m128d mx = _mm_set1_pd(DBL_MIN), mn = _mm_set1_pd(DBL_MAX);
-            size_t h = 0;
-            for (; h + 2 <= g; h += 2)
-                mx = _mm_max_pd(_mm_div_pd(_mm_sub_pd(vy, _mm_loadu_pd(&gy[h])), _mm_sub_pd(vd, _mm_loadu_pd(&gd[h]))), mx);
-            for (; h < g; h++) { const double v = (yj - gy[h]) / (dj - gd[h]); if (v > maxI1) maxI1 = v; }
-            for (h = g + 1; h + 2 <= G; h += 2)
+            __m128d mn = _mm_set1_pd(DBL_MAX);
+            size_t h = g + 1;
+            for (; h + 2 <= G; h += 2)
                 mn = _mm_min_pd(_mm_div_pd(_mm_sub_pd(_mm_loadu_pd(&gy[h]), vy), _mm_sub_pd(_mm_loadu_pd(&gd[h]), vd)), mn);
             for (; h < G; h++) { const double v = (gy[h] - yj) / (gd[h] - dj); if (v < minI2) minI2 = v; }
             double t[2];
-            _mm_storeu_pd(t, mx); if (t[0] > maxI1) maxI1 = t[0]; if (t[1] > maxI1) maxI1 = t[1];
             _mm_storeu_pd(t, mn); if (t[0] < minI2) minI2 = t[0]; if (t[1] < minI2) minI2 = t[1];
+            // (the slopes from the smaller classes only matter through "is one of them above minI2": not formed for a rectangle the test
+            // below rejects anyway, and the scan stops at the first that is)
+            if (minI2 > 0. && minI2 != DBL_MAX) {
+                bool above = false;                     // the rejection below already holds (the maximum only grows: it keeps holding)
+                for (h = 0; h + 2 <= g && !above; h += 2) {
+                    _mm_storeu_pd(t, _mm_div_pd(_mm_sub_pd(vy, _mm_loadu_pd(&gy[h])), _mm_sub_pd(vd, _mm_loadu_pd(&gd[h]))));
+                    if (t[0] > maxI1) maxI1 = t[0];
+                    if (t[1] > maxI1) maxI1 = t[1];
+                    above = maxI1 != DBL_MIN && minI2 < maxI1;
+                }
+                for (; h < g && !above; h++) { const double v = (yj - gy[h]) / (dj - gd[h]); if (v > maxI1) maxI1 = v; above = maxI1 != DBL_MIN && minI2 < maxI1; }
+            }
         }
         if (minI2 <= 0.) continue;
         if (maxI1 != DBL_MIN && minI2 != DBL_MAX && minI2 < maxI1) continue;
