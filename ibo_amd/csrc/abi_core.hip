@@ -33,7 +33,6 @@ std::atomic<int> g_force_path{0};     // ibo_set_option("sweep_path"): 0 auto, 1
 std::atomic<int> g_super_min_nb{kSuperFrom};   // ibo_set_option("super_min_nb", nb): single-matrix fits from nb block columns on run in super-panels (linalg.hip: launch_cholesky_super)
 std::atomic<int> g_direct_resident{0};  // ibo_set_option("direct_resident", 0/1): ibo_direct_max evaluates its batches on a resident kernel (small2.hip) instead of launches -- off: measured slower, DESIGN 4.4
 std::atomic<int> g_direct_idle_ms{20};  // ibo_set_option("direct_idle_ms", n): that kernel leaves when its mailbox stays silent this long
-std::atomic<int> g_panel_ahead{1};    // ibo_set_option("panel_ahead", 0/1): the grid's panels factor their diagonal blocks on a side stream beside the update of the rows below (linalg.hip: launch_cholesky_batched_left); the same bits
 std::atomic<int> g_nlml_groups{2};    // IBO_NLML_GROUPS=1..4 (env): a batch of theta-points runs as that many sub-batches, each on its own stream(s); values do not depend on it
 // The option switches above are process-wide configuration (atomics: setting one while another thread computes is a defined,
 // if unspecified-moment, change); the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad and ibo_trim are serialised by
@@ -347,7 +346,6 @@ extern "C" int ibo_set_option(const char *key, int value)
     if (!strcmp(key, "legacy_exact")) { g_legacy_exact = value; return IBO_OK; }
     if (!strcmp(key, "host_pipeline")) { g_host_pipeline = value; return IBO_OK; }
     if (!strcmp(key, "nlml_batch")) { g_nlml_batch = value; return IBO_OK; }
-    if (!strcmp(key, "panel_ahead")) { g_panel_ahead = value != 0; return IBO_OK; }
     if (!strcmp(key, "chol_left")) { g_chol_left = value; return IBO_OK; }
     if (!strcmp(key, "fused2_min_nb")) { if (value < 1) return fail(IBO_ERR_ARG, "fused2_min_nb < 1"); g_fused2_min_nb = value; return IBO_OK; }
     if (!strcmp(key, "super_min_nb")) { if (value < 2 * kSuperPanel) return fail(IBO_ERR_ARG, "super_min_nb < %d", 2 * kSuperPanel); g_super_min_nb = value; return IBO_OK; }

@@ -43,7 +43,7 @@ int ibo_fail(int code, const char *fmt, ...);
 // ---- option switches (abi_core.hip: ibo_set_option)
 extern std::atomic<int> g_super_min_nb;        // ibo_set_option("super_min_nb", nb): block columns from which a fit runs in super-panels
 extern std::atomic<int> g_direct_resident, g_direct_idle_ms;      // ibo_set_option("direct_resident", 0/1), ("direct_idle_ms", n)
-extern std::atomic<int> g_host_pipeline, g_fused2_min_nb, g_gallery_prune, g_nlml_batch, g_chol_left, g_dot_override, g_legacy_exact, g_force_path, g_nlml_groups, g_panel_ahead;
+extern std::atomic<int> g_host_pipeline, g_fused2_min_nb, g_gallery_prune, g_nlml_batch, g_chol_left, g_dot_override, g_legacy_exact, g_force_path, g_nlml_groups;
 extern std::mutex g_dev_mu[16];             // serialises the per-device workspaces of ibo_nlml_grid / ibo_nlml_grad / ibo_trim
 extern std::atomic<size_t> g_pool_limit;
 

@@ -4,15 +4,13 @@
 
 // ------------------------------------------------------------------------ marginal-likelihood grid
 struct NlmlWorkspace {
-    DevBuf<double> dX, dY, dout, dL, d64, dP, dFr;  // dP: packed store of the trailing updates (update3.hip); dFr: a panel's operand blocks (look-ahead)
+    DevBuf<double> dX, dY, dout, dL, d64, dP;       // dP: packed store of the trailing updates (update3.hip)
     DevBuf<KParams> dkp;                            // the theta-points' kernel parameters (one covariance launch per sub-batch)
     DevBuf<int> dinfo, dflags;                      // dflags: four hand-over words per matrix (chol_panel_fused_kernel)
     const double *padded = nullptr;                 // dL as it was when its matrices got their identity pad,
     int pad_Np = 0, pad_N = 0, pad_B = 0;           // and for which geometry
     hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};     // sub-batches of a grid run side by side (created on first use, kept)
     hipEvent_t t0[4] = {nullptr, nullptr, nullptr, nullptr}, t1[4] = {nullptr, nullptr, nullptr, nullptr};     // a sub-batch's span on its stream (ibo_gpu_time_ms)
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};        // a sub-batch's look-ahead stream (launch_cholesky_batched_left) and its two events
-    hipEvent_t ev[4][2] = {};
 };
 static NlmlWorkspace g_nlml_ws[16];
 static const int kSyrk3From = 2560;          // rows from which ibo_nlml_grad forms K^-1 = W^T W on the packed-operand kernel (launch_syrk3)
@@ -29,15 +27,11 @@ extern "C" int ibo_trim(int device)
     IBO_TRY(use_device(device));
     std::lock_guard<std::mutex> lk(g_dev_mu[device & 15]);
     NlmlWorkspace &ws = g_nlml_ws[device & 15];
-    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release(); ws.dflags.release(); ws.dkp.release(); ws.dFr.release();
+    ws.dX.release(); ws.dY.release(); ws.dout.release(); ws.dL.release(); ws.d64.release(); ws.dP.release(); ws.dinfo.release(); ws.dflags.release(); ws.dkp.release();
     ws.padded = nullptr;
     for (int g = 0; g < 4; g++) if (ws.streams[g]) {
         (void)hipStreamDestroy(ws.streams[g]); ws.streams[g] = nullptr;
         if (ws.t0[g]) { (void)hipEventDestroy(ws.t0[g]); (void)hipEventDestroy(ws.t1[g]); ws.t0[g] = ws.t1[g] = nullptr; }
-    }
-    for (int g = 0; g < 4; g++) if (ws.side[g]) {
-        (void)hipStreamDestroy(ws.side[g]); ws.side[g] = nullptr;
-        for (int k = 0; k < 2; k++) if (ws.ev[g][k]) { (void)hipEventDestroy(ws.ev[g][k]); ws.ev[g][k] = nullptr; }
     }
     GradWorkspace &gw = g_grad_ws[device & 15];
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
@@ -84,7 +78,6 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     const size_t pws = nn;
     IBO_TRY(ws.dP.ensure(pws * B));
     IBO_TRY(ws.dflags.ensure((size_t)4 * B));
-    IBO_TRY(ws.dFr.ensure((size_t)16 * 4096 * B));
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dY.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
     // identity pad once: the factorisation leaves the pad rows/columns as it found them, so the workspace of an
@@ -117,7 +110,7 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
     // call's blocking copies into dX / dY / dkp would not wait for them (an error return inside the batch loop used to leave them running).
     struct StreamDrain {
         NlmlWorkspace &w;
-        ~StreamDrain() { for (int g = 0; g < 4; g++) { if (w.streams[g]) (void)hipStreamSynchronize(w.streams[g]); if (w.side[g]) (void)hipStreamSynchronize(w.side[g]); } }
+        ~StreamDrain() { for (int g = 0; g < 4; g++) if (w.streams[g]) (void)hipStreamSynchronize(w.streams[g]); }
     } drain{ws};
     std::vector<int> info(n_theta);
     for (int t0 = 0; t0 < n_theta; t0 += B) {
@@ -155,28 +148,6 @@ extern "C" int ibo_nlml_grid(int device, int ktype, int N, int D, const double *
                 const int k0 = (int)((long long)nb * g / G), k1 = (int)((long long)nb * (g + 1) / G), ng = k1 - k0;
                 grp[g] = CholGroup{dL.p + nn * k0, d64.p + (size_t)(Np / 64) * 4096 * k0, ws.dP.p + pws * k0, dinfo.p + t0 + k0, ng, sg,
                                    with_flags ? ws.dflags.p + 4 * k0 : nullptr};
-                if (with_flags && left && g_panel_ahead != 0 && G <= 2) {
-                    // the look-ahead stream of this sub-batch: beside every stream made so far (with two sub-batches that is all four hardware queues)
-                    if (!ws.side[g]) {
-                        hipStream_t rejected[6];
-                        int nrej = 0, lo = 0, hi = 0;
-                        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                        for (;;) {
-                            hipStream_t cand = nullptr;
-                            HIP_TRY(hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, hi));
-                            bool ok = true;
-                            for (int g2 = 0; g2 <= g && ok; g2++) KERNEL_TRY(streams_run_side_by_side(ws.streams[g2], cand, &ok));
-                            for (int g2 = 0; g2 < g && ok; g2++) if (ws.side[g2]) KERNEL_TRY(streams_run_side_by_side(ws.side[g2], cand, &ok));
-                            if (ok || nrej == 6) { ws.side[g] = cand; break; }
-                            rejected[nrej++] = cand;
-                        }
-                        if (getenv("IBO_DEBUG")) fprintf(stderr, "[libibo_hip] look-ahead stream %d: %d candidate(s) shared a hardware queue with an earlier stream%s\n", g, nrej, nrej == 6 ? " -- none found that does not" : "");
-                        for (int r = 0; r < nrej; r++) (void)hipStreamDestroy(rejected[r]);
-                        for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreateWithFlags(&ws.ev[g][k], hipEventDisableTiming));
-                    }
-                    grp[g].side = ws.side[g]; grp[g].ev[0] = ws.ev[g][0]; grp[g].ev[1] = ws.ev[g][1];
-                    grp[g].Fr = ws.dFr.p + (size_t)16 * 4096 * k0;
-                }
                 KERNEL_TRY(launch_cov_matrix_batched(ws.dkp.p + t0 + k0, ng, N, dX.p, D, IBO_DIAG_KERNEL_PLUS_NOISE, noise, dL.p + nn * k0, Np, nn, sg, dot_ok));
                 KERNEL_TRY(launch_nlml_aug(dL.p + nn * k0, Np, N, dY.p, sg, ng, nn));
             }

@@ -268,13 +268,7 @@ int launch_chol_update2(double *L, int Npad, int p0, int pend, int batch, size_t
 // what a row workgroup of chol_panel_fused_kernel leaves in its matrix's info word when a flag wait runs out (not a pivot: the caller
 // runs the batch again through the launches that have no waits)
 static const int kPanelWaitTimeout = 0x7ffffff0;
-struct CholGroup {
-    double *L, *diag64, *Pk; int *info; int batch; hipStream_t stream; int *flags;
-    // look-ahead (optional, with flags): a second stream that brings a panel's diagonal block up to date and factors it BESIDE the update of the
-    // rows below it; ev[0]: the panel's rows are finished (main -> side), ev[1]: its diagonal block is (side -> main)
-    hipStream_t side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
-    double *Fr = nullptr;            // 16 x 4096 doubles per matrix: a panel's operand blocks in fragment order (chol_panel_operands_kernel)
-};   // flags: 4 ints per matrix (the fused panel kernel's hand-overs) or null      // a sub-batch of matrices (lstride / pstride apart) on its stream
+struct CholGroup { double *L, *diag64, *Pk; int *info; int batch; hipStream_t stream; int *flags; };   // flags: 4 ints per matrix (the fused panel kernel's hand-overs) or null      // a sub-batch of matrices (lstride / pstride apart) on its stream
 int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad, size_t lstride, int panel, size_t pstride, int nlive,
                                  int nfactor = 0, int rm_from = 0);
 int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batch, size_t lstride, double *Pk, size_t pstride,
@@ -288,7 +282,7 @@ void syrk3_plan(int Npad, int piece, std::vector<int> &tasks, std::vector<int> &
 int launch_syrk3(const double *P, double *Pk, double *C, int Npad, const int *tasks_dev, int ntasks, const int *sums_dev, int nsums, double *part,
                  hipStream_t s);
 int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
-                              const double *Pk, size_t pstride, hipStream_t s, int part = 0);
+                              const double *Pk, size_t pstride, hipStream_t s);
 // out-of-place, one fused launch per block column (plain right-looking order; `work` is destroyed)
 // Ework (identity on entry) / Eout, optional: W = L^-1 rides along -- Eout receives (L^-1)^T, blocks on and above the diagonal
 int launch_cholesky_fused(double *work, double *out, int Npad, double *diag64, int *info_dev, hipStream_t s,

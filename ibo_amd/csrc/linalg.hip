@@ -761,134 +761,6 @@ void chol_panel_rows8r_kernel(double *L, int Npad, int p0, int pend, const doubl
     }
 }
 
-// ---- The rows below a panel whose diagonal block is FINISHED (the look-ahead of launch_cholesky_batched_left), TRANSPOSED.
-// chol_panel_rows8r_kernel forms X_jj = acc_jj inv(L_jj)^T and acc_j2 -= X_jj L_j2,jj^T with the row block's tiles as the MFMA's A operand: every
-// product's result (accumulator layout) has to become the next product's A operand (fragment layout) through LDS, two barriers per product, and
-// LDS holds the row block's current X beside the operand block -- 66 KB and 20 barriers per row block, 53 % of its MFMA time busy.
-// v_mfma_f64_16x16x4 hands a lane D[(lane >> 4) + 4 r][lane & 15], r = 0 .. 3 -- and takes B[(lane >> 4)][lane & 15] per k4-step: the four result
-// registers of a 16 x 16 tile ARE the B fragments of the four k4-steps over the tile's sixteen rows.  So the transposed products
-//     X_jj^T = inv(L_jj) acc_jj^T,        acc_j2^T -= L_j2,jj X_jj^T
-// chain from register to register: A is the shared operand block (the inverse, an in-panel block of the factor), B the wave's own sixteen rows.
-// One wave owns 16 rows of the row block and all of the panel's <= 256 columns (64 accumulator registers pairs), four waves a row block; the
-// operand blocks come from Fr -- the panel's <= 10 blocks in fragment order (chol_panel_operands_kernel, once per panel and matrix) -- through a
-// double-buffered 32 KB stage of LDS: a linear copy, one barrier per operand block, no bank conflict.  X_jj leaves for the packed store
-// straight from the result registers (a lane's pairs (r, r + 1) are update3.hip's 16-byte fragments).  Per element the same products in the
-// same k4-steps in the same order as chol_panel_rows8r_kernel's (a x b against b x a under the same instruction): identical bits (tested).
-__global__ __launch_bounds__(256) void chol_panel_operands_kernel(const double *__restrict__ L, int Npad, int p0, int pend, const double *__restrict__ diag64,
-                                                                  size_t lstride, size_t dstride, double *__restrict__ Fr, size_t fstride)
-{
-    const int slot = blockIdx.x, jj = slot >> 2, j2 = slot & 3, P = pend - p0;
-    if (j2 < jj || j2 >= P) return;
-    const int z = blockIdx.z;
-    const double *M = j2 > jj ? L + z * lstride + (size_t)(p0 + j2) * 64 * Npad + (size_t)(p0 + jj) * 64 : diag64 + z * dstride + (size_t)(p0 + jj) * 4096;
-    const int ld = j2 > jj ? Npad : 64;
-    double *dst = Fr + z * fstride + (size_t)slot * 4096;
-    for (int e = threadIdx.x; e < 4096; e += 256) {
-        const int h = e & 1, l = (e >> 1) & 63, sp = (e >> 7) & 7, nb = e >> 10;
-        dst[e] = M[(size_t)(16 * nb + (l & 15)) * ld + 8 * sp + 4 * h + (l >> 4)];
-    }
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void chol_panel_rowsT_kernel(double *L, int Npad, int p0, int pend, const double *__restrict__ Fr, size_t lstride, size_t fstride,
-                             double *__restrict__ Pk, size_t pstride, int rm_from, int nrows, int batch, int chunk, int exp)
-{
-    __shared__ __attribute__((aligned(16))) double stage[2][4096];
-    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    // (workgroups go round-robin over the eight XCDs: XCD x takes the x-th eighth of the sequence "matrix 0's row blocks, matrix 1's, ..", so a
-    // matrix's operand blocks are fetched into one or two L2s, not eight)
-    const int q = chunk ? (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (q >= batch * nrows) return;
-    const int z = q / nrows, i = pend + (q - z * nrows), P = pend - p0;
-    L += z * lstride; Fr += z * fstride; Pk += z * pstride;
-    const int nk8 = Npad >> 3;
-    auto fetch = [&](int slot, d2_t (&v)[8]) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = *(const d2_t *)(Fr + (size_t)slot * 4096 + (size_t)(u * 256 + t) * 2);
-    };
-    auto stash = [&](int b, const d2_t (&v)[8]) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) *(d2_t *)&stage[b][(u * 256 + t) * 2] = v[u];
-    };
-    d2_t v[8];
-    fetch(0, v);
-    // the wave's 16 rows of the row block, transposed: acc[c][nb][r] = C[64 i + 16 w + (lane & 15)][64 (p0 + c) + 16 nb + 4 r + (lane >> 4)]
-    d4_t acc[4][4];
-    double *Ci = L + (size_t)(64 * i + 16 * w + (lane & 15)) * Npad + (size_t)p0 * 64 + (lane >> 4);
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-        if (c < P) {
-#pragma unroll
-            for (int nb = 0; nb < 4; nb++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[c][nb][r] = (exp & 2) ? 1.0 + lane : Ci[64 * c + 16 * nb + 4 * r];
-        }
-    stash(0, v);
-    __syncthreads();
-    int buf = 0;
-    const bool rowmajor = i >= rm_from;
-    double *Pw = Pk + ((size_t)(4 * i + w) * nk8 * 64 + lane) * 2;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
-        if (jj >= P) break;
-        // X_jj^T = inv(L_jj) acc_jj^T: tile nb of X's columns takes the k4-steps 0 .. 4 nb + 3 (the inverse is lower triangular)
-        {
-            const int nslot = jj + 1 < P ? 4 * jj + jj + 1 : -1;
-            if (nslot >= 0) fetch(nslot, v);
-            d4_t x[4] = {};
-            const d2_t *A = (const d2_t *)stage[buf];
-            if (!(exp & 4)) {
-#pragma unroll
-            for (int sp = 0; sp < 8; sp++)
-#pragma unroll
-                for (int nb = sp >> 1; nb < 4; nb++) {
-                    const d2_t a = A[(nb * 8 + sp) * 64 + lane];
-                    x[nb] = mfma_f64(a.x, acc[jj][sp >> 1][(2 * sp) & 3], x[nb]);
-                    x[nb] = mfma_f64(a.y, acc[jj][sp >> 1][(2 * sp + 1) & 3], x[nb]);
-                }
-            }
-#pragma unroll
-            for (int nb = 0; nb < 4; nb++) {
-#pragma unroll
-                for (int qh = 0; qh < 2; qh++) {
-                    d2_t o;
-                    o.x = x[nb][2 * qh]; o.y = x[nb][2 * qh + 1];
-                    if (!(exp & 1)) *(d2_t *)(Pw + (size_t)(8 * (p0 + jj) + 2 * nb + qh) * 128) = o;
-                }
-                if (rowmajor) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) Ci[64 * jj + 16 * nb + 4 * r] = x[nb][r];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[jj][nb][r] = -x[nb][r];            // (acc_jj's registers now hold -X_jj^T: the B fragments of the updates)
-            }
-            if (nslot >= 0) stash(buf ^ 1, v);
-            __syncthreads();
-            buf ^= 1;
-        }
-        // acc_j2^T -= L_j2,jj X_jj^T
-#pragma unroll
-        for (int j2 = 1; j2 < 4; j2++) {
-            if (j2 <= jj || j2 >= P) continue;
-            const int nslot = j2 + 1 < P ? 4 * jj + j2 + 1 : (jj + 1 < P ? 5 * (jj + 1) : -1);
-            if (nslot >= 0) fetch(nslot, v);
-            const d2_t *A = (const d2_t *)stage[buf];
-            if (!(exp & 4)) {
-#pragma unroll
-            for (int sp = 0; sp < 8; sp++)
-#pragma unroll
-                for (int nb = 0; nb < 4; nb++) {
-                    const d2_t a = A[(nb * 8 + sp) * 64 + lane];
-                    acc[j2][nb] = mfma_f64(a.x, acc[jj][sp >> 1][(2 * sp) & 3], acc[j2][nb]);
-                    acc[j2][nb] = mfma_f64(a.y, acc[jj][sp >> 1][(2 * sp + 1) & 3], acc[j2][nb]);
-                }
-            }
-            if (nslot >= 0) stash(buf ^ 1, v);
-            __syncthreads();
-            buf ^= 1;
-        }
-    }
-}
-
 static void launch_update(double *L, int Npad, int j0, int j1, int k0, int k1, int batch, size_t lstride,
                           hipStream_t s, const double *P = nullptr, int iend = 0)
 {
@@ -1047,19 +919,14 @@ __device__ __forceinline__ bool panel_wait(const int *flag, int want, int *info)
 }
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void chol_panel_fused_kernel(double *L, int Npad, int p0, int pend, double *__restrict__ diag64, int *info, size_t lstride, size_t dstride,
-                             double *__restrict__ Pk, size_t pstride, int rm_from, int batch, int nrows, int *flags, int part)
+                             double *__restrict__ Pk, size_t pstride, int rm_from, int batch, int nrows, int *flags)
 {
     __shared__ double lds[3 * 64 * SD];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wr8 = wv >> 1, wc8 = wv & 1;
     const int P = pend - p0, want = p0 + 1;
-    // part 0: the launch holds the diagonal workgroups and, behind them, the row workgroups; 1: the diagonal workgroups alone; 2: the row
-    // workgroups alone (the diagonal blocks were factored by an earlier launch: every flag is up, no wait lasts)
-    const int bx = (int)blockIdx.x + (part == 2 ? batch : 0);
-    if (bx < batch) {
+    if ((int)blockIdx.x < batch) {
         // ---------------- a diagonal block (chol_panel_diag_kernel's body, publishing after each column's row blocks)
-        const int z = bx;
-        // (beside another stream's update launches these eight waves share their SIMDs with MFMA-bound waves: the chain's instructions go first)
-        __builtin_amdgcn_s_setprio(3);
+        const int z = blockIdx.x;
         double *S = lds, *V = lds + 64 * SD, *T = lds + 2 * 64 * SD;
         L += z * lstride; diag64 += z * dstride; info += z; flags += 4 * z;
         auto blk = [&](int r, int c) { return L + (size_t)(p0 + r) * 64 * Npad + (size_t)(p0 + c) * 64; };
@@ -1137,7 +1004,7 @@ void chol_panel_fused_kernel(double *L, int Npad, int p0, int pend, double *__re
         return;
     }
     // ---------------- two row blocks below the panel
-    const int nrw = (nrows + 1) / 2, rb = bx - batch, z = rb / nrw, pair = rb - z * nrw;
+    const int nrw = (nrows + 1) / 2, rb = (int)blockIdx.x - batch, z = rb / nrw, pair = rb - z * nrw;
     double *Xc0 = lds, *Xc1 = lds + 64 * SD, *Bs = lds + 2 * 64 * SD;
     L += z * lstride; diag64 += z * dstride; info += z; flags += 4 * z;
     if (Pk) Pk += z * pstride;
@@ -1257,7 +1124,7 @@ static bool chol_inpanel(double *L, int Npad, int p0, int pend, double *diag64, 
         // (flags: four ints per matrix, zero at the start of the factorisation)
         const int nrows = nb - pend, nrw = (nrows + 1) / 2;
         hipLaunchKernelGGL(chol_panel_fused_kernel, dim3((unsigned)(batch + batch * nrw)), dim3(512), 0, s, L, Npad, p0, pend, diag64, info_dev, lstride,
-                           dstride, Pk, pstride, rm_from, batch, nrows, flags, 0);
+                           dstride, Pk, pstride, rm_from, batch, nrows, flags);
         return Pk != nullptr;
     }
     if (rows_fused)
@@ -1336,37 +1203,6 @@ int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad,
         for (int g = 0; g < ngroups; g++) {
             const CholGroup &G = groups[g];
             if (G.batch <= 0) continue;
-            // LOOK-AHEAD (a sub-batch with a side stream): the panel's diagonal block -- three tiles per matrix, each as deep as the whole update --
-            // is brought up to date and factored on the side stream while the main stream updates the rows below it; the rows then run as a
-            // launch of their own that waits for nothing (chol_panel_rowsT_kernel).  In one launch (chol_panel_fused_kernel) the row
-            // workgroups must reach the diagonal workgroups' blocks past the L2 and keep a CU each while they wait.  The same products in the
-            // same order per element: the same bits.
-            if (G.side && G.Fr && p0 < tail && pend - p0 <= 4 && pend < nfactor && (size_t)(nb - pend) * G.batch >= 256 &&
-                (size_t)Npad * Npad * sizeof(double) <= 0x7fffffffu) {
-                const int nrows = nb - pend;
-                const size_t dstride = (size_t)nb * 4096, fstride = (size_t)16 * 4096;
-                hipStream_t sd = p0 > 0 ? G.side : G.stream;          // (the first panel has no update to run beside)
-                if (p0 > 0) {
-                    HIPCHK(hipStreamWaitEvent(G.side, G.ev[0], 0));
-                    int rc = launch_chol_update3_range(G.L, Npad, 64 * p0, 64 * (pend - p0), 0, 64 * p0, nlive, G.batch, lstride, G.Pk, pstride, G.side, 1);
-                    if (rc) return rc;
-                }
-                hipLaunchKernelGGL(chol_panel_fused_kernel, dim3((unsigned)G.batch), dim3(512), 0, sd, G.L, Npad, p0, pend, G.diag64, G.info, lstride,
-                                   dstride, G.Pk, pstride, rm_from, G.batch, nrows, G.flags, 1);
-                hipLaunchKernelGGL(chol_panel_operands_kernel, dim3(16, 1, G.batch), dim3(256), 0, sd, G.L, Npad, p0, pend, G.diag64, lstride, dstride, G.Fr, fstride);
-                if (p0 > 0) {
-                    HIPCHK(hipEventRecord(G.ev[1], G.side));
-                    int rc = launch_chol_update3_range(G.L, Npad, 64 * p0, 64 * (pend - p0), 0, 64 * p0, nlive, G.batch, lstride, G.Pk, pstride, G.stream, 2);
-                    if (rc) return rc;
-                    HIPCHK(hipStreamWaitEvent(G.stream, G.ev[1], 0));
-                }
-                const long long total = (long long)G.batch * nrows;
-                const int chunk = G.batch >= 8 ? (int)((total + 7) / 8) : 0;
-                hipLaunchKernelGGL(chol_panel_rowsT_kernel, dim3((unsigned)(chunk ? 8 * chunk : total)), dim3(256), 0, G.stream, G.L, Npad, p0, pend, G.Fr, lstride, fstride,
-                                   G.Pk, pstride, rm_from, nrows, G.batch, chunk, getenv("IBO_EXP") ? atoi(getenv("IBO_EXP")) : 0);
-                HIPCHK(hipEventRecord(G.ev[0], G.stream));
-                continue;
-            }
             if (p0 > 0 && p0 <= tail) {
                 const int width = p0 == tail ? 64 * (nfactor - p0) : 64 * (pend - p0);
                 int rc = launch_chol_update3_range(G.L, Npad, 64 * p0, width, 0, 64 * p0, nlive, G.batch, lstride, G.Pk, pstride, G.stream);
@@ -1384,7 +1220,6 @@ int launch_cholesky_batched_left(const CholGroup *groups, int ngroups, int Npad,
                 int rc = launch_chol_update3_range(G.L, Npad, 64 * pend, 64 * (nfactor - pend), 64 * p0, 64 * pend, nlive, G.batch, lstride, G.Pk, pstride, G.stream);
                 if (rc) return rc;
             }
-            if (G.side && p0 == 0) HIPCHK(hipEventRecord(G.ev[0], G.stream));      // (the first panel went the other way -- few rows --: the side stream may start on the second)
         }
     }
     return (int)hipGetLastError();

@@ -138,7 +138,7 @@ __device__ __forceinline__ void u3_row_block(double *L, int Npad, int c0, int nc
 __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, int Npad, int c0, int ncb, int nlive_rb,
                                                                   const double *Pk, size_t lstride, size_t pstride,
                                                                   int tpm, int ntc, int batch, int chunk, int rowtile, int kb8, int K,
-                                                                  const int4 *__restrict__ tasks, double *__restrict__ part, int toff, int tfull)
+                                                                  const int4 *__restrict__ tasks, double *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) double lds_b[2][U3_KS / 8 * 8 * 128];      // [stage][k8-step][column-block][lane][2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -155,12 +155,10 @@ __global__ __launch_bounds__(U3_NW * 64, 4) void chol_update3_kernel(double *L, 
         const int4 tk = tasks[blockIdx.x];          // tile, first k8-step, columns, slot (0: C itself)
         q = tk.x; kb8 = tk.y; K = tk.z; pslot = tk.w;
     } else if ((chunk && (int)(blockIdx.x >> 3) >= chunk) || q >= batch * tpm) return;
-    // (a launch may hold a part of the matrices' tile sequences only: tpm entries per matrix from entry toff on, of tfull -- the look-ahead
-    // of launch_cholesky_batched_left brings a panel's diagonal block up to date in a launch of its own)
-    const int m = q / tpm, t = q - m * tpm + toff;
+    const int m = q / tpm, t = q - m * tpm;
     L += (size_t)m * lstride; Pk += (size_t)m * pstride;
-    if (rowtile && t >= tfull - rowtile) {               // the matrix's last entries: the lone live row-block below the full tiles,
-        const int ri = t - (tfull - rowtile);            // 16 column-blocks (256 columns) per workgroup
+    if (rowtile && t >= tpm - rowtile) {                 // the matrix's last entries: the lone live row-block below the full tiles,
+        const int ri = t - (tpm - rowtile);              // 16 column-blocks (256 columns) per workgroup
         u3_row_block(L, Npad, c0 + 256 * ri, ncb - 16 * ri < 16 ? ncb - 16 * ri : 16, nlive_rb - 1, Pk, wave, lane, kb8, K);
         return;
     }
@@ -318,9 +316,8 @@ int launch_chol_pack3(const double *L, int Npad, int r0, int c0, int K, int batc
 }
 
 // region: rows >= c0 (live ones), columns [c0, c0 + width), updated with the packed columns [kbeg, kend) (multiples of 64)
-// part: 0 the whole region; 1 the tiles of its diagonal block only (rows < c0 + width); 2 the rest
 int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, int kend, int nlive, int batch, size_t lstride,
-                                 const double *Pk, size_t pstride, hipStream_t s, int part)
+                                 const double *Pk, size_t pstride, hipStream_t s)
 {
     if (width <= 0 || kend <= kbeg) return 0;
     const int nlive_rb = (nlive + 15) / 16;
@@ -333,13 +330,11 @@ int launch_chol_update3_range(double *L, int Npad, int c0, int width, int kbeg, 
     const int nrt = rowtile ? rows / 128 : (rows + 127) / 128;
     int ntc = (width + 127) / 128;
     if (ntc > nrt) ntc = nrt;                                // tile columns beyond the last tile row lie above the diagonal
-    const int tfull = ntc * (ntc + 1) / 2 + (nrt - ntc) * ntc + rowtile, tri = ntc * (ntc + 1) / 2;
-    const int toff = part == 2 ? tri : 0, tpm = part == 1 ? tri : tfull - toff;
-    if (tpm <= 0) return 0;
+    const int tpm = ntc * (ntc + 1) / 2 + (nrt - ntc) * ntc + rowtile;
     const long long total = (long long)tpm * batch;
     const int chunk = batch >= 8 ? (int)((total + 7) / 8) : 0;
     hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)(chunk ? 8 * chunk : total)), dim3(U3_NW * 64), 0, s, L, Npad, c0, ncb, nlive_rb, Pk,
-                       lstride, pstride, tpm, ntc, batch, chunk, rowtile, kbeg / 8, kend - kbeg, (const int4 *)nullptr, (double *)nullptr, toff, tfull);
+                       lstride, pstride, tpm, ntc, batch, chunk, rowtile, kbeg / 8, kend - kbeg, (const int4 *)nullptr, (double *)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -433,7 +428,7 @@ int launch_syrk3(const double *P, double *Pk, double *C, int Npad, const int *ta
     hipLaunchKernelGGL(syrk3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, Npad, Pk);
     const int nt = (Npad + 127) / 128;
     hipLaunchKernelGGL(chol_update3_kernel, dim3((unsigned)ntasks), dim3(U3_NW * 64), 0, s, C, Npad, 0, Npad / 16, Npad / 16, (const double *)Pk,
-                       (size_t)0, (size_t)0, nt * (nt + 1) / 2, nt, 1, 0, 0, 0, 0, (const int4 *)tasks_dev, part, 0, nt * (nt + 1) / 2);
+                       (size_t)0, (size_t)0, nt * (nt + 1) / 2, nt, 1, 0, 0, 0, 0, (const int4 *)tasks_dev, part);
     if (nsums) hipLaunchKernelGGL(syrk3_sum_kernel, dim3((unsigned)nsums, 8), dim3(256), 0, s, C, Npad, (const double *)part, (const int4 *)sums_dev);
     return (int)hipGetLastError();
 }
