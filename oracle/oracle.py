@@ -61,6 +61,8 @@ def lib():
         path = os.path.join(_HERE, "_build", "liboracle.so")
         if not os.path.exists(path):
             build()
+        # (tools/sanitize_oracle.sh points this at a -fsanitize build of the same source)
+        path = os.environ.get("IBO_ORACLE_LIB") or path
         L = ctypes.CDLL(path)
         L.orc_cov.restype = c_double
         L.orc_cov.argtypes = [c_int, c_int, _DP, _DP, _DP, c_double]
