@@ -550,6 +550,18 @@ __global__ __launch_bounds__(256) void nlml_grad_kernel(KParams kp, GradSpec gs,
 // then one short loop per derivative: a length scale of an ARD kernel is one more pass over ITS dimension (acc_h = sum_pairs t_ab w_h u_h^2),
 // the others need only z, d2 and K.  The sum over (a, b) is symmetric: tiles above the diagonal contribute nothing, tiles below it count
 // twice (an exact scaling).  Per-workgroup partial sums in a fixed order, as before.
+// the wave's 64 values summed in a fixed order without a trip through the LDS crossbar: four DPP steps inside the rows of 16 lanes (xor 1, xor 2,
+// half-row mirror, row mirror), then the four row sums, first to last
+__device__ __forceinline__ double wave_sum_rows(double v)
+{
+#define WS_STEP(ctrl) { const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true), \
+                                  hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true); v += __hiloint2double(hi, lo); }
+    WS_STEP(0xB1) WS_STEP(0x4E) WS_STEP(0x141) WS_STEP(0x140)
+#undef WS_STEP
+    auto row = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+    return ((row(0) + row(16)) + row(32)) + row(48);
+}
+
 template <int GM, int LD>
 __global__ __launch_bounds__(256) void nlml_grad_fast_kernel(KParams kp, GradSpec gs, int N, const double *__restrict__ X, int ldx,
                                                              const double *__restrict__ Kinv, int ldk, const double *__restrict__ alpha,
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(256) void nlml_grad_fast_kernel(KParams kp, GradSpe
                     s = fma(kk[r][c], (a == b) ? 0.0 : dk, s);
                 }
         }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = wave_sum_rows(s);
         if (lane == 0) red[h][wave] = s;
     }
     __syncthreads();
