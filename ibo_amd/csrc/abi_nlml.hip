@@ -13,12 +13,16 @@ struct NlmlWorkspace {
     hipEvent_t t0[4] = {nullptr, nullptr, nullptr, nullptr}, t1[4] = {nullptr, nullptr, nullptr, nullptr};     // a sub-batch's span on its stream (ibo_gpu_time_ms)
 };
 static NlmlWorkspace g_nlml_ws[16];
-static const int kSyrk3From = 2560;          // rows from which ibo_nlml_grad forms K^-1 = W^T W on the packed-operand kernel (launch_syrk3)
+static const int kSyrk3From = 1792;          // rows from which ibo_nlml_grad forms K^-1 = W^T W on the packed-operand kernel (launch_syrk3)
 struct GradWorkspace {
     DevBuf<double> dX, dY, dL, dW, dT, dKi, d64, dal, da1, tmp, dpart, dout, dpiece, tall, Pk2;     // tall, Pk2: the super-panel order's (launch_cholesky_super)
     DevBuf<int> dinfo, dtasks, dsums;
     int plan_Np = 0, ntasks = 0, nsums = 0;         // launch_syrk3's lists on the device, for this Npad
     hipEvent_t t0 = nullptr, t1 = nullptr;          // the evaluation's span on the device (ibo_gpu_time_ms)
+    // a learning loop calls with the same data and another theta dozens of times: what is on the device is kept (compared by content) and
+    // the results come back through one pinned block behind one synchronisation
+    std::vector<double> hostX, hostY;
+    double *pin = nullptr;                          // IBO_GRAD_MAX + 4 doubles: gradient, two scalars, the info word
 };
 static GradWorkspace g_grad_ws[16];
 
@@ -37,6 +41,8 @@ extern "C" int ibo_trim(int device)
     gw.dX.release(); gw.dY.release(); gw.dL.release(); gw.dW.release(); gw.dT.release(); gw.dKi.release(); gw.d64.release();
     gw.dal.release(); gw.da1.release(); gw.tmp.release(); gw.dpart.release(); gw.dout.release(); gw.dinfo.release();
     gw.dpiece.release(); gw.dtasks.release(); gw.dsums.release(); gw.plan_Np = 0; gw.tall.release(); gw.Pk2.release();
+    gw.hostX.clear(); gw.hostY.clear();              // (dX / dY went back to the pool: nothing of this data is on the device any more)
+    if (gw.pin) { (void)hipHostFree(gw.pin); gw.pin = nullptr; }
     pool_trim(device);
     return IBO_OK;
 }
@@ -220,10 +226,19 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     IBO_TRY(dal.ensure(Np)); IBO_TRY(da1.ensure(Np)); IBO_TRY(tmp.ensure(2 * (size_t)Np + 2 * (size_t)(Np / 64) * Np + 64));
     IBO_TRY(dpart.ensure((size_t)ngrad * nblk)); IBO_TRY(dout.ensure(ngrad + 2)); IBO_TRY(dinfo.ensure(1));
     hipStream_t s = nullptr;
-    std::vector<double> yp(Np, 0.0);
-    for (int i = 0; i < N; i++) yp[i] = Y[i];
-    HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dY.p, yp.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
+    if (ws.hostX.size() != (size_t)N * D || memcmp(ws.hostX.data(), X, sizeof(double) * N * D) != 0) {
+        ws.hostX.clear();                            // (not valid while the copy is in flight or if it fails)
+        HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * D, hipMemcpyHostToDevice));
+        ws.hostX.assign(X, X + (size_t)N * D);
+    }
+    if (ws.hostY.size() != (size_t)Np || memcmp(ws.hostY.data(), Y, sizeof(double) * N) != 0) {
+        std::vector<double> yp(Np, 0.0);
+        for (int i = 0; i < N; i++) yp[i] = Y[i];
+        ws.hostY.clear();
+        HIP_TRY(hipMemcpy(dY.p, yp.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
+        ws.hostY.swap(yp);
+    }
+    if (!ws.pin) HIP_TRY(hipHostMalloc((void **)&ws.pin, sizeof(double) * (IBO_GRAD_MAX + 4), hipHostMallocDefault));
     // up to 2048 rows: the fit's route -- fused steps with W = L^-1 riding along (dT: the matrix being reduced, dKi: (L^-1)^T
     // until the transpose) -- instead of the three-kernel columns and the recursive-doubling inversion
     const bool fused = single_level_order(Np);
@@ -254,12 +269,14 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     const double *Kinv = fused ? dT.p : dKi.p;
     KERNEL_TRY(launch_nlml_scalars(dL.p, Np, N, dY.p, dal.p, dout.p + ngrad, s));        // (y . alpha, sum log L_ii): L has been read for the last time
     if (fused && Np >= kSyrk3From) {
-        // from 2560 rows the product runs on the packed-operand kernel (128 x 128 tiles, A fragments straight from L2), its long K ranges in pieces;
-        // the packed copy of W^T goes where L was
+        // from 1792 rows the product runs on the packed-operand kernel (128 x 128 tiles, A fragments straight from L2), its long K ranges in pieces
+        // of 256 columns below 2560 rows, 512 below 4096, 1024 from there (measured: 0.692 -> 0.668 ms per evaluation at N = 1792, 0.809 -> 0.766 at
+        // 2048, 1.028 -> 1.002 at 2560, 1.436 -> 1.400 at 3072; below 1792 rows wtw_kernel's 64 x 64 tiles are as fast); the packed copy of W^T
+        // goes where L was
         if (ws.plan_Np != Np) {
             std::vector<int> tasks, sums;
             int nslots = 0;
-            syrk3_plan(Np, 1024, tasks, sums, &nslots);
+            syrk3_plan(Np, Np < 2560 ? 256 : (Np < 4096 ? 512 : 1024), tasks, sums, &nslots);
             IBO_TRY(ws.dtasks.ensure(tasks.size())); IBO_TRY(ws.dsums.ensure(sums.size() + 4)); IBO_TRY(ws.dpiece.ensure((size_t)(nslots + 1) * 16384));
             HIP_TRY(hipMemcpy(ws.dtasks.p, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice));
             if (!sums.empty()) HIP_TRY(hipMemcpy(ws.dsums.p, sums.data(), sizeof(int) * sums.size(), hipMemcpyHostToDevice));
@@ -270,10 +287,12 @@ extern "C" int ibo_nlml_grad(int device, int ktype, int N, int D, const double *
     else KERNEL_TRY(launch_wtw(dW.p, dT.p, dKi.p, Np, s, 1));
     KERNEL_TRY(launch_nlml_grad(kp, gs, N, dX.p, D, Kinv, Np, dal.p, dpart.p, dout.p, s));
     HIP_TRY(hipEventRecord(ws.t1, s));
-    std::vector<double> res(ngrad + 2);
+    HIP_TRY(hipMemcpyAsync(ws.pin, dout.p, sizeof(double) * (ngrad + 2), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ws.pin + IBO_GRAD_MAX + 2, dinfo.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double *res = ws.pin;
     int h = 0;
-    HIP_TRY(hipMemcpy(res.data(), dout.p, sizeof(double) * (ngrad + 2), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&h, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+    memcpy(&h, ws.pin + IBO_GRAD_MAX + 2, sizeof(int));
     { float ms = 0.f; if (hipEventElapsedTime(&ms, ws.t0, ws.t1) == hipSuccess) gpu_time_add(device, ms); }
     if (h != 0) return fail(IBO_ERR_NOT_PD, "covariance matrix is not positive definite (pivot %d)", h);
     for (int i = 0; i < ngrad; i++) grad_host[i] = res[i];

@@ -1463,6 +1463,37 @@ def test_nlml_gradient_against_the_oracle_every_family(ibo):
         assert abs(v - ov) <= 1e-9 * abs(ov) and np.abs(np.atleast_1d(g) - np.atleast_1d(od)).max() <= 1e-7 * np.abs(od).max(), (type(k).__name__, g, od)
 
 
+def test_nlml_gradient_keeps_its_data_on_the_device_only_while_it_is_the_same_data(ibo):
+    """ibo_nlml_grad (abi_nlml.hip) leaves X and Y on the device between calls and uploads them again when their CONTENT differs (a learning
+    loop calls it dozens of times with one data set and another theta): the same data twice, then other targets, other points and another
+    size in the same shapes' buffers, then the first data again and after ibo_trim -- every value and gradient against the oracle"""
+    import oracle.oracle as orc
+    from ibo_amd import _lib
+    from ibo_amd.gaussianprocess import kernel as K
+    from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
+    D = 3
+    XA, YA = synth(911, 300, D)
+    XB, YB = synth(912, 300, D)
+    XC, YC = synth(913, 290, D)
+    def check(X, Y, theta):
+        v, g = marginalLikelihood(K.GaussianKernel_ard(theta), X, Y, D, True, noise=1e-2)
+        ov, od = orc.marginal_likelihood(orc.Kern("ard", theta), X, Y, D, True, 1e-2)
+        assert abs(v - ov) <= 1e-9 * abs(ov) and np.abs(np.asarray(g) - np.asarray(od)).max() <= 1e-8 * np.abs(od).max()
+        return v
+    v1 = check(XA, YA, [.4, .5, .6])
+    assert check(XA.copy(), YA.copy(), [.4, .5, .6]) == v1      # the same content at another address: nothing uploaded, the same bits
+    check(XA, YA, [.5, .5, .7])
+    check(XA, YB, [.4, .5, .6])                                  # other targets
+    check(XB, YB, [.4, .5, .6])                                  # other points
+    Y2 = YB.copy(); Y2[-1] += 1e-9
+    check(XB, Y2, [.4, .5, .6])                                  # one target's last bits
+    check(XC, YC, [.4, .5, .6])                                  # fewer rows (the buffers stay)
+    check(XA[:290], YA[:290], [.4, .5, .6])                      # the same size as the call before, other content
+    assert check(XA, YA, [.4, .5, .6]) == v1
+    _lib.check(_lib.lib.ibo_trim(0))
+    assert check(XA, YA, [.4, .5, .6]) == v1
+
+
 def test_single_level_fit_at_every_launch_shape(ibo):
     """fits below 104 block columns: fused steps (up to three block columns), pipelined block columns with one step per pass over the trailing
     tiles (4 .. 11 block columns) and with two (from 12), W = L^-1 riding along: L against NumPy's Cholesky of GP.R, W L = I; the NLML
@@ -1490,16 +1521,17 @@ def test_single_level_fit_at_every_launch_shape(ibo):
             GaussianProcess(GaussianKernel_ard([.3, .4, .5]), Xd, Y, noise=0.0)
 
 
-def test_nlml_gradient_from_2560_rows_on_the_packed_operand_product(ibo):
-    """from 2560 rows ibo_nlml_grad forms K^-1 = W^T W on chol_update3_kernel (csrc/update3.hip launch_syrk3: W^T packed into fragment order,
-    128 x 128 tiles, K ranges beyond ~1280 columns in pieces that are summed in a fixed order): value and gradient against the oracle
-    (ego/gaussianprocess/trainhyper.py:47-95) where the last tile row is 64 rows (2600 -> 2624) and where it is whole (2688), an evaluation
-    repeated bit for bit, and the sizes below the switch unchanged by it"""
+def test_nlml_gradient_from_1792_rows_on_the_packed_operand_product(ibo):
+    """from 1792 rows ibo_nlml_grad forms K^-1 = W^T W on chol_update3_kernel (csrc/update3.hip launch_syrk3: W^T packed into fragment order,
+    128 x 128 tiles, long K ranges in pieces -- of 256 columns below 2560 rows, 512 below 4096, 1024 from there -- that are summed in a fixed
+    order): value and gradient against the oracle (ego/gaussianprocess/trainhyper.py:47-95) at the first size of the route (1729 -> 1792), in
+    the 256-piece range where the last tile row is 64 rows (1990 -> 2048 is whole; 2100 -> 2112 is not), in the 512-piece range where it is
+    64 rows (2600 -> 2624) and where it is whole (2688), and just below the switch (1728, wtw_kernel); an evaluation repeated bit for bit"""
     import oracle.oracle as orc
     from ibo_amd.gaussianprocess.kernel import GaussianKernel_ard
     from ibo_amd.gaussianprocess.trainhyper import marginalLikelihood
     theta = [.5, .7, .9, 1.1]
-    for N in (2600, 2688):
+    for N in (1728, 1729, 1990, 2100, 2600, 2688):
         X, Y = synth(N + 7, N, 4)
         v, g = marginalLikelihood(GaussianKernel_ard(theta), X, Y, 4, True, noise=1e-2)
         ov, od = orc.marginal_likelihood(orc.Kern("ard", theta), X, Y, 4, True, 1e-2)
