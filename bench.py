@@ -592,7 +592,7 @@ def worker(args):
                     ng["N%d_D%d" % (n, d)] = {"ms": per, "first_call_ms": ms[0],
                                               "roofline": attach_pmc(roofline_mfma(fl, per * 1e-3, flops_per_evaluation=fl,
                                                                                    algorithmic_bytes_per_evaluation=8 * n * d + 4 * 8 * n * n,
-                                                                                   kernels="cov_fit + chol_pipe8 (W riding along; super-panels + chol_update3 from 4096 rows) + transpose_pack + K^-1 = W^T W (wtw_kernel; from 2560 rows syrk3_pack + chol_update3 in pieces + syrk3_sum) + nlml_grad_fast + reductions"),
+                                                                                   kernels="cov_fit + chol_pipe8 (W riding along; super-panels + chol_update3 from 4096 rows) + transpose_pack + K^-1 = W^T W (wtw_kernel; from 1792 rows syrk3_pack + chol_update3 in pieces + syrk3_sum) + nlml_grad_fast + reductions"),
                                                                      "learn%d" % n)}
                 cfgs["nlml_grad"] = {"workload": "one marginalLikelihood(..., computeGradient=True) evaluation, SE-ARD, D = 16 length scales, host X, Y in, value + gradient out (wall, median of 5)",
                                      "results": ng}
