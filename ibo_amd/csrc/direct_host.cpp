@@ -311,7 +311,100 @@ void make_division(const Pool &pool, size_t j, Division &dv)      // dv is reuse
 // never becomes a class minimum and equal infinities are rejected by the suffix-minimum test.  The GP acquisitions
 // this search is run on are finite by construction (clamped variance, finite means); a host callback that returns
 // NaN or inf gets a well-defined search, not the reference's trajectory.
+// Two things keep the test off most classes.  (1) The decision is a function of (y, d) alone: it is taken once per CLASS -- for the class's best
+// value -- and holds for every member that attains it.  (2) A class that is not a vertex of the lower convex hull of the points (d, best y) has
+// two hull vertices around it, h1 smaller and h2 larger, and in exact arithmetic the slope from h1 exceeds the slope to h2: the full test would
+// find minI2 < maxI1.  In floating point that is not a proof -- but the full test's maxI1 is a maximum over the very quotient s1 formed here and its
+// minI2 a minimum over the very quotient s2, so "s2 <= 0" or "s1 > DBL_MIN and s2 < s1" IS one (minI2 <= s2 < s1 <= maxI1): such a class is
+// rejected by two divisions instead of one per class; everything else -- hull vertices, near-ties, NaNs -- takes the full test.  The hull itself
+// is only a way of finding good witnesses: no decision rests on how it was rounded.  The same set in the same (pool) order as the full test on
+// every candidate (potentially_optimal_ref, compared call by call under IBO_DIRECT_SELFCHECK: tools/direct_host_check.cpp).
 void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out)
+{
+    const double eps = 10e-10;
+    const double *Y = pool.y.data(), *Dd = pool.d.data();
+    out.clear();
+    // (scratch kept between calls: this runs once per iteration of every search)
+    static thread_local std::vector<double> gd, gy, sufmin;    // the classes that have members, ascending d; their smallest y; min of gy beyond
+    static thread_local std::vector<int> gc, hull, before;     // their class numbers; the hull's vertices; the last hull vertex at or before g
+    gd.clear(); gy.clear(); gc.clear();
+    for (int c : pool.by_size)
+        if (!pool.members[c].empty()) { gc.push_back(c); gd.push_back(pool.cls_d[c]); gy.push_back(pool.cls_best[c]); }
+    const size_t G = gd.size();
+    // A rectangle is rejected as soon as some LARGER class holds a value <= its own (the slope to it is <= 0: minI2 <= 0).
+    // With the minimum of gy over the larger classes at hand that is one comparison, and it removes all but the few classes on
+    // the descending staircase before any slope is formed -- the same decisions as forming them all (a quotient with a positive
+    // denominator is <= 0 exactly when its numerator is).  NaN values fall through to the full test.
+    sufmin.assign(G + 1, DBL_MAX);
+    for (size_t h = G; h-- > 0;) sufmin[h] = (gy[h] < sufmin[h + 1] || gy[h] != gy[h]) ? gy[h] : sufmin[h + 1];
+    // lower hull by the monotone chain (a vertex that lies on or above the segment around it is dropped)
+    hull.clear();
+    before.assign(G, 0);
+    for (size_t g = 0; g < G; g++) {
+        while (hull.size() >= 2) {
+            const int a = hull[hull.size() - 2], b = hull.back();
+            if ((gy[b] - gy[a]) * (gd[g] - gd[a]) >= (gy[g] - gy[a]) * (gd[b] - gd[a])) hull.pop_back();
+            else break;
+        }
+        hull.push_back((int)g);
+    }
+    for (size_t k = 0; k < hull.size(); k++) {
+        const size_t g1 = k + 1 < hull.size() ? (size_t)hull[k + 1] : G;
+        for (size_t g = (size_t)hull[k]; g < g1; g++) before[g] = (int)k;
+    }
+    for (size_t g = 0; g < G; g++) {
+        if (g + 1 < G && sufmin[g + 1] <= gy[g]) continue;      // every member of the class fails the minI2 test
+        const std::vector<int> &am = pool.argmin[gc[g]];
+        if (am.empty()) continue;
+        const size_t j = (size_t)am[0];
+        const double yj = Y[j], dj = Dd[j];
+        const size_t k = (size_t)before[g];
+        if ((size_t)hull[k] != g && k + 1 < hull.size()) {      // not a vertex: the two vertices around it as witnesses
+            const size_t h1 = (size_t)hull[k], h2 = (size_t)hull[k + 1];
+            const double s2 = (gy[h2] - yj) / (gd[h2] - dj);
+            if (s2 <= 0.) continue;
+            const double s1 = (yj - gy[h1]) / (dj - gd[h1]);
+            if (s1 > DBL_MIN && s2 < s1) continue;
+        }
+        // (the slopes two at a time: SSE2 is the x86-64 baseline, a division per class and candidate was 5 us of every iteration; the
+        // quotients are the scalar ones and a maximum / minimum of finite values does not depend on the order it is taken in)
+        double maxI1 = DBL_MIN, minI2 = DBL_MAX;
+        {
+            const __m128d vy = _mm_set1_pd(yj), vd = _mm_set1_pd(dj);
+            __m128d mn = _mm_set1_pd(DBL_MAX);
+            size_t h = g + 1;
+            for (; h + 2 <= G; h += 2)
+                mn = _mm_min_pd(_mm_div_pd(_mm_sub_pd(_mm_loadu_pd(&gy[h]), vy), _mm_sub_pd(_mm_loadu_pd(&gd[h]), vd)), mn);
+            for (; h < G; h++) { const double v = (gy[h] - yj) / (gd[h] - dj); if (v < minI2) minI2 = v; }
+            double t[2];
+            _mm_storeu_pd(t, mn); if (t[0] < minI2) minI2 = t[0]; if (t[1] < minI2) minI2 = t[1];
+            // (the slopes from the smaller classes only matter through "is one of them above minI2": not formed for a rectangle the test
+            // below rejects anyway, and the scan stops at the first that is)
+            if (minI2 > 0. && minI2 != DBL_MAX) {
+                bool above = false;                     // the rejection below already holds (the maximum only grows: it keeps holding)
+                for (h = 0; h + 2 <= g && !above; h += 2) {
+                    _mm_storeu_pd(t, _mm_div_pd(_mm_sub_pd(vy, _mm_loadu_pd(&gy[h])), _mm_sub_pd(vd, _mm_loadu_pd(&gd[h]))));
+                    if (t[0] > maxI1) maxI1 = t[0];
+                    if (t[1] > maxI1) maxI1 = t[1];
+                    above = maxI1 != DBL_MIN && minI2 < maxI1;
+                }
+                for (; h < g && !above; h++) { const double v = (yj - gy[h]) / (dj - gd[h]); if (v > maxI1) maxI1 = v; above = maxI1 != DBL_MIN && minI2 < maxI1; }
+            }
+        }
+        if (minI2 <= 0.) continue;
+        if (maxI1 != DBL_MIN && minI2 != DBL_MAX && minI2 < maxI1) continue;
+        bool take;
+        if (minI2 == DBL_MAX) take = true;
+        else if (fmin == 0.0) take = (yj <= dj * minI2);
+        else take = (eps <= (fmin - yj) / std::fabs(fmin) + (dj / std::fabs(fmin)) * minI2);
+        if (take) for (int m : am) out.push_back((size_t)m);
+    }
+    std::sort(out.begin(), out.end());             // pool order: the order the reference collects them in
+}
+
+#ifdef IBO_DIRECT_SELFCHECK
+// the full test on every candidate rectangle, as it stood before the per-class decision and the hull witnesses: the comparator
+void potentially_optimal_ref(const Pool &pool, double fmin, std::vector<size_t> &out)
 {
     const double eps = 10e-10;
     const size_t n = pool.size();
@@ -381,6 +474,8 @@ void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out
     }
 }
 
+#endif
+
 }  // namespace
 
 DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, const double *ub,
@@ -446,6 +541,13 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
     while (iteration < opt.maxiter && !done) {
         iteration++;
         potentially_optimal(pool, S.fmin, pot);
+#ifdef IBO_DIRECT_SELFCHECK
+        {
+            std::vector<size_t> chk;
+            potentially_optimal_ref(pool, S.fmin, chk);
+            if (chk != pot) { fprintf(stderr, "direct_host.cpp: potentially_optimal disagrees with its comparator (%zu against %zu rectangles)\n", pot.size(), chk.size()); abort(); }
+        }
+#endif
         if (pot.empty()) {
             printf("[cdirect] could not divide any more\n");
             break;

@@ -3,6 +3,8 @@
 //                                        cannot run under a sanitizer on this pool)
 //   ./direct_host_check time             the tree logic's milliseconds per run beside a cheap objective (what tools/time_direct.py cannot
 //                                        separate from the GPU's batches)
+// Built with -DIBO_DIRECT_SELFCHECK (the script does) every call of the potentially-optimal test is also compared with its comparator -- the full
+// slope test on every candidate rectangle -- and a difference aborts.
 // The cases: 1 .. 12 dimensions, both evaluation schedules (per rectangle / one batch per iteration) which must agree in (fmin, xmin, samples),
 // the dimension-0 quirk on and off, degenerate boxes (lb == ub in a dimension), tiny and exhausted sample budgets, an objective with ties
 // everywhere (a constant), one with non-finite values, and an evaluator that aborts.
@@ -27,7 +29,10 @@ struct Obj {
         case 1: for (int d = 0; d < D; d++) s += std::sin(5 * x[d] + d) * std::exp(-x[d]); return -s * s;                       // wavy
         case 2: return 1.0;                                                                                                    // ties everywhere
         case 3: for (int d = 0; d < D; d++) s += x[d]; return s > 0.9 * D ? std::numeric_limits<double>::infinity() : -s;       // +inf in a corner
-        default: for (int d = 0; d < D; d++) s += std::fabs(x[d] - 0.5); return s;                                              // kink at the first centre
+        case 4: for (int d = 0; d < D; d++) s += std::fabs(x[d] - 0.5); return s;                                              // kink at the first centre
+        case 5: for (int d = 0; d < D; d++) s += (x[d] - 0.7) * (x[d] - 0.7); return -std::fmax(0.0, 0.05 * D - s);              // an EI-like surface: exact zeros (ties) over most of the box
+        case 6: return 0.0;                                                                                                    // fmin = 0: the test's other branch
+        default: for (int d = 0; d < D; d++) s += x[d]; return std::floor(4.0 * s) / 4.0;                                       // terraces: ties inside every size class
         }
     }
 };
@@ -72,7 +77,7 @@ int main(int argc, char **argv)
     }
     int ncase = 0;
     for (int D = 1; D <= 12; D++)
-        for (int kind = 0; kind < 5; kind++)
+        for (int kind = 0; kind < 8; kind++)
             for (int compat = 0; compat < 2; compat++)
                 for (int budget : {1, 7, 200, 10000}) {
                     std::vector<double> lb(D), ub(D);
