@@ -48,6 +48,14 @@ struct Pool {
     std::vector<double> cls_best;
     std::vector<int> pos;              // where rectangle j sits in members[cls[j]]
     size_t size() const { return y.size(); }
+    // a pool is kept from search to search (Workspace below): emptied, its storage -- the per-class vectors' too -- stays
+    void reset(int dims)
+    {
+        D = dims;
+        lb.clear(); ub.clear(); ctr.clear(); y.clear(); d.clear(); cls.clear(); alive.clear(); pos.clear();
+        cls_d.clear(); by_size.clear(); cls_best.clear();
+        last_dd = -1.0; last_cls = -1;
+    }
     double last_dd = -1.0; int last_cls = -1;      // (the two children of a cut have the same d: every second look-up is the one before)
     int class_of(double dd)
     {
@@ -67,7 +75,9 @@ struct Pool {
         const int c = (int)cls_d.size();
         cls_d.push_back(dd);
         by_size.insert(by_size.begin() + lo, c);
-        members.emplace_back(); argmin.emplace_back(); cls_best.push_back(0.0);
+        if ((size_t)c == members.size()) { members.emplace_back(); argmin.emplace_back(); }
+        else { members[c].clear(); argmin[c].clear(); }      // (an earlier search's vectors: their storage is reused)
+        cls_best.push_back(0.0);
         return c;
     }
     void push(const double *l, const double *u, const double *c, double yy, double dd)
@@ -337,10 +347,13 @@ void potentially_optimal(const Pool &pool, double fmin, std::vector<size_t> &out
     // denominator is <= 0 exactly when its numerator is).  NaN values fall through to the full test.
     sufmin.assign(G + 1, DBL_MAX);
     for (size_t h = G; h-- > 0;) sufmin[h] = (gy[h] < sufmin[h + 1] || gy[h] != gy[h]) ? gy[h] : sufmin[h + 1];
-    // lower hull by the monotone chain (a vertex that lies on or above the segment around it is dropped)
+    // lower hull by the monotone chain (a vertex that lies on or above the segment around it is dropped), over the classes that passed the
+    // comparison above only: they are the hull's vertices from the lowest value on (beyond it a vertex lies below everything larger), and no
+    // other class asks for witnesses
     hull.clear();
     before.assign(G, 0);
     for (size_t g = 0; g < G; g++) {
+        if (g + 1 < G && sufmin[g + 1] <= gy[g]) continue;
         while (hull.size() >= 2) {
             const int a = hull[hull.size() - 2], b = hull.back();
             if ((gy[b] - gy[a]) * (gd[g] - gd[a]) >= (gy[g] - gy[a]) * (gd[b] - gd[a])) hull.pop_back();
@@ -476,6 +489,35 @@ void potentially_optimal_ref(const Pool &pool, double fmin, std::vector<size_t> 
 
 #endif
 
+// What a search allocates -- the pool's arrays (megabytes at the default budget), a vector per size class, the divisions' vectors, the batch --
+// is kept per thread from one search to the next: a Bayesian-optimisation loop runs one search per iteration, a gallery seven per call, and
+// growing ~110 per-class vectors and a dozen arrays from nothing was a tenth of a search's tree logic.  A search that starts while this
+// thread's workspace is in use (an objective that itself calls direct) works on one of its own; a workspace beyond 64 MB is given back.
+struct Workspace {
+    Pool pool;
+    std::vector<size_t> pot, dead, redo, fix_div, fix_kid;
+    std::vector<Division> divs;
+    std::vector<double> pts, vals;
+    bool busy = false;
+};
+struct WorkspaceLease {
+    Workspace *w;
+    bool own;
+    WorkspaceLease()
+    {
+        static thread_local Workspace kept;
+        own = kept.busy;
+        w = own ? new Workspace : &kept;
+        w->busy = true;
+    }
+    ~WorkspaceLease()
+    {
+        if (own) { delete w; return; }
+        w->busy = false;
+        if (w->pool.lb.capacity() * sizeof(double) * 3 > ((size_t)64 << 20)) { Workspace fresh; std::swap(*w, fresh); }
+    }
+};
+
 }  // namespace
 
 DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, const double *ub,
@@ -483,13 +525,16 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
 {
     DirectResult res;
     const time_t start = time(nullptr);
+    WorkspaceLease lease;
+    Workspace &ws = *lease.w;
     Search S;
     S.D = D; S.compat = opt.compat; S.eval = &eval;
     S.lo.assign(lb, lb + D); S.hi.assign(ub, ub + D);
     S.fixed.resize(D); S.xmin.assign(D, 0.0);
     for (int i = 0; i < D; i++) S.fixed[i] = (lb[i] == ub[i]);
 
-    Pool pool; pool.D = D;
+    Pool &pool = ws.pool;
+    pool.reset(D);
     {   // room for every rectangle the sample budget allows (a division appends two children per cut and the shrunken rectangle): no
         // reallocation while the tree grows (the vectors' growth copies were a tenth of a run's tree logic)
         const size_t cap = (size_t)(opt.maxsample > 0 && opt.maxsample < 200000 ? opt.maxsample : 200000) * 3 / 2 + 4096;
@@ -533,9 +578,9 @@ DirectResult direct_minimize(const batch_eval_t &eval, int D, const double *lb, 
         S.apply(dv, pool);
     }
 
-    std::vector<size_t> pot, dead, redo, fix_div, fix_kid;
-    std::vector<Division> divs;
-    std::vector<double> pts, vals;
+    std::vector<size_t> &pot = ws.pot, &dead = ws.dead, &redo = ws.redo, &fix_div = ws.fix_div, &fix_kid = ws.fix_kid;
+    std::vector<Division> &divs = ws.divs;
+    std::vector<double> &pts = ws.pts, &vals = ws.vals;
     bool done = false;
     int iteration = 0;
     while (iteration < opt.maxiter && !done) {

@@ -510,7 +510,7 @@ def test_prefix_variance_bounds_the_reference_acquisitions(oracle):
 
 def test_direct_host_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     """The library's host-only C++ (DIRECT's tree logic, csrc/direct_host.cpp) built with g++ -fsanitize=address,undefined and driven
-    through 769 cases (tools/direct_host_check.cpp: 1..12 dimensions, both evaluation schedules -- which must agree in fmin, xmin and
+    through 770 cases (tools/direct_host_check.cpp: 1..12 dimensions, both evaluation schedules -- which must agree in fmin, xmin and
     samples --, fixed dimensions, sample budgets of 1 and 7, constant / infinite objectives, an aborting evaluator).  CPU only: the
     GPU build cannot run under a sanitizer on this pool."""
     import shutil, subprocess

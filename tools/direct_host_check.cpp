@@ -7,7 +7,7 @@
 // slope test on every candidate rectangle -- and a difference aborts.
 // The cases: 1 .. 12 dimensions, both evaluation schedules (per rectangle / one batch per iteration) which must agree in (fmin, xmin, samples),
 // the dimension-0 quirk on and off, degenerate boxes (lb == ub in a dimension), tiny and exhausted sample budgets, an objective with ties
-// everywhere (a constant), one with non-finite values, and an evaluator that aborts.
+// everywhere (a constant), one with non-finite values, an evaluator that aborts, and a search nested inside an objective.
 #include "direct_host.h"
 #include <chrono>
 #include <cmath>
@@ -108,6 +108,36 @@ int main(int argc, char **argv)
         ibo::DirectResult r = ibo::direct_minimize(ev, 4, lb.data(), ub.data(), opt);
         ncase++;
         CHECK(r.status == 42, "abort code %d", r.status);
+    }
+    // a search inside an objective (the per-thread workspace is in use: the inner search takes one of its own), against the same inner search run
+    // on its own and added by hand
+    {
+        std::vector<double> lb2(2, 0.0), ub2(2, 1.0), lb3(3, -1.0), ub3(3, 2.0);
+        auto inner_at = [&](double shift, int64_t *ns) {
+            ibo::batch_eval_t in = [&](const double *p, int n, double *v) -> int {
+                for (int i = 0; i < n; i++) v[i] = (p[2 * i] - shift) * (p[2 * i] - shift) + (p[2 * i + 1] - 0.25) * (p[2 * i + 1] - 0.25);
+                return 0; };
+            ibo::DirectOptions io; io.maxiter = 8; io.per_rectangle = false;
+            ibo::DirectResult r = ibo::direct_minimize(in, 2, lb2.data(), ub2.data(), io);
+            if (ns) *ns = r.nsamples;
+            return r.fmin;
+        };
+        std::vector<double> seen_x, seen_v;
+        ibo::batch_eval_t outer = [&](const double *p, int n, double *v) -> int {
+            for (int i = 0; i < n; i++) {
+                const double sh = 0.5 + 0.1 * p[3 * i];
+                v[i] = inner_at(sh, nullptr) + std::fabs(p[3 * i + 1] - 0.4) + p[3 * i + 2] * p[3 * i + 2];
+                seen_x.push_back(sh); seen_v.push_back(v[i] - std::fabs(p[3 * i + 1] - 0.4) - p[3 * i + 2] * p[3 * i + 2]);
+            }
+            return 0; };
+        ibo::DirectOptions oo; oo.maxiter = 6; oo.per_rectangle = false;
+        ibo::DirectResult r = ibo::direct_minimize(outer, 3, lb3.data(), ub3.data(), oo);
+        ncase++;
+        CHECK(r.status == 0 && r.nsamples > 10, "nested search: status %d, %ld samples", r.status, (long)r.nsamples);
+        for (size_t i = 0; i < seen_x.size(); i += 7) {
+            const double alone = inner_at(seen_x[i], nullptr);
+            CHECK(alone == seen_v[i] || std::fabs(alone - seen_v[i]) <= 1e-15, "nested search: inner result %.17g inside against %.17g alone", seen_v[i], alone);
+        }
     }
     printf("%d cases, %d failure(s)\n", ncase, g_fail);
     return g_fail ? 1 : 0;
