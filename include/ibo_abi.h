@@ -392,6 +392,8 @@ int ibo_trim(int device);
  * Kernel.derivative(X, h) builds it (ego/gaussianprocess/kernel.py).  modes[h]: 0 SE-ARD length
  * scale of dimension dims[h]; 1 SE-iso length scale; 2 signal magnitude (2K); 3 Matern-3/2 and
  * 4 Matern-5/2 length scale.  grad_host receives ngrad values (1 <= ngrad <= 65; 17 per pass of the gradient kernel).
+ * A learning loop calls this dozens of times with one data set and another theta: X and Y stay on the device between calls and go up again
+ * only when their CONTENT differs from the last call's (compared on the host; ibo_trim forgets them).
  */
 int ibo_nlml_grad(int device, int ktype, int N, int D, const double *X_host, const double *Y_host,
                   const double *hyper_host, int nhyper, double sf2, double noise,
