@@ -64,16 +64,14 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
     // from ~8192 candidates on the panel-split kernel's tiles fill the chip by themselves and it is the faster one).
     // They beat the GEMV kernel down to a single candidate (N = 2048: 22 us against 87; N = 1024: 16 against 38), which
     // is left with the models they do not take (no dot form, rows beyond sweep2's LDS budget).
-    // ("sweep_path" 4: the automatic choice, but a small batch on a model of up to 128 rows as two launches -- the comparator of tiny_batch_kernel)
-    const int force_path = g_force_path == 4 ? 0 : g_force_path.load();
-    const bool small2_ok = force_path == 0 && M <= 4096 && a.dot_form && sweep2_fits(a.Npad);
-    bool gemv = (force_path == 1) || (force_path == 0 && M <= 16 && !small2_ok);
+    const bool small2_ok = g_force_path == 0 && M <= 4096 && a.dot_form && sweep2_fits(a.Npad);
+    bool gemv = (g_force_path == 1) || (g_force_path == 0 && M <= 16 && !small2_ok);
     // small batches: spread the IBO_SPLIT_PANEL-row panels over the grid too (one tile per 64 candidates alone
     // would leave most of the 256 CUs idle); above ~128 tiles the plain kernel fills the chip
     // (4097 .. 8192 candidates are at most 256 tiles of the large-batch kernel -- one round of the chip, 134 us at N = 1024 and
     // 495 us at N = 2048 whatever their number, where the panel-split kernel takes 142 .. 221 and 478 .. 842 us)
     const bool sweep2_ok = a.dot_form && sweep2_fits(a.Npad);
-    bool split = !gemv && (force_path == 3 || (force_path == 0 && ntiles * 2 <= 256 && !(sweep2_ok && M > 4096)));
+    bool split = !gemv && (g_force_path == 3 || (g_force_path == 0 && ntiles * 2 <= 256 && !(sweep2_ok && M > 4096)));
     const bool small2 = split && small2_ok;
     if (small2) {
         IBO_TRY(exp_table(g->device, &a.exp_tab));
@@ -90,8 +88,8 @@ static int run_sweep(ibo_gp *g, int64_t M, const double *cand_dev, int acq, doub
             a.done_flag = g->done_flag; a.done_seq = ++g->done_seq; a.done_count = g->done_count.p;
             g->signal_pending = true;
         }
-        KERNEL_TRY(launch_sweep_small(a, g->small_ws.p, s, timed ? g->ev0 : nullptr, timed ? g->ev1 : nullptr, g_force_path == 4));
-        g->sweep_kernel = small_batch_is_one_launch(a) && g_force_path != 4 ? "tiny_batch_kernel" : "wk_small_kernel";
+        KERNEL_TRY(launch_sweep_small(a, g->small_ws.p, s, timed ? g->ev0 : nullptr, timed ? g->ev1 : nullptr));
+        g->sweep_kernel = "wk_small_kernel";
     } else if (split) {
         IBO_TRY(g->qpart.ensure((size_t)((g->Npad + IBO_SPLIT_PANEL - 1) / IBO_SPLIT_PANEL) * M)); IBO_TRY(g->mupart.ensure(2 * (size_t)M));
         a.qpart = g->qpart.p; a.mupart = g->mupart.p;

@@ -236,8 +236,7 @@ int sweep2_part_levels(int Npad, int *h);        // the row splits h[0] < h[1] <
 bool sweep2_fits(int Npad);
 bool sweep2_rank1_fits(int Npad, int D);
 // small batches (16 < M <= 8192), dot form: k* to HBM, one workgroup per 16-row block of W, fixed-order sums (small2.hip)
-bool small_batch_is_one_launch(const SweepArgs &a);
-int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool two_launches = false);   // two_launches: never the one-launch kernel of models up to 128 rows (the test's comparator)
+int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 size_t small_sweep_workspace(int Npad, int64_t M);
 // the resident evaluation server of ibo_direct_max (small2.hip): mailbox layout in doubles -- [0] seq, [1] M, [2] done, [3] state, [8 ..) candidates
 #define IBO_SRV_BOX_CAND 8

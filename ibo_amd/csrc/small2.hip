@@ -441,154 +441,6 @@ static int launch_wkl_small(const SweepArgs &a, double *qpart, double *mupart, i
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// ONE launch for a batch on a model of at most 128 observations (the first hundred iterations of every optimisation loop, the reference's own
-// test sizes): wkl_small_kernel + small_finish_kernel are two launches whose second costs more than both kernels' work (16 us per DIRECT batch
-// at N = 64 against this box's floor of 6 for one launch to its flag).  Here one workgroup takes 64 candidates -- a finish item, two 32-candidate
-// tiles -- through all of it.  Phase A: wave (tile, row tile rt) makes k* of its 16 rows for the tile's two candidate blocks by the exponent GEMM
-// (once, where every row-block's workgroup of wkl_small_kernel makes it again) and that row tile's part of the two mean dot products;
-// k* stays in LDS in B-fragment order.  Phase B: wave (tile, row-block g) forms V_g = sum_rt W[g][rt] k*[rt] -- each term its own chain of four
-// MFMAs from zero, the terms added in ascending rt --, squares, sums over the 16 rows.  Phase C: wave 0 is small_finish_body's tail.
-// Every number is formed from the same operands by the same operations in the same order as in the two launches (a workgroup of wkl_small_kernel
-// gives row tile rt to wave rt and adds the waves' tiles in wave order; the finish kernel's eight partial sums are one row-block each up to 128
-// rows): the values are THE SAME BITS (tested), so which path a batch takes is a matter of speed only.
-template <int FAM, int KA4>
-__global__ __launch_bounds__(SM_NW * 64) void tiny_batch_kernel(InlineCand ic, SweepArgs a, int inlined)
-{
-    constexpr int KA = 4 * KA4;
-    __shared__ double lds_c[2][SM_TC * (KA + 1)];
-    __shared__ double lds_tab[2048];
-    __shared__ double lds_k[2][8][2][4][64];             // k*: [tile][row tile][candidate block][r][lane]
-    __shared__ double lds_m[2][2][8][2][16];             // mean parts: [which][tile][row tile][candidate block][candidate]
-    __shared__ double lds_q[8][64];                      // [row-block][candidate of the item]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nrb = a.Npad >> 4, nk8 = a.Npad >> 3, item = blockIdx.x;
-    const int expf = inlined >> 8; inlined &= 255;
-    const double *cands = inlined ? (const double *)__builtin_amdgcn_kernarg_segment_ptr() : nullptr;
-    const int ntile = ((int64_t)(2 * item + 1) * SM_TC < a.M) ? 2 : 1;          // (the item's second tile may lie beyond the batch)
-    // everything a wave will want from memory is requested now, behind the candidates: the table, its row tile's X fragments and alpha values
-    // (phase A), its row-block's W fragments (phase B) -- their round trips pass while the candidates are staged
-    const int wt = wave >> 3, wr = wave & 7;              // this wave's tile and row tile (phase A) / row-block (phase B)
-    const bool wact = wt < ntile && wr < nrb;
-    for (int t = 0; t < ntile; t++) s2_stage_candidates_load<FAM, SM_TC, KA, SM_NW * 64>(a, (int64_t)(2 * item + t) * SM_TC, lds_c[t], cands);
-    const double tab0 = a.exp_tab[tid], tab1 = a.exp_tab[tid + 1024];
-    double xav[KA4], aYv[4], a1vv[4];
-    double2 w[8][2];
-    if (wact) {
-#pragma unroll
-        for (int s = 0; s < KA4; s++) xav[s] = a.XA[(size_t)wr * KA4 * 64 + s * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { aYv[r] = a.alphaY[16 * wr + 4 * r + (lane >> 4)]; a1vv[r] = a.alpha1[16 * wr + 4 * r + (lane >> 4)]; }
-        const double2 *Wp2 = (const double2 *)a.Wp + (size_t)wr * nk8 * 64 + lane;
-#pragma unroll
-        for (int rt = 0; rt < 8; rt++)
-            if (rt <= wr) { w[rt][0] = Wp2[(size_t)(2 * rt) * 64]; w[rt][1] = Wp2[(size_t)(2 * rt + 1) * 64]; }
-    }
-    __syncthreads();
-    for (int t = 0; t < ntile; t++) s2_stage_candidates_finish<FAM, SM_TC, KA>(a, lds_c[t]);
-    lds_tab[tid] = tab0;
-    lds_tab[tid + 1024] = tab1;
-    __syncthreads();
-    {
-        const int t = wt, rt = wr;
-        if (wact && !(expf & 2)) {
-            const double *cfrag0 = &lds_c[t][(lane & 15) * (KA + 1) + (lane >> 4)], *cfrag1 = cfrag0 + 16 * (KA + 1);
-            d4_t y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < KA4; s++) { y0 = mfma_f64(xav[s], cfrag0[4 * s], y0); y1 = mfma_f64(xav[s], cfrag1[4 * s], y1); }
-            double mY0 = 0.0, mY1 = 0.0, m10 = 0.0, m11 = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double k0 = s2_kstar<FAM>(y0[r], a.kp.sf2, lds_tab), k1 = s2_kstar<FAM>(y1[r], a.kp.sf2, lds_tab);
-                lds_k[t][rt][0][r][lane] = k0;
-                lds_k[t][rt][1][r][lane] = k1;
-                const double aY = aYv[r], a1v = a1vv[r];
-                mY0 = fma(aY, k0, mY0); mY1 = fma(aY, k1, mY1); m10 = fma(a1v, k0, m10); m11 = fma(a1v, k1, m11);
-            }
-            mY0 += __shfl_xor(mY0, 16); mY0 += __shfl_xor(mY0, 32); mY1 += __shfl_xor(mY1, 16); mY1 += __shfl_xor(mY1, 32);
-            m10 += __shfl_xor(m10, 16); m10 += __shfl_xor(m10, 32); m11 += __shfl_xor(m11, 16); m11 += __shfl_xor(m11, 32);
-            if (lane < 16) { lds_m[0][t][rt][0][lane] = mY0; lds_m[0][t][rt][1][lane] = mY1; lds_m[1][t][rt][0][lane] = m10; lds_m[1][t][rt][1][lane] = m11; }
-        }
-    }
-    __syncthreads();
-    {
-        const int t = wt, g = wr;
-        if (wact && !(expf & 4)) {
-            d4_t v0 = {0.0, 0.0, 0.0, 0.0}, v1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int rt = 0; rt < 8; rt++)
-                if (rt <= g) {
-                    const double wk[4] = {w[rt][0].x, w[rt][0].y, w[rt][1].x, w[rt][1].y};
-                    d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { acc0 = mfma_f64(wk[r], lds_k[t][rt][0][r][lane], acc0); acc1 = mfma_f64(wk[r], lds_k[t][rt][1][r][lane], acc1); }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { v0[r] += acc0[r]; v1[r] += acc1[r]; }
-                }
-            // the 16 rows of the block, row (lane >> 4) + 4 r in lane's register r, added in row order per candidate lane & 15
-            double q0 = 0.0, q1 = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double s0 = v0[r] * v0[r], s1 = v1[r] * v1[r];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { q0 += __shfl(s0, (lane & 15) + 16 * j); q1 += __shfl(s1, (lane & 15) + 16 * j); }
-            }
-            if (lane < 16) { lds_q[g][32 * t + lane] = q0; lds_q[g][32 * t + 16 + lane] = q1; }
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const int64_t li = (int64_t)item * 64 + lane;
-    const bool valid = li < a.M;
-    const int64_t ci = valid ? li : a.M - 1;
-    const int lc = (int)(ci - (int64_t)item * 64);        // (the item's first candidate exists: 0 <= lc < 64)
-    double q = 0.0, my = 0.0, m1 = 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; u++) q += (u < nrb) ? lds_q[u][lc] : 0.0;
-    for (int rt = 0; rt < nrb; rt++) { my += lds_m[0][lc >> 5][rt][(lc >> 4) & 1][lc & 15]; m1 += lds_m[1][lc >> 5][rt][(lc >> 4) & 1][lc & 15]; }
-    bool excl;
-    double val = (expf & 8) ? q + my + m1 : s2_finish<false>(a, a.cand + ci * a.kp.D, q, my, m1, li, valid, excl);
-    if ((expf & 8) && valid && a.out_acq) a.out_acq[li] = val;
-    int64_t idx = a.index_base + li;
-    if (!valid || excl || !(val == val)) { val = -INFINITY; idx = INT64_MAX; }
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(val, o);
-        const int64_t oi = __shfl_xor(idx, o);
-        if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
-    }
-    if (lane == 0 && a.part_val) { a.part_val[item] = val; a.part_idx[item] = idx; }
-    if (a.done_flag) {                                   // (as small_finish_kernel)
-        __threadfence_system();
-        if (gridDim.x == 1) {
-            if (lane == 0) *(volatile unsigned long long *)a.done_flag = a.done_seq;
-        } else if (lane == 0) {
-            if (atomicAdd(a.done_count, 1u) == gridDim.x - 1) {
-                *a.done_count = 0;
-                __threadfence_system();
-                *(volatile unsigned long long *)a.done_flag = a.done_seq;
-            }
-        }
-    }
-}
-template <int FAM>
-static int launch_tiny_batch(const SweepArgs &a, int nitems, hipStream_t s)
-{
-    InlineCand ic;
-    int inl = 0;
-    if (a.cand_host && a.M * a.kp.D <= SM_INLINE) {
-        memcpy(ic.v, a.cand_host, sizeof(double) * (size_t)(a.M * a.kp.D));
-        inl = 1;
-    }
-    if (getenv("IBO_EXP")) inl |= atoi(getenv("IBO_EXP")) << 8;
-    switch ((a.kp.D + 2 + 3) / 4) {
-    case 1: hipLaunchKernelGGL((tiny_batch_kernel<FAM, 1>), dim3(nitems), dim3(SM_NW * 64), 0, s, ic, a, inl); break;
-    case 2: hipLaunchKernelGGL((tiny_batch_kernel<FAM, 2>), dim3(nitems), dim3(SM_NW * 64), 0, s, ic, a, inl); break;
-    default: hipLaunchKernelGGL((tiny_batch_kernel<FAM, 3>), dim3(nitems), dim3(SM_NW * 64), 0, s, ic, a, inl); break;
-    }
-    return (int)hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------------
 // The RESIDENT evaluation server of ibo_direct_max (round 6).  DIRECT hands the objective ~53 dependent batches of a few dozen to a few
 // hundred points; as launches a batch costs ~25 us of which ~4 are kernel execution (10 us in three launch calls, 6 us from an empty launch
 // to its flag, 2.5 us per further launch: profiles/r05_direct_batch_floor.txt), whatever the model's size (maximizeEI: 1.37 ms at N = 64).
@@ -802,12 +654,7 @@ size_t small_sweep_workspace(int Npad, int64_t M)
     return Mp * NA128 + (size_t)(Npad / 16) * Mp + 2 * (NA128 / 128) * Mp;
 }
 
-// a batch of at most 128 candidates on a model of at most 128 observations in at most 10 dimensions: one launch (tiny_batch_kernel)
-bool small_batch_is_one_launch(const SweepArgs &a)
-{
-    return (a.M + SM_TC - 1) / SM_TC <= 4 && a.Npad / 16 <= 8 && a.kp.D <= 10;
-}
-int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool two_launches)
+int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     const int Mp = (int)((a.M + SM_TC - 1) / SM_TC) * SM_TC, ctiles = Mp / SM_TC;
     const int NA128 = (a.Npad + 127) & ~127, nst = NA128 / 128, nrb = a.Npad / 16;
@@ -821,16 +668,6 @@ int launch_sweep_small(const SweepArgs &a, double *ws, hipStream_t s, hipEvent_t
     // its 14-instruction exp() chains are then the throughput of the 128 CUs it occupies.  (A stage-by-stage fusion through an
     // LDS stage and a barrier per 128 rows was measured too: 0.6 us per stage, slower from N = 512 on, and removed.)
     const bool local = ctiles <= 4 && nrb <= 32 && a.kp.D <= 10;
-    // up to 128 observations: the whole batch in one launch (tiny_batch_kernel: the same bits; ibo_set_option("sweep_path", 4) keeps the two launches -- the test's comparator)
-    if (small_batch_is_one_launch(a) && !two_launches) {
-        const int nitems = (int)((a.M + 63) / 64);
-        if (e0 && e1) (void)hipEventRecord(e1, s);
-        if (a.kp.family == FAM_SE) rc = launch_tiny_batch<FAM_SE>(a, nitems, s);
-        else if (a.kp.family == FAM_M3) rc = launch_tiny_batch<FAM_M3>(a, nitems, s);
-        else rc = launch_tiny_batch<FAM_M5>(a, nitems, s);
-        if (rc) return rc;
-        return launch_argmax_final(a, nitems, s);
-    }
     if (local) {
         const dim3 gl(ctiles, nrb);
         if (a.kp.family == FAM_SE) rc = launch_wkl_small<FAM_SE>(a, qpart, mupart, Mp, gl, s);

@@ -104,36 +104,6 @@ __device__ __forceinline__ double s2_kstar(double y, double sf2, const double *t
 // length scales from the origin (hence > 450 from every observation: |x~| <= 316 where the dot form is in use) has k* = 0
 // exactly; it is pulled in to that radius, where k* is still 0, so that the exponent stays within what s2_exp's integer
 // arithmetic covers (|y| < 7e5).  Called by the whole workgroup; ends with a barrier.
-// (the two halves of the staging, for a caller that puts other loads and its own barrier between them: small2.hip's tiny_batch_kernel)
-template <int FAM, int TCAND, int KA, int NT, bool SYS = false>
-__device__ __forceinline__ void s2_stage_candidates_load(const SweepArgs &a, int64_t tile0, double *lds_c, const double *cand = nullptr, int64_t Mo = -1)
-{
-    const int tid = threadIdx.x, D = a.kp.D;
-    const int64_t Mtot = Mo >= 0 ? Mo : a.M;          // (a resident kernel's batches differ in size: the caller says)
-    if (!cand) cand = a.cand;
-    for (int e = tid; e < TCAND * KA; e += NT) {
-        const int c = e / KA, col = e - c * KA;
-        int64_t gi = tile0 + c;
-        if (gi > Mtot - 1) gi = Mtot - 1;
-        lds_c[c * (KA + 1) + col] = (col < D) ? (SYS ? __hip_atomic_load(cand + gi * D + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : cand[gi * D + col]) * a.kp.sw[col]
-                                              : (col == D ? 1.0 : 0.0);
-    }
-}
-template <int FAM, int TCAND, int KA>
-__device__ __forceinline__ void s2_stage_candidates_finish(const SweepArgs &a, double *lds_c)
-{
-    const int tid = threadIdx.x, D = a.kp.D;
-    if (tid < TCAND) {
-        double n2 = 0.0;
-        for (int d = 0; d < D; d++) { const double v = lds_c[tid * (KA + 1) + d]; n2 = fma(v, v, n2); }
-        if (n2 > 6e5) {
-            const double sc = sqrt(6e5 / n2);
-            for (int d = 0; d < D; d++) lds_c[tid * (KA + 1) + d] *= sc;
-            n2 = 6e5;
-        }
-        lds_c[tid * (KA + 1) + D + 1] = fma(-0.5, n2, FAM == FAM_SE ? a.log_sf2 : 0.0);
-    }
-}
 template <int FAM, int TCAND, int KA, int NT, bool SYS = false>
 __device__ __forceinline__ void s2_stage_candidates(const SweepArgs &a, int64_t tile0, double *lds_c, const double *cand = nullptr, int64_t Mo = -1)
 {

@@ -456,7 +456,7 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
             # (up to 512 observations and 128 candidates the wave-local kernel runs -- k* made by the wave that multiplies it -- beyond,
             # the separate k* / product kernels: the cases cover both)
             r = sweep(GP, cand, outputs=("mu", "s2", "acq"))
-            assert r["kernel"] == ("tiny_batch_kernel" if N <= 128 and M <= 128 and D <= 10 else "wk_small_kernel")
+            assert r["kernel"] == "wk_small_kernel"
             opt(b"sweep_path", 3); r0 = sweep(GP, cand, outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
             assert r0["kernel"] == "sweep_mfma_kernel<split>" and r0["best_idx"] == r["best_idx"]
             opt(b"sweep_path", 1); rg = sweep(GP, cand[:40], outputs=("mu", "s2", "acq")); opt(b"sweep_path", 0)
@@ -474,66 +474,6 @@ def test_small_batch_kernels_against_oracle_and_the_other_kernels(ibo, oracle):
             runs.append(gpuDirectGP(GP, [[0., 1.]] * 3, 30, 30, 10000, acqfunc='ei', xi=.01, return_samples=True))
         for v, x, ns in runs[1:]:
             assert ns == runs[0][2] and np.array_equal(x, runs[0][1]); close(v, runs[0][0], rtol=1e-9)
-    finally:
-        opt(b"sweep_path", 0)
-
-
-def test_one_launch_batch_on_models_up_to_128_rows_has_the_bits_of_the_two_launches(ibo, oracle):
-    """small2.hip tiny_batch_kernel: a batch of up to 128 candidates on a model of up to 128 observations in ONE launch (k* once per row tile,
-    the products' terms added in row-tile order, the finish in the same workgroup) against wkl_small_kernel + small_finish_kernel
-    (ibo_set_option("sweep_path", 4)): mean, variance, acquisition and the arg-max BIT FOR BIT -- every kernel family, 1..10 dimensions, 1..128
-    rows (one row-block with pad rows, exactly eight, the first size beyond: 129 rows take the two launches either way), batches that end inside
-    a tile, on a tile, on an item and beyond one, a mean prior, exclusion balls -- and against the oracle; DIRECT takes the same samples"""
-    from ibo_amd import _lib
-    from ibo_amd.gaussianprocess import GaussianProcess, prior as P
-    from ibo_amd.gaussianprocess import kernel as K
-    from ibo_amd.acquisition import sweep, gpuDirectGP
-    opt = lambda k, v: _lib.check(_lib.lib.ibo_set_option(k, v))
-    cases = []
-    for N in (1, 5, 16, 17, 48, 64, 100, 127, 128, 129):
-        for D, kern, ok in ((1, K.GaussianKernel_iso([.4]), ("iso", [.4])), (2, K.GaussianKernel_ard([.3, .5]), ("ard", [.3, .5])),
-                            (3, K.MaternKernel3([.6, 1.0]), ("m3", [.6, 1.0])), (6, K.MaternKernel5([.5, 1.0]), ("m5", [.5, 1.0])),
-                            (10, K.GaussianKernel_ard(list(np.linspace(.5, 1.4, 10))), ("ard", list(np.linspace(.5, 1.4, 10))))):
-            cases.append((N, D, kern, ok))
-    try:
-        nbits = 0
-        for ci, (N, D, kern, (okind, ohyp)) in enumerate(cases):
-            X, Y = synth(400 + N + D, N, D)
-            GP = GaussianProcess(kern, X, Y, noise=.05)
-            ogp = oracle.GP(oracle.Kern(okind, ohyp), X, Y, noise=.05)
-            for M in ((1, 31, 64, 128) if ci % 2 else (2, 32, 33, 65, 100)):
-                cand = np.random.RandomState(N * 131 + M).rand(M, D); cand[M // 2] = X[N // 2]
-                kw = dict(outputs=("mu", "s2", "acq"))
-                if ci % 5 == 3 and M > 2: kw.update(exclude=cand[:2], exclude_radius=.15)
-                for acq in (("ei", dict(xi=.01)), ("ucb", dict(parm=1.3))) if M in (33, 64) else (("ei", dict(xi=.01)),):
-                    akw = dict(kw, acq=acq[0], **acq[1])
-                    opt(b"sweep_path", 0); r1 = sweep(GP, cand, **akw)
-                    opt(b"sweep_path", 4); r2 = sweep(GP, cand, **akw)
-                    opt(b"sweep_path", 0)
-                    assert r1["kernel"] == ("tiny_batch_kernel" if N <= 128 else "wk_small_kernel") and r2["kernel"] == "wk_small_kernel"
-                    for k in ("mu", "s2", "acq"):
-                        assert np.array_equal(np.asarray(r1[k]).view(np.int64), np.asarray(r2[k]).view(np.int64)), (N, D, M, k)
-                    assert r1["best_idx"] == r2["best_idx"] and (r1["best_val"] == r2["best_val"] or (np.isnan(r1["best_val"]) and np.isnan(r2["best_val"])))
-                    nbits += 3 * M
-                if M in (32, 100, 128):
-                    idx = np.arange(0, M, max(1, M // 12))
-                    o = oracle.sweep_native(ogp, cand[idx], oracle.ACQ_EI, .01)
-                    close(r1["mu"][idx], o["mu"], atol=1e-9); close(r1["s2"][idx], o["s2"], rtol=1e-7, atol=1e-10); close(r1["acq"][idx], o["acq"], atol=ACQ_ATOL)
-        assert nbits > 15000
-        # a mean prior rides in the finish; DIRECT on either path
-        X, Y = synth(77, 90, 2)
-        pr = P.RBFNMeanPrior(); pr.train(X, Y, bounds=[[0., 1.]] * 2, k=5, seed=3)
-        GP = GaussianProcess(K.GaussianKernel_ard([.3, .4]), X, Y, noise=.05, prior=pr)
-        cand = np.random.RandomState(5).rand(77, 2)
-        opt(b"sweep_path", 0); r1 = sweep(GP, cand, outputs=("mu", "s2", "acq"))
-        opt(b"sweep_path", 4); r2 = sweep(GP, cand, outputs=("mu", "s2", "acq"))
-        for k in ("mu", "s2", "acq"):
-            assert np.array_equal(np.asarray(r1[k]).view(np.int64), np.asarray(r2[k]).view(np.int64)), k
-        runs = []
-        for path in (0, 4):
-            opt(b"sweep_path", path)
-            runs.append(gpuDirectGP(GP, [[0., 1.]] * 2, 40, 30, 10000, acqfunc='ei', xi=.01, return_samples=True))
-        assert runs[0][2] == runs[1][2] and np.array_equal(runs[0][1], runs[1][1]) and runs[0][0] == runs[1][0]
     finally:
         opt(b"sweep_path", 0)
 
