@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 rows = []
 units = [("sweep2_fam", ["-DS2_FAM=FAM_%s" % fam, "-DS2_PIECE=%d" % pc]) for fam in ("SE", "M3", "M5") for pc in (0, 1)]
-units += [(f, []) for f in ("sweep2", "sweep", "small2", "update3", "linalg", "assemble", "legacy", "comm", "abi")]
+units += [(f, []) for f in ("sweep2", "sweep", "small2", "update3", "linalg", "assemble", "legacy", "comm", "abi_core", "abi_fit", "abi_sweep", "abi_nlml", "abi_legacy")]
 for f, defs in units:
     out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage"] + defs +
                          ["-c", os.path.join(root, "ibo_amd", "csrc", f + ".hip"), "-o", "/dev/null"], capture_output=True, text=True).stderr
