@@ -177,6 +177,38 @@ def test_direct_grouped_selection_matches_the_all_pairs_reference(oracle):
         assert ns == ref[2] and fm == ref[0] and np.array_equal(xm, ref[1])
 
 
+def test_direct_against_the_compiled_reference_on_random_objectives(oracle):
+    """csrc/direct_host.cpp (per-class decisions, hull witnesses, one batch per iteration) against the reference's OWN compiled search
+    (oracle/_ref/libego.so, cpp/direct.cpp:329-581) on 160 random objectives in 1..7 dimensions -- smooth, rippled, terraced (ties inside
+    every size class), clipped at zero like an expected improvement (exact zeros over most of the box), shifted boxes, boxes with a fixed dimension -- at two budgets:
+    the same minimum, the same point, the same number of samples, value for value"""
+    if not oracle.RefLib.available():
+        pytest.skip("oracle/_ref/libego.so not built")
+    from ibo_amd.utils.optimize import cdirect
+    ref = oracle.RefLib()
+    rs = np.random.RandomState(4242)
+    ncase = 0
+    for case in range(160):
+        D = 1 + case % 7
+        c = rs.rand(D); w = rs.uniform(.5, 3, D); ph = rs.rand(D) * 6
+        kind = case % 4
+        if kind == 0: f = lambda x, c=c, w=w: float(np.sum(w * (x - c) ** 2))
+        elif kind == 1: f = lambda x, c=c, w=w, ph=ph: float(np.sum(w * (x - c) ** 2) + .3 * np.sum(np.sin(9 * x + ph)))
+        elif kind == 2: f = lambda x, c=c: float(np.floor(6 * np.sum(np.abs(x - c))) / 6)
+        else: f = lambda x, c=c, D=D: -max(0.0, .04 * D - float(np.sum((x - c) ** 2)))
+        lo = rs.uniform(-2, 0, D); b = [[float(l), float(l + rs.uniform(.5, 3))] for l in lo]
+        if case % 7 == 3: b = [[0., 1.]] * D
+        if D >= 2 and case % 11 == 5: b[case % D] = [b[case % D][0]] * 2            # a fixed dimension (dimension 0 among them: the stall)
+        # (a fixed dimension maps to 0: the compiled reference does not survive an objective that returns NaN)
+        fb = (lambda x, f=f, b=b: f((np.asarray(x) - np.array([q[0] for q in b])) / np.array([(q[1] - q[0]) or 1.0 for q in b])))
+        for maxiter, maxsample in ((6, 20000), (28, 1500)):
+            fm, xm, ns = cdirect(fb, b, maxiter=maxiter, maxsample=maxsample, return_samples=True)
+            r = ref.direct(fb, b, maxiter=maxiter, maxsample=maxsample)
+            assert ns == r[2] and fm == r[0] and np.array_equal(xm, r[1]), (case, D, kind, maxiter, ns, r[2])
+            ncase += 1
+    assert ncase == 320
+
+
 def test_direct_one_batch_per_iteration_equals_the_sequential_search(oracle):
     """the schedule ibo_direct_max runs the GPU objective under: probes and GUESSED child centres of all potentially-optimal
     rectangles in one batch per iteration, the guesses verified bit for bit against the centres the division produces and
